@@ -1,0 +1,152 @@
+#!/usr/bin/env python3
+"""Headline benchmark: log-likelihood evaluations per second on synthetic track batches.
+
+Workload at N GPUs (weak scaling): every rank holds BASELINE.json configs[1] - 1e6 tracks, 2 states, length 30,
+2-D, nb_substeps=1, frame_len=6 - resident in HBM; a "step" is one evaluation of -sum(LL) over all ranks' tracks
+(local kernel + one all-reduce of the fp64 scalar over RCCL).  `value` = (N x 1e6-track evaluations) / s, i.e. in
+units of "1e6-track log-likelihood evaluations per second".
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_TRACKS, LEN, DIMS, S, NS, FRAME = 1000000, 30, 2, 2, 1, 6
+DS_COEF, TRMAT, FS, LOCERR, DT, PBL, CELL = [0.0, 0.25], [[0.9, 0.1], [0.1, 0.9]], [0.6, 0.4], 0.02, 0.02, 0.1, [1.0]
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+FP64_VALU_PEAK_TF = 78.6   # 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
+
+
+def cpu_baseline_worker(args):
+    from oracle import oracle_np as O
+    Cs, model = args
+    t0 = time.perf_counter()
+    O.proba_cs(Cs, *model)
+    return time.perf_counter() - t0
+
+
+def cpu_baseline(sample_tracks_per_core=4000):
+    """numpy port (oracle/oracle_np.py, parity-pinned to the reference) on a bounded sample, all host cores."""
+    import multiprocessing as mp
+    from extrack_amd import synth
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    n = sample_tracks_per_core * cores
+    Cs = synth.brownian_tracks(n, LEN, DS_COEF, TRMAT, FS, LOCERR, DT, DIMS, seed=123)
+    ds = np.sqrt(2 * np.array(DS_COEF) * DT)
+    T = 1 - np.exp(-np.array(TRMAT)); T[np.arange(S), np.arange(S)] = 0; T[np.arange(S), np.arange(S)] = 1 - T.sum(1)
+    model = (np.array([[[LOCERR]]]), ds, np.array(FS), T, PBL, 0, CELL, NS, FRAME, LEN)
+    chunks = [(Cs[a:a + 2000], model) for a in range(0, n, 2000)]   # 2000 = the reference's chunk (tracking.py:991)
+    ctx = mp.get_context("fork")
+    t0 = time.perf_counter()
+    with ctx.Pool(cores) as pool:
+        pool.map(cpu_baseline_worker, chunks)
+    wall = time.perf_counter() - t0
+    tps = n / wall
+    return {"value": tps / N_TRACKS, "unit": "1e6-track LL evals/s", "cores": cores, "kind": "port",
+            "sample": "%d tracks (len %d, 2 states, frame_len %d) in 2000-track chunks over a %d-process fork pool, "
+                      "numpy oracle; %.0f tracks/s, scaled linearly to 1e6 tracks" % (n, LEN, FRAME, cores, tps),
+            "tracks_per_s": tps}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--tracks", type=int, default=N_TRACKS, help="tracks per GPU (default = the BASELINE config)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    import torch
+    from extrack_amd import synth, tracking
+    from extrack_amd.lmfit_compat import Parameters
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % a.gpus)
+    torch.cuda.set_device(local)
+    comm = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        from extrack_amd.distributed import Comm
+        comm = Comm()
+
+    # synthetic data of the BASELINE shape, resident in HBM before the timed region
+    Cs = synth.brownian_tracks(a.tracks, LEN, DS_COEF, TRMAT, FS, LOCERR, DT, DIMS, seed=rank)
+    ts = tracking.TrackSet([Cs], device=local, min_len=LEN, max_len=LEN)
+    del Cs
+    p = Parameters()
+    for k, v in dict(D0=DS_COEF[0], D1=DS_COEF[1], LocErr=LOCERR, F0=FS[0], F1=FS[1], p01=0.1, p10=0.1, pBL=PBL).items():
+        p.add(k, value=v)
+    model = tracking._objective_model(p, ts, DT, CELL, None, S, NS, FRAME, 1)
+
+    def step():
+        return ts.loglik(model) if comm is None else comm.allreduce_loglik(ts, model)
+
+    def barrier():
+        if comm is not None:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        val = step()
+    kernel_ms = []
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        val = step()
+        kernel_ms.append(ts.ctx.last_kernel_ms())
+    barrier()
+    dt_loc = time.perf_counter() - t0
+    if comm is not None:
+        dt_all = comm.allreduce_scalar(dt_loc, "max")
+    else:
+        dt_all = dt_loc
+    if rank != 0:
+        return
+    ms_per_step = dt_all / a.steps * 1e3
+    evals_per_s = world * (a.tracks / N_TRACKS) * a.steps / dt_all
+    k_ms = float(np.mean(kernel_ms))
+    alg_bytes = a.tracks * LEN * DIMS * 8          # one read of the track, LL reduced in-kernel
+    achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("bytes_per_launch")
+        except Exception:
+            traffic = None
+    out = {
+        "metric": "log-likelihood evals/sec (1e6 tracks, 2-state, len=30)", "value": evals_per_s, "unit": "1e6-track LL evals/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: %d tracks/GPU, 2 states, len=30, 2-D, nb_substeps=1, frame_len=6, "
+                               "single log-likelihood eval per step" % a.tracks,
+                   "tracks_per_gpu": a.tracks, "parallelism": "dp%d" % world, "launch": ts.ctx.last_launch_info()},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": traffic, "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                     "note": "the recursion is FP64-VALU bound, not HBM bound (arithmetic intensity ~1e2 flop/B, DESIGN.md)"},
+        "neg_loglik": -val,
+    }
+    if not a.no_cpu_baseline and world == 1:
+        out["cpu_baseline"] = cpu_baseline()
+        out["speedup_vs_cpu_baseline"] = evals_per_s / out["cpu_baseline"]["value"]
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

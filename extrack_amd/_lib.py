@@ -1,0 +1,215 @@
+"""ctypes binding of libextrack_hip.so (C ABI declared in include/extrack_hip.h).
+
+There is deliberately NO CPU fallback: if the shared library or a gfx950 device is missing the
+functions here raise, loudly.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libextrack_hip.so")
+
+EXPORTS = [
+    "extrack_abi_version", "extrack_create", "extrack_destroy", "extrack_last_error", "extrack_set_stream",
+    "extrack_upload_bucket", "extrack_attach_bucket", "extrack_clear_buckets", "extrack_bucket_count",
+    "extrack_loglik", "extrack_loglik_async", "extrack_predict", "extrack_last_kernel_ms",
+    "extrack_last_launch_info", "extrack_p_stay_table",
+]
+
+_dp = C.POINTER(C.c_double)
+
+
+class ExtrackModel(C.Structure):
+    """Mirror of ``struct extrack_model`` (include/extrack_hip.h)."""
+    _fields_ = [
+        ("n_states", C.c_int32), ("nb_substeps", C.c_int32), ("frame_len", C.c_int32), ("min_len", C.c_int32),
+        ("max_len", C.c_int32), ("locerr_mode", C.c_int32), ("locerr_dims", C.c_int32), ("reserved", C.c_int32),
+        ("locerr", C.c_double * 3), ("slope", C.c_double), ("offset", C.c_double), ("pBL", C.c_double),
+        ("ds", _dp), ("Fs", _dp), ("TrMat", _dp), ("p_stay", _dp),
+    ]
+
+
+class ExtrackError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libextrack_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+
+def load():
+    """Loads the shared library; raises if it has not been built (``python __graft_entry__.py``)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
+    lib.extrack_abi_version.restype = C.c_int
+    lib.extrack_create.argtypes = [C.c_int, C.POINTER(vp)]
+    lib.extrack_destroy.argtypes = [vp]
+    lib.extrack_destroy.restype = None
+    lib.extrack_last_error.argtypes = [vp]
+    lib.extrack_last_error.restype = C.c_char_p
+    lib.extrack_set_stream.argtypes = [vp, vp]
+    lib.extrack_upload_bucket.argtypes = [vp, vp, i64, i32, i32, vp, i32, C.POINTER(i32)]
+    lib.extrack_attach_bucket.argtypes = [vp, vp, i64, i32, i32, vp, i32, C.POINTER(i32)]
+    lib.extrack_clear_buckets.argtypes = [vp]
+    lib.extrack_bucket_count.argtypes = [vp]
+    lib.extrack_loglik.argtypes = [vp, C.POINTER(ExtrackModel), _dp, vp]
+    lib.extrack_loglik_async.argtypes = [vp, C.POINTER(ExtrackModel), vp]
+    lib.extrack_predict.argtypes = [vp, C.POINTER(ExtrackModel), i32, vp]
+    lib.extrack_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.extrack_last_launch_info.argtypes = [vp, C.POINTER(i32 * 6)]
+    lib.extrack_p_stay_table.argtypes = [vp, i32, i32, vp, i32, vp]
+    if lib.extrack_abi_version() != 1:
+        raise ImportError("libextrack_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class ModelHandle:
+    """Keeps the numpy arrays referenced by an ExtrackModel alive."""
+
+    def __init__(self, ds, Fs, TrMat, p_stay, pBL, nb_substeps, frame_len, min_len, max_len, locerr=None, locerr_mode=0,
+                 slope=0.0, offset=0.0):
+        self.ds, self.Fs, self.TrMat, self.p_stay = _f64(ds), _f64(Fs), _f64(TrMat), _f64(p_stay)
+        S = len(self.ds)
+        if self.TrMat.shape != (S, S) or self.Fs.shape != (S,) or self.p_stay.shape != (S ** int(nb_substeps),):
+            raise ValueError("inconsistent model array shapes")
+        m = ExtrackModel()
+        m.n_states, m.nb_substeps, m.frame_len = S, int(nb_substeps), int(frame_len)
+        m.min_len, m.max_len = int(min_len), int(max_len)
+        m.locerr_mode = int(locerr_mode)
+        le = np.zeros(3)
+        if locerr_mode == 0:
+            v = np.atleast_1d(np.asarray(locerr, float)).ravel()
+            if len(v) < 1 or len(v) > 3:
+                raise ValueError("global localisation error must have 1..3 components")
+            le[:len(v)] = v
+            m.locerr_dims = len(v)
+        else:
+            m.locerr_dims = 1
+        m.locerr = (C.c_double * 3)(*le)
+        m.slope, m.offset, m.pBL = float(slope), float(offset), float(pBL)
+        m.ds = self.ds.ctypes.data_as(_dp)
+        m.Fs = self.Fs.ctypes.data_as(_dp)
+        m.TrMat = self.TrMat.ctypes.data_as(_dp)
+        m.p_stay = self.p_stay.ctypes.data_as(_dp)
+        self.c = m
+
+
+class Context:
+    """One libextrack_hip context = one GPU, one stream, a set of uploaded length buckets."""
+
+    def __init__(self, device=0):
+        self._lib = load()
+        h = C.c_void_p()
+        rc = self._lib.extrack_create(int(device), C.byref(h))
+        if rc != 0:
+            raise ExtrackError(rc, self._lib.extrack_last_error(None).decode())
+        self._h = h
+        self.device = int(device)
+        self.buckets = []  # (N, L, D, KS)
+        self._keep = []    # attached device tensors
+
+    def _check(self, rc):
+        if rc != 0:
+            raise ExtrackError(rc, self._lib.extrack_last_error(self._h).decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.extrack_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, stream_ptr):
+        self._check(self._lib.extrack_set_stream(self._h, C.c_void_p(stream_ptr or None)))
+
+    def upload_bucket(self, tracks, sigma=None):
+        tracks = _f64(tracks)
+        if tracks.ndim != 3:
+            raise ValueError("a bucket is an array [n_tracks, len, dims]")
+        N, L, D = tracks.shape
+        KS = 0
+        sp = None
+        if sigma is not None:
+            sigma = _f64(sigma)
+            if sigma.ndim != 3 or sigma.shape[:2] != (N, L):
+                raise ValueError("Localization error is not specified correctly")
+            KS = sigma.shape[2]
+            sp = sigma.ctypes.data_as(C.c_void_p)
+        bid = C.c_int32(-1)
+        self._check(self._lib.extrack_upload_bucket(self._h, tracks.ctypes.data_as(C.c_void_p), N, L, D, sp, KS, C.byref(bid)))
+        self.buckets.append((N, L, D, KS))
+        return bid.value
+
+    def attach_bucket(self, tracks_t, sigma_t=None):
+        """tracks_t / sigma_t: contiguous float64 torch CUDA tensors on this device (zero copy)."""
+        N, L, D = tracks_t.shape
+        KS = 0 if sigma_t is None else sigma_t.shape[2]
+        bid = C.c_int32(-1)
+        self._check(self._lib.extrack_attach_bucket(self._h, C.c_void_p(tracks_t.data_ptr()), N, L, D,
+                                                     C.c_void_p(sigma_t.data_ptr()) if sigma_t is not None else None, KS, C.byref(bid)))
+        self._keep.append((tracks_t, sigma_t))
+        self.buckets.append((N, L, D, KS))
+        return bid.value
+
+    def clear_buckets(self):
+        self._check(self._lib.extrack_clear_buckets(self._h))
+        self.buckets, self._keep = [], []
+
+    def n_tracks(self):
+        return sum(b[0] for b in self.buckets)
+
+    def loglik(self, model, per_track=False):
+        tot = C.c_double(0.0)
+        out = np.empty(self.n_tracks()) if per_track else None
+        self._check(self._lib.extrack_loglik(self._h, C.byref(model.c), C.byref(tot), out.ctypes.data_as(C.c_void_p) if per_track else None))
+        return (tot.value, out) if per_track else tot.value
+
+    def loglik_async(self, model, d_total_ptr=None):
+        self._check(self._lib.extrack_loglik_async(self._h, C.byref(model.c), C.c_void_p(d_total_ptr) if d_total_ptr else None))
+
+    def predict(self, model, bucket_id):
+        N, L, D, KS = self.buckets[bucket_id]
+        out = np.empty((N, L, model.c.n_states))
+        self._check(self._lib.extrack_predict(self._h, C.byref(model.c), int(bucket_id), out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def last_kernel_ms(self):
+        ms = C.c_float(0)
+        self._check(self._lib.extrack_last_kernel_ms(self._h, C.byref(ms)))
+        return ms.value
+
+    def last_launch_info(self):
+        info = (C.c_int32 * 6)()
+        self._check(self._lib.extrack_last_launch_info(self._h, C.byref(info)))
+        return dict(zip(("blocks", "threads", "lds_bytes", "tracks_per_block", "blocks_per_cu", "compute_units"), list(info)))
+
+
+def p_stay_table_c(ds, nb_substeps, cell_dims):
+    """The library's own erfc-based p_stay table (host code, no GPU needed)."""
+    lib = load()
+    ds = _f64(ds)
+    cd = _f64(cell_dims)
+    out = np.empty(len(ds) ** int(nb_substeps))
+    rc = lib.extrack_p_stay_table(ds.ctypes.data_as(C.c_void_p), len(ds), int(nb_substeps), cd.ctypes.data_as(C.c_void_p), len(cd),
+                                  out.ctypes.data_as(C.c_void_p))
+    if rc != 0:
+        raise ExtrackError(rc, "extrack_p_stay_table")
+    return out

@@ -1,0 +1,564 @@
+// libextrack_hip.so - HIP kernels (gfx950) + C ABI for ExTrack's track-likelihood hot path.
+// See include/extrack_hip.h for the contract and xt_kernel.h for the algorithm/data layout.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/extrack_hip.h"
+#include "xt_dispatch.h"
+#include "xt_tables.h"
+
+// ------------------------------------------------------------------------------------------------
+// device side
+// ------------------------------------------------------------------------------------------------
+extern __shared__ double xt_smem[];
+
+struct DevCtx {
+    __device__ __forceinline__ int tid() const { return threadIdx.x; }
+    __device__ __forceinline__ int nthreads() const { return blockDim.x; }
+    __device__ __forceinline__ int block() const { return blockIdx.x; }
+    __device__ __forceinline__ int nblocks() const { return gridDim.x; }
+    __device__ __forceinline__ double* smem() const { return xt_smem; }
+    __device__ __forceinline__ void sync() { __syncthreads(); }
+    __device__ __forceinline__ void atomic_max_i32(int* p, int v)
+    {
+        __hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    __device__ __forceinline__ void atomic_add_f64(double* p, double v)
+    {
+        __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+};
+
+// MAXT: 256 for the common one-wave-set-per-few-tracks geometry (lets the allocator use up to 256
+// VGPRs at 2 waves/SIMD if it needs them), 1024 when one track's groups need more than 256 threads.
+template <int G_, int D, int K, bool PREDS, int MAXT>
+__global__ void __launch_bounds__(MAXT) xt_track_kernel(XtKernelArgs a)
+{
+    DevCtx cx;
+    xt_track_body<G_, D, K, PREDS>(a, cx);
+}
+
+// Fixed-order reduction of the per-block partial sums (deterministic for a given launch geometry).
+__global__ void __launch_bounds__(256) xt_reduce_partials(const double* __restrict__ partials, int n, double* __restrict__ out)
+{
+    __shared__ double sh[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) s += partials[i];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out = sh[0];
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+struct XtBucket {
+    const double* d_tracks = nullptr;
+    const double* d_sigma = nullptr;
+    bool owned = false;
+    int64_t N = 0;
+    int L = 0, D = 0, KS = 0;
+    double* d_ll = nullptr;  // per-track output, allocated on first request
+};
+
+struct extrack_ctx {
+    int device = 0;
+    int n_cu = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    std::vector<XtBucket> buckets;
+    XtConfig cfg;
+    int32_t* d_base_tab = nullptr;
+    int32_t* d_off_tab = nullptr;
+    double* d_blob = nullptr;
+    size_t blob_cap = 0;
+    double* h_blob = nullptr;  // pinned
+    double* d_partials = nullptr;
+    size_t partials_cap = 0;
+    double* d_total = nullptr;
+    double* h_total = nullptr;  // pinned
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+    int32_t launch_info[6] = {0, 0, 0, 0, 0, 0};
+    std::map<std::pair<const void*, std::pair<int, size_t>>, int> occ_cache;
+    std::string err;
+};
+
+static std::string g_create_err;
+
+#define XT_HIP(ctx, call)                                                                       \
+    do {                                                                                        \
+        hipError_t e__ = (call);                                                                \
+        if (e__ != hipSuccess) {                                                                \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e__);                    \
+            return EXTRACK_E_HIP;                                                               \
+        }                                                                                       \
+    } while (0)
+
+static int xt_fail(extrack_ctx* ctx, int code, const std::string& msg)
+{
+    if (ctx) ctx->err = msg;
+    return code;
+}
+
+extern "C" int extrack_abi_version(void) { return EXTRACK_ABI_VERSION; }
+
+extern "C" const char* extrack_last_error(const extrack_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+extern "C" int extrack_create(int device_id, extrack_ctx** out)
+{
+    if (!out) return EXTRACK_E_INVALID;
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        g_create_err = std::string("no HIP device: ") + hipGetErrorString(e);
+        return EXTRACK_E_NODEVICE;
+    }
+    if (device_id < 0 || device_id >= ndev) {
+        g_create_err = "device id out of range";
+        return EXTRACK_E_INVALID;
+    }
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device_id)) != hipSuccess) {
+        g_create_err = std::string("hipGetDeviceProperties: ") + hipGetErrorString(e);
+        return EXTRACK_E_HIP;
+    }
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        g_create_err = std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only";
+        return EXTRACK_E_NODEVICE;
+    }
+    extrack_ctx* c = new extrack_ctx();
+    c->device = device_id;
+    c->n_cu = prop.multiProcessorCount;
+#define XT_CREATE(call)                                                             \
+    if ((e = (call)) != hipSuccess) {                                               \
+        g_create_err = std::string(#call) + ": " + hipGetErrorString(e);            \
+        delete c;                                                                   \
+        return EXTRACK_E_HIP;                                                       \
+    }
+    XT_CREATE(hipSetDevice(device_id));
+    XT_CREATE(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
+    XT_CREATE(hipEventCreate(&c->ev0));
+    XT_CREATE(hipEventCreate(&c->ev1));
+    XT_CREATE(hipMalloc(&c->d_total, sizeof(double)));
+    XT_CREATE(hipHostMalloc(&c->h_total, sizeof(double), hipHostMallocDefault));
+#undef XT_CREATE
+    *out = c;
+    return EXTRACK_OK;
+}
+
+static void xt_free_bucket(XtBucket& b)
+{
+    if (b.owned) {
+        if (b.d_tracks) (void)hipFree((void*)b.d_tracks);
+        if (b.d_sigma) (void)hipFree((void*)b.d_sigma);
+    }
+    if (b.d_ll) (void)hipFree(b.d_ll);
+    b = XtBucket();
+}
+
+extern "C" int extrack_clear_buckets(extrack_ctx* ctx)
+{
+    if (!ctx) return EXTRACK_E_INVALID;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto& b : ctx->buckets) xt_free_bucket(b);
+    ctx->buckets.clear();
+    return EXTRACK_OK;
+}
+
+extern "C" void extrack_destroy(extrack_ctx* ctx)
+{
+    if (!ctx) return;
+    extrack_clear_buckets(ctx);
+    if (ctx->d_base_tab) (void)hipFree(ctx->d_base_tab);
+    if (ctx->d_off_tab) (void)hipFree(ctx->d_off_tab);
+    if (ctx->d_blob) (void)hipFree(ctx->d_blob);
+    if (ctx->h_blob) (void)hipHostFree(ctx->h_blob);
+    if (ctx->d_partials) (void)hipFree(ctx->d_partials);
+    if (ctx->d_total) (void)hipFree(ctx->d_total);
+    if (ctx->h_total) (void)hipHostFree(ctx->h_total);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+extern "C" int extrack_set_stream(extrack_ctx* ctx, void* hip_stream)
+{
+    if (!ctx) return EXTRACK_E_INVALID;
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return EXTRACK_OK;
+}
+
+extern "C" int extrack_bucket_count(const extrack_ctx* ctx) { return ctx ? (int)ctx->buckets.size() : EXTRACK_E_INVALID; }
+
+static int xt_check_bucket_shape(extrack_ctx* ctx, int64_t n, int32_t len, int32_t dims, const void* sigma, int32_t sigma_dims)
+{
+    if (n <= 0) return xt_fail(ctx, EXTRACK_E_INVALID, "bucket must hold at least one track");
+    if (len < 2) return xt_fail(ctx, EXTRACK_E_INVALID, "minimal track length = 2");  // tracking.py:149-150
+    if (dims < 1 || dims > XT_MAX_DIMS) return xt_fail(ctx, EXTRACK_E_INVALID, "dims must be 1, 2 or 3");
+    if (sigma && sigma_dims != 1 && sigma_dims != dims)
+        return xt_fail(ctx, EXTRACK_E_INVALID, "sigma_dims must be 1 or dims");  // tracking.py:138-143
+    return EXTRACK_OK;
+}
+
+extern "C" int extrack_upload_bucket(extrack_ctx* ctx, const double* tracks, int64_t n, int32_t len, int32_t dims,
+                                     const double* sigma, int32_t sigma_dims, int32_t* bucket_id_out)
+{
+    if (!ctx || !tracks) return xt_fail(ctx, EXTRACK_E_INVALID, "null argument");
+    int rc = xt_check_bucket_shape(ctx, n, len, dims, sigma, sigma_dims);
+    if (rc) return rc;
+    XT_HIP(ctx, hipSetDevice(ctx->device));
+    XtBucket b;
+    b.owned = true;
+    b.N = n;
+    b.L = len;
+    b.D = dims;
+    b.KS = sigma ? sigma_dims : 0;
+    const size_t tb = (size_t)n * len * dims * sizeof(double);
+    double* dt = nullptr;
+    XT_HIP(ctx, hipMalloc(&dt, tb));
+    b.d_tracks = dt;
+    hipError_t e = hipMemcpyAsync(dt, tracks, tb, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && sigma) {
+        const size_t sb = (size_t)n * len * sigma_dims * sizeof(double);
+        double* dsg = nullptr;
+        e = hipMalloc(&dsg, sb);
+        b.d_sigma = dsg;
+        if (e == hipSuccess) e = hipMemcpyAsync(dsg, sigma, sb, hipMemcpyHostToDevice, ctx->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // the caller may free its host buffers on return
+    if (e != hipSuccess) {
+        xt_free_bucket(b);
+        return xt_fail(ctx, EXTRACK_E_HIP, std::string("bucket upload: ") + hipGetErrorString(e));
+    }
+    ctx->buckets.push_back(b);
+    if (bucket_id_out) *bucket_id_out = (int32_t)ctx->buckets.size() - 1;
+    return EXTRACK_OK;
+}
+
+extern "C" int extrack_attach_bucket(extrack_ctx* ctx, const double* d_tracks, int64_t n, int32_t len, int32_t dims,
+                                     const double* d_sigma, int32_t sigma_dims, int32_t* bucket_id_out)
+{
+    if (!ctx || !d_tracks) return xt_fail(ctx, EXTRACK_E_INVALID, "null argument");
+    int rc = xt_check_bucket_shape(ctx, n, len, dims, d_sigma, sigma_dims);
+    if (rc) return rc;
+    XtBucket b;
+    b.owned = false;
+    b.d_tracks = d_tracks;
+    b.d_sigma = d_sigma;
+    b.N = n;
+    b.L = len;
+    b.D = dims;
+    b.KS = d_sigma ? sigma_dims : 0;
+    ctx->buckets.push_back(b);
+    if (bucket_id_out) *bucket_id_out = (int32_t)ctx->buckets.size() - 1;
+    return EXTRACK_OK;
+}
+
+static int xt_validate_model(extrack_ctx* ctx, const extrack_model* m)
+{
+    if (!m || !m->ds || !m->Fs || !m->TrMat || !m->p_stay) return xt_fail(ctx, EXTRACK_E_INVALID, "null model field");
+    if (m->locerr_mode < 0 || m->locerr_mode > 2) return xt_fail(ctx, EXTRACK_E_INVALID, "locerr_mode must be 0, 1 or 2");
+    if (m->locerr_mode == 0 && (m->locerr_dims < 1 || m->locerr_dims > 3))
+        return xt_fail(ctx, EXTRACK_E_INVALID, "locerr_dims must be 1..3");
+    if (m->min_len < 1 || m->max_len < 2) return xt_fail(ctx, EXTRACK_E_INVALID, "min_len must be >= 1 and max_len >= 2");
+    return EXTRACK_OK;
+}
+
+// (Re)builds the digit-slot tables when (S, ns, F) changes and uploads the model blob.
+static int xt_prepare(extrack_ctx* ctx, const extrack_model* m)
+{
+    if (ctx->cfg.S != m->n_states || ctx->cfg.NS != m->nb_substeps || ctx->cfg.F != m->frame_len || !ctx->d_base_tab) {
+        XtConfig c;
+        std::string err = xt_build_config(m->n_states, m->nb_substeps, m->frame_len, c);
+        if (!err.empty()) return xt_fail(ctx, EXTRACK_E_INVALID, err);
+        XT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->d_base_tab) (void)hipFree(ctx->d_base_tab);
+        if (ctx->d_off_tab) (void)hipFree(ctx->d_off_tab);
+        ctx->d_base_tab = ctx->d_off_tab = nullptr;
+        XT_HIP(ctx, hipMalloc(&ctx->d_base_tab, c.base_tab.size() * sizeof(int32_t)));
+        XT_HIP(ctx, hipMalloc(&ctx->d_off_tab, c.off_tab.size() * sizeof(int32_t)));
+        XT_HIP(ctx, hipMemcpy(ctx->d_base_tab, c.base_tab.data(), c.base_tab.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        XT_HIP(ctx, hipMemcpy(ctx->d_off_tab, c.off_tab.data(), c.off_tab.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        ctx->cfg = c;
+    }
+    XtModelHost mh;
+    mh.S = m->n_states;
+    mh.NS = m->nb_substeps;
+    mh.locerr_dims = m->locerr_mode == 0 ? m->locerr_dims : 1;
+    for (int k = 0; k < 3; ++k) mh.locerr[k] = m->locerr[k];
+    mh.slope = m->slope;
+    mh.offset = m->offset;
+    mh.pBL = m->pBL;
+    mh.ds = m->ds;
+    mh.Fs = m->Fs;
+    mh.TrMat = m->TrMat;
+    mh.p_stay = m->p_stay;
+    std::vector<double> blob;
+    xt_build_blob(mh, ctx->cfg, blob);
+    if (blob.size() > ctx->blob_cap) {
+        XT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->d_blob) (void)hipFree(ctx->d_blob);
+        if (ctx->h_blob) (void)hipHostFree(ctx->h_blob);
+        ctx->d_blob = nullptr;
+        ctx->h_blob = nullptr;
+        ctx->blob_cap = 0;
+        XT_HIP(ctx, hipMalloc(&ctx->d_blob, blob.size() * sizeof(double)));
+        XT_HIP(ctx, hipHostMalloc(&ctx->h_blob, blob.size() * sizeof(double), hipHostMallocDefault));
+        ctx->blob_cap = blob.size();
+    } else {
+        // the pinned staging buffer may still be in flight from the previous evaluation
+        XT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    memcpy(ctx->h_blob, blob.data(), blob.size() * sizeof(double));
+    XT_HIP(ctx, hipMemcpyAsync(ctx->d_blob, ctx->h_blob, blob.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    return EXTRACK_OK;
+}
+
+struct DevLauncher {
+    extrack_ctx* ctx;
+    XtKernelArgs a;
+    int threads;
+    size_t lds;
+    int grid_cap;  // upper bound on blocks (partials capacity reserved by the caller)
+    int grid = 0, occ = 0;
+    hipError_t herr = hipSuccess;
+
+    template <int G_, int D, int K, bool PREDS>
+    bool run()
+    {
+        if (threads <= 256) return launch(xt_track_kernel<G_, D, K, PREDS, 256>);
+        return launch(xt_track_kernel<G_, D, K, PREDS, 1024>);
+    }
+
+    template <class KernT>
+    bool launch(KernT kern)
+    {
+        const void* kp = (const void*)kern;
+        auto key = std::make_pair(kp, std::make_pair(threads, lds));
+        auto it = ctx->occ_cache.find(key);
+        if (it == ctx->occ_cache.end()) {
+            if (lds > 64 * 1024) {
+                herr = hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (herr != hipSuccess) return true;
+            }
+            int o = 0;
+            herr = hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, kern, threads, lds);
+            if (herr != hipSuccess) return true;
+            it = ctx->occ_cache.emplace(key, o < 1 ? 1 : o).first;
+        }
+        occ = it->second;
+        const int64_t nbatch = (a.N + a.TPB - 1) / a.TPB;
+        int64_t gmax = (int64_t)occ * ctx->n_cu;
+        grid = (int)(nbatch < gmax ? nbatch : gmax);
+        if (grid > grid_cap) grid = grid_cap;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, ctx->stream, a);
+        herr = hipGetLastError();
+        return true;
+    }
+};
+
+static int xt_reserve_partials(extrack_ctx* ctx, size_t n)
+{
+    if (n <= ctx->partials_cap) return EXTRACK_OK;
+    XT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->d_partials) (void)hipFree(ctx->d_partials);
+    ctx->d_partials = nullptr;
+    ctx->partials_cap = 0;
+    XT_HIP(ctx, hipMalloc(&ctx->d_partials, n * sizeof(double)));
+    ctx->partials_cap = n;
+    return EXTRACK_OK;
+}
+
+static const int XT_MAX_BLOCKS_PER_CU = 8;
+
+// Launches the track kernel for one bucket; partial sums go to d_partials[poff .. poff+grid).
+static int xt_launch_bucket(extrack_ctx* ctx, const extrack_model* m, XtBucket& b, bool preds, double* d_ll, double* d_preds,
+                            size_t poff, int* grid_out)
+{
+    const XtConfig& c = ctx->cfg;
+    const int D = b.D;
+    int K;
+    if (m->locerr_mode == 0) {
+        K = m->locerr_dims;
+        if (K != 1 && K != D) return xt_fail(ctx, EXTRACK_E_INVALID, "locerr_dims must be 1 or the track dimensionality");
+    } else {
+        if (!b.d_sigma) return xt_fail(ctx, EXTRACK_E_INVALID, "per-peak localisation error mode but the bucket has no sigma");
+        K = b.KS;
+    }
+    DevLauncher l;
+    l.ctx = ctx;
+    memset(&l.a, 0, sizeof(l.a));
+    xt_fill_args_from_config(c, l.a);
+    int tpb, threads;
+    xt_geometry(c, D, K, tpb, threads);
+    if (threads > 1024) return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "n_states^(frame_len-nb_substeps) > 1024 groups per track is not built");
+    l.threads = threads;
+    l.lds = xt_lds_bytes(c, D, K, tpb);
+    if (l.lds > 160 * 1024) return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "sequence state does not fit the 160 KiB LDS of a CU");
+    l.grid_cap = ctx->n_cu * XT_MAX_BLOCKS_PER_CU;
+    l.a.tracks = b.d_tracks;
+    l.a.sigma = m->locerr_mode ? b.d_sigma : nullptr;
+    l.a.blob = ctx->d_blob;
+    l.a.base_tab = ctx->d_base_tab;
+    l.a.off_tab = ctx->d_off_tab;
+    l.a.ll_out = d_ll;
+    l.a.partials = ctx->d_partials + poff;
+    l.a.preds_out = d_preds;
+    l.a.N = b.N;
+    l.a.L = b.L;
+    l.a.TPB = tpb;
+    l.a.isBL = (b.L != m->max_len) ? 1 : 0;  // tracking.py:1037-1040
+    l.a.min_len = m->min_len;
+    l.a.locerr_mode = m->locerr_mode;
+    l.a.KS = b.KS ? b.KS : 1;
+    l.a.ll_const = -(double)(b.L - 1) * D * 0.5 * XT_LOG2PI;
+    if (!xt_dispatch(c.G, D, K, preds, l))
+        return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, preds ? "posteriors are built for n_states <= 6" : "kernel variant not built");
+    if (l.herr != hipSuccess) return xt_fail(ctx, EXTRACK_E_HIP, std::string("kernel launch: ") + hipGetErrorString(l.herr));
+    ctx->launch_info[0] = l.grid;
+    ctx->launch_info[1] = threads;
+    ctx->launch_info[2] = (int32_t)l.lds;
+    ctx->launch_info[3] = tpb;
+    ctx->launch_info[4] = l.occ;
+    ctx->launch_info[5] = ctx->n_cu;
+    *grid_out = l.grid;
+    return EXTRACK_OK;
+}
+
+static int xt_loglik_enqueue(extrack_ctx* ctx, const extrack_model* m, double* d_total, bool per_track)
+{
+    int rc = xt_validate_model(ctx, m);
+    if (rc) return rc;
+    if (ctx->buckets.empty()) return xt_fail(ctx, EXTRACK_E_INVALID, "no bucket uploaded");
+    XT_HIP(ctx, hipSetDevice(ctx->device));
+    if ((rc = xt_prepare(ctx, m))) return rc;
+    if ((rc = xt_reserve_partials(ctx, ctx->buckets.size() * (size_t)ctx->n_cu * XT_MAX_BLOCKS_PER_CU))) return rc;
+    if (per_track)
+        for (auto& b : ctx->buckets)
+            if (!b.d_ll) XT_HIP(ctx, hipMalloc(&b.d_ll, (size_t)b.N * sizeof(double)));
+    size_t poff = 0;
+    XT_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    for (auto& b : ctx->buckets) {
+        int grid = 0;
+        if ((rc = xt_launch_bucket(ctx, m, b, false, per_track ? b.d_ll : nullptr, nullptr, poff, &grid))) return rc;
+        poff += (size_t)grid;
+    }
+    XT_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    ctx->timed = true;
+    hipLaunchKernelGGL(xt_reduce_partials, dim3(1), dim3(256), 0, ctx->stream, ctx->d_partials, (int)poff, d_total);
+    XT_HIP(ctx, hipGetLastError());
+    return EXTRACK_OK;
+}
+
+extern "C" int extrack_loglik_async(extrack_ctx* ctx, const extrack_model* model, double* d_total_ll)
+{
+    if (!ctx) return EXTRACK_E_INVALID;
+    return xt_loglik_enqueue(ctx, model, d_total_ll ? d_total_ll : ctx->d_total, false);
+}
+
+extern "C" int extrack_loglik(extrack_ctx* ctx, const extrack_model* model, double* total_ll, double* per_track)
+{
+    if (!ctx || !total_ll) return xt_fail(ctx, EXTRACK_E_INVALID, "null argument");
+    int rc = xt_loglik_enqueue(ctx, model, ctx->d_total, per_track != nullptr);
+    if (rc) return rc;
+    XT_HIP(ctx, hipMemcpyAsync(ctx->h_total, ctx->d_total, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (per_track) {
+        size_t o = 0;
+        for (auto& b : ctx->buckets) {
+            XT_HIP(ctx, hipMemcpyAsync(per_track + o, b.d_ll, (size_t)b.N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+            o += (size_t)b.N;
+        }
+    }
+    XT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *total_ll = *ctx->h_total;
+    return EXTRACK_OK;
+}
+
+extern "C" int extrack_predict(extrack_ctx* ctx, const extrack_model* m, int32_t bucket_id, double* preds)
+{
+    if (!ctx || !preds) return xt_fail(ctx, EXTRACK_E_INVALID, "null argument");
+    int rc = xt_validate_model(ctx, m);
+    if (rc) return rc;
+    if (bucket_id < 0 || bucket_id >= (int)ctx->buckets.size()) return xt_fail(ctx, EXTRACK_E_INVALID, "bucket id out of range");
+    if (m->nb_substeps != 1) return xt_fail(ctx, EXTRACK_E_INVALID, "state predictions require nb_substeps == 1");
+    XT_HIP(ctx, hipSetDevice(ctx->device));
+    if ((rc = xt_prepare(ctx, m))) return rc;
+    if ((rc = xt_reserve_partials(ctx, (size_t)ctx->n_cu * XT_MAX_BLOCKS_PER_CU))) return rc;
+    XtBucket& b = ctx->buckets[bucket_id];
+    const size_t nb = (size_t)b.N * b.L * m->n_states * sizeof(double);
+    double* d_preds = nullptr;
+    XT_HIP(ctx, hipMalloc(&d_preds, nb));
+    int grid = 0;
+    hipError_t e = hipEventRecord(ctx->ev0, ctx->stream);
+    rc = xt_launch_bucket(ctx, m, b, true, nullptr, d_preds, 0, &grid);
+    if (rc == EXTRACK_OK) {
+        if (e == hipSuccess) e = hipEventRecord(ctx->ev1, ctx->stream);
+        ctx->timed = true;
+        if (e == hipSuccess) e = hipMemcpyAsync(preds, d_preds, nb, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) rc = xt_fail(ctx, EXTRACK_E_HIP, std::string("predict: ") + hipGetErrorString(e));
+    }
+    (void)hipFree(d_preds);
+    return rc;
+}
+
+extern "C" int extrack_last_kernel_ms(extrack_ctx* ctx, float* ms)
+{
+    if (!ctx || !ms) return EXTRACK_E_INVALID;
+    if (!ctx->timed) return xt_fail(ctx, EXTRACK_E_INVALID, "no timed launch yet");
+    XT_HIP(ctx, hipEventSynchronize(ctx->ev1));
+    XT_HIP(ctx, hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+    return EXTRACK_OK;
+}
+
+extern "C" int extrack_last_launch_info(const extrack_ctx* ctx, int32_t info[6])
+{
+    if (!ctx || !info) return EXTRACK_E_INVALID;
+    for (int i = 0; i < 6; ++i) info[i] = ctx->launch_info[i];
+    return EXTRACK_OK;
+}
+
+extern "C" int extrack_p_stay_table(const double* ds, int32_t S, int32_t ns, const double* cell_dims, int32_t n_cell, double* out)
+{
+    if (!ds || !out || S < 1 || ns < 1 || (n_cell > 0 && !cell_dims)) return EXTRACK_E_INVALID;
+    int G = 1;
+    for (int i = 0; i < ns; ++i) G *= S;
+    for (int r = 0; r < G; ++r) {
+        double sub = 0.0;
+        int rr = r;
+        for (int c = 0; c < ns; ++c) {
+            sub += ds[rr % S] * ds[rr % S];
+            rr /= S;
+        }
+        const double sd = sqrt(sub / ns) + 1e-200;
+        double p = 1.0;
+        for (int j = 0; j < n_cell; ++j) {
+            const double cl = cell_dims[j];
+            const double x0 = cl / 2000.0, x1 = cl - cl / 2000.0;
+            double acc = 0.0;
+            for (int i = 0; i < 1000; ++i) {
+                const double x = x0 + (x1 - x0) * (double)i / 999.0;
+                // Phi(z) = erfc(-z / sqrt(2)) / 2
+                acc += 0.5 * erfc(-((cl - x) / sd) * M_SQRT1_2) - 0.5 * erfc((x / sd) * M_SQRT1_2);
+            }
+            p *= acc / 1000.0;
+        }
+        out[r] = p;
+    }
+    return EXTRACK_OK;
+}

@@ -1,0 +1,394 @@
+// Track-likelihood / state-posterior recursion: the kernel body shared by the HIP kernels
+// (extrack_hip.hip) and by the CPU-thread emulator used in tests (tests/emul).
+//
+// What it computes (reference: extrack/tracking.py:109-318 P_Cs_inter_bound_stats, fixed window,
+// + extrack/tracking_0.py:440-458 Proba_Cs; exact statement in SURVEY.md Appendix A):
+//   per track: LL = log sum_{state sequences} P(track, sequence | model)   with sequences older than
+//   frame_len states merged by moment matching, and (PREDS) the per-position state posteriors.
+//
+// How it is organised for CDNA4 (this is NOT the reference's data flow):
+//   * A track's S^F live sequences sit in LDS as struct-of-arrays {zm, ze, m[D], u[K]} holding the
+//     state AFTER the Gaussian integration of a position: weight z = zm*2^ze (linear domain,
+//     extended range), mean m, and u = l2*s2/(l2+s2) (the variance before the next step's
+//     diffusion term d2 is added).
+//   * Sequence index = F base-S digit "slots" used as a circular buffer: the ns new state digits of
+//     a step overwrite the slots of the ns oldest digits, which are exactly the digits the reference
+//     fuses away (tracking.py:253-277).  A "group" = the S^ns sequences that differ only in those
+//     slots.  Because the expansion terms (transition probability, stay probability, d2) depend only
+//     on (newest old digit, new digits) - constant inside a group - the reference's expand -> integrate
+//     -> fuse becomes fuse -> expand -> integrate: ONE moment-matching merge per group, then S^ns
+//     cheap per-new-digit updates.  One thread owns one group: read S^ns entries, merge, write S^ns
+//     entries in place; one workgroup barrier per track position.
+//   * Unused slots during warm-up (track shorter than the window) hold zero-weight entries, so the
+//     same code path covers warm-up, steady state and short tracks.
+//   * The last position and the bleaching/leaving term (isBL) are a pure reduction:
+//     sum_{Q,q} z_Q * T[prev][q] * Eend[q_newest] * N(c_last; m_Q, s2_Qq + l2).
+#pragma once
+#include "xt_math.h"
+
+#define XT_MAX_STATES 8
+#define XT_MAX_DIMS 3
+#define XT_BLOB_HDR 16  // doubles: [0..2] l2 (global loc. error^2 per dim), [3] slope, [4] offset, [8..15] Fs
+#define XT_NTAB 5       // tables [v][prev][q]: 0 T, 1 T*stay, 2 T*Eend, 3 T*stay*Eend, 4 d2
+
+struct XtKernelArgs {
+    const double* tracks;     // [N][L][D] device
+    const double* sigma;      // [N][L][KS] per-peak localisation error (std) or nullptr
+    const double* blob;       // model blob, XT_BLOB_HDR + XT_NTAB*S*G doubles
+    const int32_t* base_tab;  // [P][NG] entry index of the group's q=0 member per phase
+    const int32_t* off_tab;   // [P][G]  entry offset of member q per phase
+    double* ll_out;           // [N] per-track log-likelihood or nullptr
+    double* partials;         // [nblocks] per-block sum of LL
+    double* preds_out;        // [N][L][S] (PREDS kernels)
+    int64_t N;
+    int32_t L, S, NS, F, G, E, NG, P;
+    int32_t TPB;              // tracks processed concurrently by one block
+    int32_t isBL, min_len;
+    int32_t locerr_mode;      // 0 global (blob[0..2]), 1 per-peak sigma, 2 per-peak affine clip(s*slope+offset,1e-6)
+    int32_t KS;               // last dim of sigma (1 or D)
+    int32_t prev_div;         // S^(F-NS-1): prev digit of group g = g / prev_div
+    int32_t pw[16];           // S^i
+    double ll_const;          // -(L-1)*D/2*log(2*pi)
+};
+
+// LDS footprint in doubles.  Layout: [tables][per-track regions x TPB][pred accumulators x TPB]
+XT_HD int xt_tab_doubles(int S, int G) { return XT_BLOB_HDR + XT_NTAB * S * G; }
+XT_HD int xt_region_doubles(int E, int D, int K) { return E * (1 + D + K) + (E + 1) / 2 + 2; }
+XT_HD int xt_pred_doubles(int S, int F) { return 2 * (S + 1) + (F + 1) * S + 2; }
+
+template <int K, int D>
+struct XtL2 {
+    double v[K];
+};
+
+template <int G_, int D, int K, bool PREDS, class Ctx>
+XT_HD void xt_track_body(const XtKernelArgs& a, Ctx& cx)
+{
+    const int G = G_ ? G_ : a.G;
+    const int S = a.S, E = a.E, NG = a.NG, L = a.L, F = a.F;
+    const int tid = cx.tid();
+    double* smem = cx.smem();
+
+    // ---- model tables -> LDS
+    const int ntab = xt_tab_doubles(S, G);
+    for (int i = tid; i < ntab; i += cx.nthreads()) smem[i] = a.blob[i];
+    const double* hdr = smem;
+    const double* TAB = smem + XT_BLOB_HDR;
+    const int SG = S * G;
+
+    const int slot = tid / NG;
+    const int g = tid - slot * NG;
+    const bool tvalid = slot < a.TPB;
+    const int rdoubles = xt_region_doubles(E, D, K);
+    double* reg = smem + ((ntab + 1) & ~1) + (tvalid ? slot : 0) * rdoubles;
+    double* zm = reg;
+    double* mm = zm + E;
+    double* uu = mm + D * E;
+    int* ze = (int*)(uu + K * E);
+    int* red_e = ze + ((E + 1) & ~1);  // [2] ints: final-reduce exponent, spare
+    double* pbase = smem + ((ntab + 1) & ~1) + a.TPB * rdoubles + (tvalid ? slot : 0) * xt_pred_doubles(S, F);
+    // PREDS accumulators: pe[2] (ints, in one double), pacc[2][S], facc[F+1][S]
+    int* pe = (int*)pbase;
+    double* pacc = pbase + 2;
+    double* facc = pacc + 2 * S;
+
+    const int prev = g / a.prev_div;
+    const double* T0 = TAB + (0 * S + prev) * G;
+    const double* T1 = TAB + (1 * S + prev) * G;
+    const double* TD2 = TAB + (4 * S + prev) * G;
+    const int stay_from = a.min_len > 2 ? a.min_len : 2;
+
+    double block_ll = 0.0;  // meaningful in thread g == 0 of each slot
+    const int64_t nbatch = (a.N + a.TPB - 1) / a.TPB;
+    cx.sync();
+
+    for (int64_t batch = cx.block(); batch < nbatch; batch += cx.nblocks()) {
+        const int64_t trk = batch * a.TPB + slot;
+        const bool act = tvalid && trk < a.N;
+        const double* c = a.tracks + (act ? trk : 0) * (int64_t)L * D;
+        const double* sg = a.sigma ? a.sigma + (act ? trk : 0) * (int64_t)L * a.KS : nullptr;
+
+        auto load_l2 = [&](int pos, double* l2) {
+            if (a.locerr_mode == 0) {
+                for (int k = 0; k < K; ++k) l2[k] = hdr[k];
+            } else {
+                for (int k = 0; k < K; ++k) {
+                    double s = sg[pos * a.KS + (a.KS == 1 ? 0 : k)];
+                    if (a.locerr_mode == 2) {
+                        s = xt_fma(s, hdr[3], hdr[4]);
+                        s = s < 1e-6 ? 1e-6 : s;
+                    }
+                    l2[k] = s * s;
+                }
+            }
+        };
+
+        // ---- position 0: one digit (initial state) in slot 0, everything else zero weight
+        if (act) {
+            double l20[K], c0[D];
+            load_l2(0, l20);
+            for (int d = 0; d < D; ++d) c0[d] = c[d];
+            for (int i = g; i < E; i += NG) {
+                const bool live = i < S;
+                zm[i] = live ? hdr[8 + i] : 0.0;
+                ze[i] = live ? 0 : XT_EMIN;
+                for (int d = 0; d < D; ++d) mm[d * E + i] = c0[d];
+                for (int k = 0; k < K; ++k) uu[k * E + i] = l20[k];
+            }
+            if (g == 0) {
+                red_e[0] = XT_EMIN;
+                if (PREDS) {
+                    pe[0] = pe[1] = XT_EMIN;
+                    for (int i = 0; i < 2 * S + (F + 1) * S; ++i) pacc[i] = 0.0;
+                }
+            }
+        }
+        cx.sync();
+
+        // ---- positions 1 .. L-2: fuse the group, expand by the new digits, integrate position t
+        for (int t = 1; t <= L - 2; ++t) {
+            const int ph = (t - 1) % a.P;
+            const bool do_pred = PREDS && t >= F;
+            const int par = t & 1;
+            XtAcc pq[PREDS ? (G_ ? G_ : 1) : 1];
+            if (act) {
+                const int base = a.base_tab[ph * NG + g];
+                const int32_t* off = a.off_tab + ph * G;
+                double ct[D], l2t[K];
+                for (int d = 0; d < D; ++d) ct[d] = c[t * D + d];
+                load_l2(t, l2t);
+                const double* TT = (t >= stay_from) ? T1 : T0;
+
+                int emax = XT_EMIN;
+                for (int q = 0; q < G; ++q) {
+                    const int e = ze[base + off[q]];
+                    emax = e > emax ? e : emax;
+                }
+                double W = 0.0, mb[D], ub[K];
+                for (int d = 0; d < D; ++d) mb[d] = 0.0;
+                for (int k = 0; k < K; ++k) ub[k] = 0.0;
+                for (int q = 0; q < G; ++q) {
+                    const int idx = base + off[q];
+                    const double aq = xt_ldexp(zm[idx], ze[idx] - emax);
+                    W += aq;
+                    for (int d = 0; d < D; ++d) mb[d] = xt_fma(aq, mm[d * E + idx], mb[d]);
+                    for (int k = 0; k < K; ++k) ub[k] = xt_fma(aq, uu[k * E + idx], ub[k]);
+                }
+
+                if (do_pred) {
+                    // posterior of the digit about to be fused away, weighted by the predictive density of
+                    // position t (tracking.py:255-271; note the reference's missing 1/2 on the log term)
+                    int pemax = XT_EMIN;
+                    for (int Q = 0; Q < G; ++Q) {
+                        const int idx = base + off[Q];
+                        pq[Q].clear();
+                        const double zq = zm[idx];
+                        if (zq != 0.0) {
+                            double dq[D], uq[K], dsq = 0.0;
+                            for (int d = 0; d < D; ++d) {
+                                dq[d] = ct[d] - mm[d * E + idx];
+                                dsq = xt_fma(dq[d], dq[d], dsq);
+                            }
+                            for (int k = 0; k < K; ++k) uq[k] = uu[k * E + idx];
+                            for (int q = 0; q < G; ++q) {
+                                double quad, gf;
+                                if (K == 1) {
+                                    const double r = xt_rcp(TD2[q] + uq[0] + l2t[0]);
+                                    quad = 0.5 * dsq * r;
+                                    gf = r;
+                                    for (int d = 1; d < D; ++d) gf *= r;
+                                } else {
+                                    quad = 0.0;
+                                    gf = 1.0;
+                                    for (int d = 0; d < D; ++d) {
+                                        const double r = xt_rcp(TD2[q] + uq[d] + l2t[d]);
+                                        quad = xt_fma(0.5 * dq[d] * dq[d], r, quad);
+                                        gf *= r;
+                                    }
+                                }
+                                double p;
+                                int n;
+                                xt_exp_split(-quad, p, n);
+                                pq[Q].add(zq * TT[q] * gf * p, ze[idx] + n);
+                            }
+                        }
+                        pemax = pq[Q].e > pemax ? pq[Q].e : pemax;
+                    }
+                    if (pemax > XT_EMIN) cx.atomic_max_i32(&pe[par], pemax);
+                }
+
+                const double rW = W > 0.0 ? xt_rcp(W) : 0.0;
+                for (int d = 0; d < D; ++d) mb[d] *= rW;
+                for (int k = 0; k < K; ++k) ub[k] *= rW;
+                const double Wm = xt_frexp_mant(W);
+                const int We = W > 0.0 ? emax + xt_frexp_exp(W) : XT_EMIN;
+
+                double dm[D], dsq = 0.0;
+                for (int d = 0; d < D; ++d) {
+                    dm[d] = ct[d] - mb[d];
+                    dsq = xt_fma(dm[d], dm[d], dsq);
+                }
+                for (int q = 0; q < G; ++q) {
+                    const int idx = base + off[q];
+                    const double d2 = TD2[q];
+                    double quad, gf, tt[K];
+                    if (K == 1) {
+                        const double s2 = d2 + ub[0];
+                        const double r = xt_rcp(l2t[0] + s2);
+                        tt[0] = s2 * r;
+                        quad = 0.5 * dsq * r;
+                        gf = xt_pow_half<D>(r);
+                    } else {
+                        quad = 0.0;
+                        gf = 1.0;
+                        for (int d = 0; d < D; ++d) {
+                            const double s2 = d2 + ub[d];
+                            const double r = xt_rcp(l2t[d] + s2);
+                            tt[d] = s2 * r;
+                            quad = xt_fma(0.5 * dm[d] * dm[d], r, quad);
+                            gf *= r;
+                        }
+                        gf = sqrt(gf);
+                    }
+                    double p;
+                    int n;
+                    xt_exp_split(-quad, p, n);
+                    double zn = Wm * TT[q] * gf * p;
+                    int en = We + n;
+                    if (zn == 0.0 || en <= XT_EMIN) {
+                        zn = 0.0;
+                        en = XT_EMIN;
+                    }
+                    zm[idx] = zn;
+                    ze[idx] = en;
+                    for (int d = 0; d < D; ++d) mm[d * E + idx] = xt_fma(dm[d], tt[K == 1 ? 0 : d], mb[d]);
+                    for (int k = 0; k < K; ++k) uu[k * E + idx] = l2t[k] * tt[k];
+                }
+            }
+            cx.sync();
+            if (PREDS && do_pred) {
+                if (act) {
+                    const int pem = pe[par];
+                    for (int Q = 0; Q < G; ++Q)
+                        if (pq[Q].m != 0.0) cx.atomic_add_f64(&pacc[par * S + Q], xt_ldexp(pq[Q].m, pq[Q].e - pem));
+                    if (g < S) pacc[(par ^ 1) * S + g] = 0.0;
+                    if (g == 0) pe[par ^ 1] = XT_EMIN;
+                }
+                cx.sync();
+                if (act && g < S) {
+                    double tot = 0.0;
+                    for (int s = 0; s < S; ++s) tot += pacc[par * S + s];
+                    a.preds_out[(trk * L + (t - F)) * S + g] = pacc[par * S + g] / tot;
+                }
+            }
+        }
+
+        // ---- last position (+ leaving/bleaching term): pure reduction over (old entry Q, new digits q)
+        XtAcc tot;
+        tot.clear();
+        XtAcc accQ[PREDS ? (G_ ? G_ : 1) : 1], accq[PREDS ? (G_ ? G_ : 1) : 1];
+        if (act) {
+            const int tl = L - 1;
+            const int ph = (tl - 1) % a.P;
+            const int base = a.base_tab[ph * NG + g];
+            const int32_t* off = a.off_tab + ph * G;
+            const int vfin = (a.isBL ? 2 : 0) + (tl >= stay_from ? 1 : 0);
+            const double* TF = TAB + (vfin * S + prev) * G;
+            double cl[D], l2l[K];
+            for (int d = 0; d < D; ++d) cl[d] = c[tl * D + d];
+            load_l2(tl, l2l);
+            if (PREDS)
+                for (int q = 0; q < G; ++q) {
+                    accQ[q].clear();
+                    accq[q].clear();
+                }
+            for (int Q = 0; Q < G; ++Q) {
+                const int idx = base + off[Q];
+                const double zq = zm[idx];
+                if (zq == 0.0) continue;
+                const int eq = ze[idx];
+                double dq[D], uq[K], dsq = 0.0;
+                for (int d = 0; d < D; ++d) {
+                    dq[d] = cl[d] - mm[d * E + idx];
+                    dsq = xt_fma(dq[d], dq[d], dsq);
+                }
+                for (int k = 0; k < K; ++k) uq[k] = uu[k * E + idx];
+                for (int q = 0; q < G; ++q) {
+                    double quad, gf;
+                    if (K == 1) {
+                        const double r = xt_rcp(TD2[q] + uq[0] + l2l[0]);
+                        quad = 0.5 * dsq * r;
+                        gf = xt_pow_half<D>(r);
+                    } else {
+                        quad = 0.0;
+                        gf = 1.0;
+                        for (int d = 0; d < D; ++d) {
+                            const double r = xt_rcp(TD2[q] + uq[d] + l2l[d]);
+                            quad = xt_fma(0.5 * dq[d] * dq[d], r, quad);
+                            gf *= r;
+                        }
+                        gf = sqrt(gf);
+                    }
+                    double p;
+                    int n;
+                    xt_exp_split(-quad, p, n);
+                    const double wm = zq * TF[q] * gf * p;
+                    const int we = eq + n;
+                    tot.add(wm, we);
+                    if (PREDS) {
+                        accQ[Q].add(wm, we);
+                        accq[q].add(wm, we);
+                    }
+                }
+            }
+            if (tot.m != 0.0) cx.atomic_max_i32(&red_e[0], tot.e);
+        }
+        cx.sync();  // all reads of the state are done: zm can be reused as reduction scratch
+        int fe = XT_EMIN;
+        if (act) {
+            fe = red_e[0];
+            zm[g] = tot.m != 0.0 ? xt_ldexp(tot.m, tot.e - fe) : 0.0;
+            if (PREDS) {
+                const double al = zm[g];
+                // column 0 = newest digit q; column F = fused slot digit Q; columns 1..F-1 = digits of g
+                for (int q = 0; q < G; ++q) {
+                    if (accq[q].m != 0.0) cx.atomic_add_f64(&facc[0 * S + q], xt_ldexp(accq[q].m, accq[q].e - fe));
+                    if (L - 1 >= F && accQ[q].m != 0.0) cx.atomic_add_f64(&facc[F * S + q], xt_ldexp(accQ[q].m, accQ[q].e - fe));
+                }
+                if (al != 0.0)
+                    for (int j = 1; j <= F - 1 && j <= L - 1; ++j) {
+                        const int dig = (g / a.pw[F - j - 1]) % S;
+                        cx.atomic_add_f64(&facc[j * S + dig], al);
+                    }
+            }
+        }
+        cx.sync();
+        if (act && g == 0) {
+            double sum = 0.0;
+            for (int i = 0; i < NG; ++i) sum += zm[i];
+            const double ll = log(sum) + (double)fe * XT_LN2 + a.ll_const;
+            if (a.ll_out) a.ll_out[trk] = ll;
+            block_ll += ll;
+        }
+        if (PREDS && act) {
+            const int ncol = (L - 1 < F ? L - 1 : F) + 1;
+            for (int i = g; i < ncol * S; i += NG) {
+                const int j = i / S;
+                double tots = 0.0;
+                for (int s = 0; s < S; ++s) tots += facc[j * S + s];
+                a.preds_out[(trk * L + (L - 1 - j)) * S + (i - j * S)] = facc[i] / tots;
+            }
+        }
+        cx.sync();  // scratch (zm) and accumulators are re-initialised by the next batch
+    }
+
+    // ---- block partial: fixed-order sum over the block's track slots
+    cx.sync();
+    if (tvalid && g == 0) smem[slot] = block_ll;
+    cx.sync();
+    if (tid == 0) {
+        double s = 0.0;
+        for (int i = 0; i < a.TPB; ++i) s += smem[i];
+        a.partials[cx.block()] = s;
+    }
+}

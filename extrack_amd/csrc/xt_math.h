@@ -1,0 +1,118 @@
+// Scalar math helpers for the track-likelihood kernels (MI355X / gfx950, fp64).
+//
+// The recursion is carried in the LINEAR domain with extended-range weights
+//     value = m * 2^e        (m: double mantissa, not necessarily normalised; e: int32)
+// instead of the reference's log domain (extrack/tracking.py:109-318 keeps log-probabilities and
+// pays one exp per sequence and one log per fused sequence per step).  The only transcendental
+// left per (sequence, step) is the exponential of the Gaussian quadratic form, whose power-of-two
+// part goes straight into the integer exponent, so nothing under- or overflows.
+//
+// Every function is usable from host code too: tests/emul runs the very same kernel body on CPU
+// threads (test infrastructure only; the product never does).
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define XT_HD __host__ __device__ __forceinline__
+#else
+#define XT_HD inline
+#endif
+
+#define XT_EMIN (-(1 << 30))          // exponent of an exactly-zero weight
+#define XT_XCLAMP (-1.0e8)            // exp argument clamp: keeps e within int32 for >10 such steps
+#define XT_LN2 0.693147180559945309417232121458
+#define XT_LOG2PI 1.83787706640934548356065947281
+
+#if defined(__HIP_DEVICE_COMPILE__)
+XT_HD double xt_rcp(double x)
+{
+    // v_rcp_f64 seed + two Newton steps (4 FMA): <= 1 ulp for normal x, no scaling needed because
+    // the arguments (variances, weight sums) are far from the fp64 range limits.
+    double r = __builtin_amdgcn_rcp(x);
+    double e = __builtin_fma(-x, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-x, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    return r;
+}
+XT_HD double xt_frexp_mant(double x) { return __builtin_amdgcn_frexp_mant(x); }
+XT_HD int xt_frexp_exp(double x) { return __builtin_amdgcn_frexp_exp(x); }
+XT_HD double xt_ldexp(double x, int e) { return __builtin_amdgcn_ldexp(x, e); }
+XT_HD double xt_rint(double x) { return __builtin_rint(x); }
+#else
+XT_HD double xt_rcp(double x) { return 1.0 / x; }
+XT_HD double xt_frexp_mant(double x)
+{
+    int e;
+    return frexp(x, &e);
+}
+XT_HD int xt_frexp_exp(double x)
+{
+    int e;
+    frexp(x, &e);
+    return x == 0.0 ? 0 : e;
+}
+XT_HD double xt_ldexp(double x, int e) { return ldexp(x, e); }
+XT_HD double xt_rint(double x) { return nearbyint(x); }
+#endif
+
+XT_HD double xt_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
+// exp(x) for x <= 0, returned as p * 2^n with p in [0.70, 1.42].  |rel err| < 3e-16.
+XT_HD void xt_exp_split(double x, double& p, int& n)
+{
+    x = x < XT_XCLAMP ? XT_XCLAMP : x;
+    const double kf = xt_rint(x * 1.44269504088896338700e+00);
+    double r = xt_fma(kf, -6.93147180369123816490e-01, x);  // ln2 hi (low 21 bits zero: kf*hi exact)
+    r = xt_fma(kf, -1.90821492927058770002e-10, r);         // ln2 lo
+    // Taylor/Horner degree 13 on |r| <= 0.3466 (truncation 4e-18)
+    double q = 1.6059043836821613e-10;            // 1/13!
+    q = xt_fma(q, r, 2.08767569878680989792e-09);  // 1/12!
+    q = xt_fma(q, r, 2.50521083854417187751e-08);  // 1/11!
+    q = xt_fma(q, r, 2.75573192239858906526e-07);  // 1/10!
+    q = xt_fma(q, r, 2.75573192239858906526e-06);  // 1/9!
+    q = xt_fma(q, r, 2.48015873015873015873e-05);  // 1/8!
+    q = xt_fma(q, r, 1.98412698412698412698e-04);  // 1/7!
+    q = xt_fma(q, r, 1.38888888888888888889e-03);  // 1/6!
+    q = xt_fma(q, r, 8.33333333333333333333e-03);  // 1/5!
+    q = xt_fma(q, r, 4.16666666666666666667e-02);  // 1/4!
+    q = xt_fma(q, r, 1.66666666666666666667e-01);  // 1/3!
+    q = xt_fma(q, r, 0.5);
+    q = xt_fma(q, r, 1.0);
+    p = xt_fma(q, r, 1.0);
+    n = (int)kf;
+}
+
+// den^(-D/2) for a scalar variance (K == 1) given r = 1/den.
+template <int D>
+XT_HD double xt_pow_half(double r)
+{
+    if (D == 1) return sqrt(r);
+    if (D == 2) return r;
+    if (D == 3) return r * sqrt(r);
+    double o = 1.0;
+    for (int d = 0; d < D / 2; ++d) o *= r;
+    return (D & 1) ? o * sqrt(r) : o;
+}
+
+// Extended-range accumulator: sum of terms m_i * 2^e_i, kept as m * 2^e with e = max e_i seen.
+struct XtAcc {
+    double m;
+    int e;
+    XT_HD void clear()
+    {
+        m = 0.0;
+        e = XT_EMIN;
+    }
+    XT_HD void add(double m2, int e2)
+    {
+        if (m2 == 0.0) return;
+        if (e2 > e) {
+            m = xt_ldexp(m, e - e2) + m2;  // e - e2 may be hugely negative: ldexp saturates to 0
+            e = e2;
+        } else {
+            m += xt_ldexp(m2, e2 - e);
+        }
+    }
+};

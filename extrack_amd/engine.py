@@ -1,0 +1,112 @@
+"""Device-resident track sets and the model-table plumbing between the Python API and the C ABI.
+
+A ``TrackSet`` is the MI355X counterpart of the argument list that the reference rebuilds for
+every objective evaluation (extrack/tracking.py:1019-1056): the length buckets are uploaded to HBM
+ONCE and stay resident for the whole fit; an evaluation only ships the ~100-byte model tables.
+"""
+import numpy as np
+from scipy.special import ndtr
+
+from . import _lib
+
+
+def p_stay_table(ds, nb_states, nb_substeps, cell_dims):
+    """Probability of staying in the field of view for each of the S**ns newest sub-sequences.
+
+    Same quadrature as the reference (extrack/tracking.py:182-191): mean over a 1000-point grid of
+    Phi((cell - x)/sigma) - Phi(-x/sigma), product over cell dimensions, with
+    sigma_r = sqrt(mean_c ds[g_c(r)]**2) and digit c of r = (r // S**c) % S.
+    """
+    S, ns = int(nb_states), int(nb_substeps)
+    ds2 = np.asarray(ds, float) ** 2
+    r = np.arange(S ** ns)
+    acc = np.zeros(len(r))
+    for c in range(ns):
+        acc += ds2[(r // S ** c) % S]
+    sub_ds = np.sqrt(acc / ns)
+    out = np.ones(len(r))
+    for cell_len in cell_dims:
+        xs = np.linspace(0 + cell_len / 2000, cell_len - cell_len / 2000, 1000)[:, None]
+        out = out * np.mean(ndtr((cell_len - xs) / (sub_ds + 1e-200)) - ndtr(-xs / (sub_ds + 1e-200)), 0)
+    return out
+
+
+def sort_buckets(all_tracks, input_LocErr=None):
+    """Numeric sort of the length keys, dropping empty buckets (extrack/tracking.py:1346-1367).
+
+    Returns (all_keys_sorted, [track arrays short->long], [sigma arrays] or None)."""
+    keys = np.sort(np.array(list(all_tracks.keys())).astype(int)).astype(str)
+    tracks, sigmas = [], []
+    for l in keys:
+        if len(all_tracks[l]) > 0:
+            tracks.append(np.asarray(all_tracks[l], dtype=np.float64))
+            if input_LocErr is not None:
+                sigmas.append(np.asarray(input_LocErr[l], dtype=np.float64))
+    return list(keys), tracks, (sigmas if input_LocErr is not None else None)
+
+
+class TrackSet:
+    """Length buckets resident on one GPU.
+
+    buckets: list of arrays [N_l, l, D] sorted short -> long (as the reference's objective receives them).
+    sigmas:  optional list of per-peak localisation errors with matching shapes [N_l, l, 1|D].
+    min_len / max_len: dataset-global values (default: from ``buckets``); a shard of a distributed
+    dataset must be given the global ones (extrack/tracking.py:1009-1010 uses the whole list).
+    """
+
+    def __init__(self, buckets, sigmas=None, device=0, min_len=None, max_len=None):
+        if len(buckets) < 1:
+            raise ValueError("No track could be detected. The loaded tracks seem empty. Errors often come from wrong input paths.")
+        self.ctx = _lib.Context(device)
+        self.shapes = []
+        for i, b in enumerate(buckets):
+            b = np.asarray(b, dtype=np.float64)
+            if b.ndim != 3:
+                raise ValueError("each bucket must be an array [n_tracks, len, dims]")
+            if b.shape[1] < 2:
+                raise ValueError("minimal track length = 2, here track length = %s" % b.shape[1])
+            s = None if sigmas is None else np.asarray(sigmas[i], dtype=np.float64)
+            if s is not None and (s.ndim != 3 or s.shape[:2] != b.shape[:2] or s.shape[2] not in (1, b.shape[2])):
+                raise ValueError("Localization error is not specified correctly: input_LocErr must match all_tracks")
+            if len(b):
+                self.ctx.upload_bucket(b, s)
+                self.shapes.append(b.shape)
+        if not self.shapes:
+            raise ValueError("No track could be detected. The loaded tracks seem empty. Errors often come from wrong input paths.")
+        lens = [s[1] for s in self.shapes]
+        self.min_len = int(min(lens) if min_len is None else min_len)
+        self.max_len = int(max(lens) if max_len is None else max_len)
+        self.has_sigma = sigmas is not None
+        self.n_tracks = int(sum(s[0] for s in self.shapes))
+        self.dims = int(self.shapes[0][2])
+
+    # ---- model handle -------------------------------------------------------------------------------------
+    def make_model(self, LocErr, ds, Fs, TrMat, pBL, cell_dims, nb_substeps, frame_len, slope_offset=None):
+        """LocErr: global localisation error array of shape (1,1,k) (k = 1 or dims), or None when the per-peak
+        errors uploaded with the buckets are to be used (then slope_offset = (slope, offset) or None)."""
+        ds = np.asarray(ds, float)
+        S = len(ds)
+        ps = p_stay_table(ds, S, nb_substeps, cell_dims)
+        if LocErr is None:
+            if not self.has_sigma:
+                raise ValueError("per-peak localisation errors requested but none were uploaded")
+            mode, le = (2, None) if slope_offset is not None else (1, None)
+            slope, offset = slope_offset if slope_offset is not None else (0.0, 0.0)
+        else:
+            le = np.asarray(LocErr, float).reshape(-1)
+            if len(le) not in (1, self.dims):
+                raise ValueError("Localization error is not specified correctly, in case of unique localization error specify a float "
+                                 "number; if one localization error per dimension, specify one value per dimension")
+            mode, slope, offset = 0, 0.0, 0.0
+        return _lib.ModelHandle(ds, Fs, TrMat, ps, pBL, nb_substeps, frame_len, self.min_len, self.max_len, locerr=le,
+                                locerr_mode=mode, slope=slope, offset=offset)
+
+    def loglik(self, model, per_track=False):
+        return self.ctx.loglik(model, per_track=per_track)
+
+    def predict(self, model):
+        """Posteriors for every uploaded bucket, in upload order: list of arrays [N_l, l, S]."""
+        return [self.ctx.predict(model, i) for i in range(len(self.shapes))]
+
+    def close(self):
+        self.ctx.close()

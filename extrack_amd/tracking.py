@@ -1,0 +1,353 @@
+"""Drop-in replacement for the track-likelihood path of ``extrack.tracking``.
+
+Same public names, argument meaning and error behaviour as the reference for THIS path
+(reference file:line relative to the reference root):
+
+  param_fitting     extrack/tracking.py:1299-1386  (fixed-window twin: extrack/tracking_0.py:918-1022)
+  predict_Bs        extrack/tracking.py:792-906    (twin: extrack/tracking_0.py:463-563)
+  cum_Proba_Cs      extrack/tracking.py:991-1088   (twin: extrack/tracking_0.py:637-715)
+  Proba_Cs          extrack/tracking_0.py:440-458
+  P_Cs_inter_bound_stats  extrack/tracking.py:109-318
+  extract_params    extrack/tracking.py:913-986
+  generate_params   extrack/tracking.py:1214-1290
+  get_params        extrack/tracking.py:1090-1212
+
+The recursion itself runs in hand-written HIP kernels for gfx950 through the C ABI in
+include/extrack_hip.h; nothing here computes likelihoods on the CPU.  The algorithm is the
+FIXED-WINDOW kernel (``P_Cs_inter_bound_stats``); ``threshold`` / ``max_nb_states`` / ``nb_max`` of the
+threshold-fusion variant are accepted for signature compatibility and ignored.
+``workers`` is accepted and ignored: the tracks are sharded over GPUs instead (extrack_amd.distributed).
+"""
+import numpy as np
+from scipy import linalg
+
+from . import engine
+from .engine import TrackSet
+from .lmfit_compat import Parameters, is_parameters, minimize
+
+__all__ = ["param_fitting", "predict_Bs", "cum_Proba_Cs", "Proba_Cs", "P_Cs_inter_bound_stats", "extract_params",
+           "generate_params", "get_params", "TrackSet"]
+
+
+# ------------------------------------------------------------------------------------------------------------
+# parameter plumbing
+# ------------------------------------------------------------------------------------------------------------
+def extract_params(params, dt, nb_states, nb_substeps, input_LocErr=None, Matrix_type=1):
+    """Parameters -> (LocErr, ds, Fs, TrMat, pBL); mirrors extrack/tracking.py:913-986.
+
+    ``nb_states`` is accepted and unused, exactly like the reference.  ``LocErr`` is a list: one
+    (1,1,k) array for a global error, or one per-peak array per bucket when ``input_LocErr`` is given
+    (affinely rescaled and clipped at 1e-6 if ``slope_LocErr``/``offset_LocErr`` are parameters)."""
+    if isinstance(dt, (list, dict)):
+        raise NotImplementedError("per-track time steps (dt as list/dict) belong to the threshold-fusion kernel, which is not built")
+    names = np.sort(list(params.keys()))
+    LocErr = [np.array([params[n].value for n in names if n.startswith("LocErr")])[None, None]]
+    if input_LocErr is not None:
+        if "slope_LocErr" in params:
+            sl, of = params["slope_LocErr"].value, params["offset_LocErr"].value
+            LocErr = [np.clip(le * sl + of, 0.000001, np.inf) for le in input_LocErr]
+        else:
+            LocErr = input_LocErr
+    Ds = np.array([params[n].value for n in names if n.startswith("D") and len(n) < 3])
+    Fs = np.array([params[n].value for n in names if n.startswith("F")])
+    S = len(Ds)
+    TrMat = np.zeros((S, S))
+    pBL = None
+    for n in params:
+        if n == "pBL":
+            pBL = params[n].value
+        elif n.startswith("p"):
+            TrMat[int(n[1]), int(n[2])] = params[n].value
+    TrMat = TrMat / nb_substeps
+    diag = np.arange(S)
+    if Matrix_type == 0:
+        TrMat[diag, diag] = 1 - np.sum(TrMat, 1)
+    if Matrix_type == 1:
+        TrMat = 1 - np.exp(-TrMat)
+        TrMat[diag, diag] = 1 - np.sum(TrMat, 1)
+    elif Matrix_type == 2:
+        TrMat[diag, diag] = -np.sum(TrMat, 1)
+        TrMat = linalg.expm(TrMat)
+    elif Matrix_type in (3, 4):
+        TrMat[diag, diag] = 0
+        G = np.copy(TrMat)
+        TrMat[diag, diag] = 1 - np.sum(TrMat, 1)
+        G[diag, diag] = -np.sum(G, 1)
+        TrMatG = linalg.expm(G)
+        TrMat = np.mean([TrMat, TrMatG], axis=0) if Matrix_type == 3 else (TrMat * TrMatG) ** 0.5
+    ds = np.sqrt(2 * Ds * dt)
+    return LocErr, ds, Fs, TrMat, pBL
+
+
+def generate_params(nb_states=3, LocErr_type=1, nb_dims=3, LocErr_bounds=[0.005, 0.1], D_max=10, Fractions_bounds=[0.001, 0.99],
+                    estimated_LocErr=None, estimated_Ds=None, estimated_Fs=None, estimated_transition_rates=0.1,
+                    slope_offsets_estimates=None):
+    """Initial Parameters for an n-state model; same names/values/bounds as extrack/tracking.py:1214-1290."""
+    rows = []
+    for s in range(nb_states):
+        v = 0.5 * s ** 2 * D_max / (nb_states - 1) ** 2 if estimated_Ds is None else estimated_Ds[s]
+        rows.append(dict(name="D%d" % s, value=v, min=0, max=D_max, vary=True))
+    geo = (LocErr_bounds[0] * LocErr_bounds[1]) ** 0.5
+    le = (lambda i: geo) if estimated_LocErr is None else (lambda i: estimated_LocErr[i])
+    lo, hi = LocErr_bounds
+    if LocErr_type == 1:
+        rows.append(dict(name="LocErr", value=le(0), min=lo, max=hi, vary=True))
+    elif LocErr_type == 2:
+        for d in range(nb_dims):
+            rows.append(dict(name="LocErr%d" % d, value=le(d), min=lo, max=hi, vary=True))
+    elif LocErr_type == 3:
+        rows.append(dict(name="LocErr0", value=le(0), min=lo, max=hi, vary=True))
+        rows.append(dict(name="LocErr1", expr="LocErr0"))
+        rows.append(dict(name="LocErr2", value=le(-1), min=lo, max=hi, vary=True))
+    if LocErr_type == 4:
+        rows.append(dict(name="slope_LocErr", value=slope_offsets_estimates[0], min=-1, max=20, vary=True))
+        rows.append(dict(name="offset_LocErr", value=slope_offsets_estimates[1], min=-1, max=1, vary=True))
+    F_expr = "1"
+    for s in range(nb_states - 1):
+        v = 1 / nb_states if estimated_Fs is None else estimated_Fs[s]
+        rows.append(dict(name="F%d" % s, value=v, min=Fractions_bounds[0], max=Fractions_bounds[1], vary=True))
+        F_expr += " - F%d" % s
+    rows.append(dict(name="F%d" % (nb_states - 1), expr=F_expr))
+    if not isinstance(estimated_transition_rates, (np.ndarray, list)):
+        estimated_transition_rates = [estimated_transition_rates] * (nb_states * (nb_states - 1))
+    idx = 0
+    for i in range(nb_states):
+        for j in range(nb_states):
+            if i != j:
+                rows.append(dict(name="p%d%d" % (i, j), value=estimated_transition_rates[idx], min=0.0001, max=1, vary=True))
+                idx += 1
+    rows.append(dict(name="pBL", value=0.1, min=0.0001, max=1, vary=True))
+    params = Parameters()
+    for r in rows:
+        params.add(**r)
+    return params
+
+
+_GP_VARY = {'LocErr': True, 'D0': True, 'D1': True, 'F0': True, 'p01': True, 'p10': True, 'pBL': True}
+_GP_EST = {'LocErr': 0.025, 'D0': 1e-20, 'D1': 0.05, 'F0': 0.45, 'p01': 0.05, 'p10': 0.05, 'pBL': 0.1}
+_GP_MIN = {'LocErr': 0.007, 'D0': 1e-12, 'D1': 0.00001, 'F0': 0.001, 'p01': 0.01, 'p10': 0.01, 'pBL': 0.01}
+_GP_MAX = {'LocErr': 0.6, 'D0': 1, 'D1': 10, 'F0': 0.999, 'p01': 1., 'p10': 1., 'pBL': 0.99}
+
+
+def get_params(nb_states=2, steady_state=False, vary_params=_GP_VARY, estimated_vals=_GP_EST, min_values=_GP_MIN, max_values=_GP_MAX):
+    """Parameters from explicit dicts; same construction as extrack/tracking.py:1090-1212 (the generic branch is
+    the only live one there: D_k are chained through ``D{k}_minus_D{k-1}`` increments, the last fraction is
+    ``1-F0-...``).  ``nb_states``/``steady_state`` are accepted and unused, like the reference."""
+    rows = []
+    if "slope_LocErr" in estimated_vals:
+        for n in ("slope_LocErr", "offset_LocErr"):
+            rows.append(dict(name=n, value=estimated_vals[n], min=min_values[n], max=max_values[n], vary=vary_params[n]))
+    if "LocErr" in estimated_vals:
+        LocErr = estimated_vals["LocErr"]
+        if type(LocErr) == float:
+            rows.append(dict(name="LocErr", value=LocErr, min=min_values["LocErr"], max=max_values["LocErr"], vary=vary_params["LocErr"]))
+        elif isinstance(LocErr, (np.ndarray, list)):
+            for s in range(len(LocErr)):
+                rows.append(dict(name="LocErr%d" % s, value=LocErr[s], min=min_values["LocErr"][s], max=max_values["LocErr"][s],
+                                 vary=vary_params["LocErr"][s]))
+    Ds = [k for k in vary_params if k.startswith("D")]
+    Fs = [k for k in vary_params if k.startswith("F")]
+    rows.append(dict(name="D0", value=estimated_vals["D0"], min=min_values["D0"], max=0.3, brute_step=0.04, vary=vary_params["D0"]))
+    last_D, sum_Ds, expr = "D0", estimated_vals["D0"], "D0"
+    for D in Ds[1:]:
+        rows.append(dict(name=D + "_minus_" + last_D, value=estimated_vals[D] - sum_Ds, min=0, max=max_values[D], vary=vary_params[D]))
+        expr = expr + "+" + D + "_minus_" + last_D
+        rows.append(dict(name=D, expr=expr))
+        last_D = D
+        sum_Ds += estimated_vals[D]
+    rows.append(dict(name="F0", value=estimated_vals["F0"], min=min_values["F0"], max=max_values["F0"], brute_step=0.04,
+                     vary=vary_params["F0"]))
+    expr = "1-F0"
+    for F in Fs[1:len(Ds) - 1]:
+        rows.append(dict(name=F, value=estimated_vals[F], min=0.001, max=0.99, vary=vary_params[F]))
+        expr = expr + "-" + F
+    rows.append(dict(name="F%d" % (len(Ds) - 1), expr=expr))
+    for p in vary_params:
+        if p.startswith("p"):
+            rows.append(dict(name=p, value=estimated_vals[p], min=min_values[p], max=max_values[p], vary=vary_params[p]))
+    params = Parameters()
+    for r in rows:
+        params.add(**r)
+    return params
+
+
+# ------------------------------------------------------------------------------------------------------------
+# kernel-level mirrors (one-off uploads; used by tests and for drop-in calls on small chunks)
+# ------------------------------------------------------------------------------------------------------------
+def _one_bucket(Cs, LocErr, isBL, min_len, device):
+    Cs = np.asarray(Cs, dtype=np.float64)
+    if Cs.ndim != 3:
+        raise ValueError("Cs must be [n_tracks, len, dims]")
+    L = Cs.shape[1]
+    if L < 2:
+        raise ValueError("minimal track length = 2, here track length = %s" % L)  # tracking.py:149-150
+    LocErr = np.asarray(LocErr, dtype=np.float64)
+    if LocErr.ndim != 3 or LocErr.shape[1] not in (1, L):
+        raise ValueError("Localization error is not specified correctly, in case of unique localization error specify a float "
+                         "number in estimated_vals['LocErr'].")  # tracking.py:143
+    per_peak = LocErr.shape[1] == L and not (L == 1)
+    if per_peak and LocErr.shape[0] != Cs.shape[0]:
+        LocErr = np.broadcast_to(LocErr, (Cs.shape[0],) + LocErr.shape[1:])
+    ts = TrackSet([Cs], [LocErr] if per_peak else None, device=device, min_len=max(int(min_len), 2),
+                  max_len=(L + 1 if isBL else L))
+    return ts, (None if per_peak else LocErr)
+
+
+def Proba_Cs(Cs, LocErr, ds, Fs, TrMat, pBL, isBL, cell_dims, nb_substeps, frame_len, min_len, threshold=None, max_nb_states=None,
+             device=0):
+    """Per-track log-likelihood LP_C[N] of one chunk (extrack/tracking_0.py:440-458), computed on the GPU."""
+    ts, le = _one_bucket(Cs, LocErr, isBL, min_len, device)
+    try:
+        model = ts.make_model(le, ds, Fs, TrMat, pBL, cell_dims, nb_substeps, frame_len)
+        return ts.loglik(model, per_track=True)[1]
+    finally:
+        ts.close()
+
+
+def P_Cs_inter_bound_stats(Cs, LocErr, ds, Fs, TrMat, pBL=0.1, isBL=1, cell_dims=[0.5], nb_substeps=1, frame_len=4, do_preds=0,
+                           min_len=3, device=0):
+    """Mirror of extrack/tracking.py:109-318 with one documented difference: the per-sequence matrix
+    ``LP[N, nB]`` is never materialised on the GPU (it is reduced in-kernel), so the first return value is
+    ``LP_C[:, None]`` - its logsumexp over axis 1 is what Proba_Cs computes from the reference's matrix.
+    Returns ``(LP_C[:, None], None, preds)``; ``preds`` is ``[]`` when ``do_preds`` is 0."""
+    ts, le = _one_bucket(Cs, LocErr, isBL, min_len, device)
+    try:
+        model = ts.make_model(le, ds, Fs, TrMat, pBL, cell_dims, nb_substeps, frame_len)
+        lpc = ts.loglik(model, per_track=True)[1]
+        preds = []
+        if do_preds:
+            if nb_substeps != 1:
+                raise ValueError("state predictions require nb_substeps == 1")
+            preds = ts.predict(model)[0]
+        return lpc[:, None], None, preds
+    finally:
+        ts.close()
+
+
+# ------------------------------------------------------------------------------------------------------------
+# objective
+# ------------------------------------------------------------------------------------------------------------
+_TRACKSET_CACHE = {}
+
+
+def _as_trackset(all_tracks, input_LocErr, device=0):
+    """The reference hands the objective a list of arrays at every call; keep ONE device copy per list."""
+    if isinstance(all_tracks, TrackSet):
+        return all_tracks
+    key = (tuple((id(a), a.shape, a.__array_interface__["data"][0]) for a in all_tracks),
+           None if input_LocErr is None else tuple(id(a) for a in input_LocErr), device)
+    ts = _TRACKSET_CACHE.get(key)
+    if ts is None:
+        while len(_TRACKSET_CACHE) >= 2:
+            _TRACKSET_CACHE.pop(next(iter(_TRACKSET_CACHE))).close()
+        ts = TrackSet(list(all_tracks), input_LocErr, device=device)
+        _TRACKSET_CACHE[key] = ts
+    return ts
+
+
+def _objective_model(params, ts, dt, cell_dims, input_LocErr, nb_states, nb_substeps, frame_len, Matrix_type):
+    LocErr, ds, Fs, TrMat, pBL = extract_params(params, dt, nb_states, nb_substeps, None, Matrix_type)
+    valid = bool(np.all(TrMat > 0) and np.all(Fs > 0) and np.all(ds[1:] - ds[:-1] >= 0))  # tracking.py:1017
+    if not valid:
+        return None
+    if ts.has_sigma:  # per-peak errors win over any LocErr parameter (tracking.py:926-932)
+        so = (params["slope_LocErr"].value, params["offset_LocErr"].value) if "slope_LocErr" in params else None
+        return ts.make_model(None, ds, Fs, TrMat, pBL, cell_dims, nb_substeps, frame_len, slope_offset=so)
+    return ts.make_model(LocErr[0], ds, Fs, TrMat, pBL, cell_dims, nb_substeps, frame_len)
+
+
+def cum_Proba_Cs(params, all_tracks, dt, cell_dims, input_LocErr, nb_states, nb_substeps, frame_len, verbose=1, workers=1,
+                 Matrix_type=1, threshold=0.2, max_nb_states=120, max_number_of_tracks_per_matrix=2000, comm=None):
+    """-sum of per-track log-likelihoods, or +inf for invalid parameters / NaN (extrack/tracking.py:991-1088).
+
+    ``all_tracks``: list of bucket arrays sorted short->long (as the reference passes it) or a ``TrackSet``.
+    ``comm``: optional extrack_amd.distributed.Comm; when given, ``all_tracks`` is this rank's shard and the
+    scalar is all-reduced over the ranks."""
+    ts = _as_trackset(all_tracks, input_LocErr)
+    model = _objective_model(params, ts, dt, cell_dims, input_LocErr, nb_states, nb_substeps, frame_len, Matrix_type)
+    if model is not None:
+        Cum_P = ts.loglik(model) if comm is None else comm.allreduce_loglik(ts, model)
+        if verbose == 1:
+            q = [p + " = " + str(np.round(params[p].value, 6)) for p in params]
+            print(Cum_P, q)
+        else:
+            print(".", end="")
+        out = -Cum_P
+    else:
+        out = np.inf
+        print("x", end="")
+        if verbose == 1:
+            print([p + " = " + str(np.round(params[p].value, 4)) for p in params])
+    if np.isnan(out):
+        out = np.inf
+        print("input parameters give nans, you may want to pick more suitable parameter initial values")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------
+# public API
+# ------------------------------------------------------------------------------------------------------------
+def param_fitting(all_tracks, dt, params=None, nb_states=2, nb_substeps=1, frame_len=6, verbose=1, workers=1, Matrix_type=1,
+                  method="bfgs", steady_state=False, cell_dims=[1], input_LocErr=None, threshold=0.2, max_nb_states=120,
+                  device=0, comm=None):
+    """Fit the model parameters to a length-bucketed track dict (extrack/tracking.py:1299-1386).
+
+    all_tracks: {str(len): ndarray[n_tracks, len, dims]}.  Returns the lmfit (or lmfit_compat) MinimizerResult:
+    ``.params[name].value``, ``.residual[0] == -log-likelihood``.  Extra keywords: ``device`` (GPU index) and
+    ``comm`` (distributed shard communicator)."""
+    if params is None:
+        params = generate_params(nb_states=nb_states, LocErr_type=1, LocErr_bounds=[0.005, 0.1], D_max=3,
+                                 Fractions_bounds=[0.001, 0.99], estimated_transition_rates=0.1)
+    _, tracks, sigmas = engine.sort_buckets(all_tracks, input_LocErr)
+    if len(tracks) < 1:
+        raise ValueError("No track could be detected. The loaded tracks seem empty. Errors often come from wrong input paths.")
+    if frame_len <= nb_substeps:  # tracking_0.py:1015-1017
+        print("Warning frame_len has to be at least nb_substeps + 1")
+        frame_len = nb_substeps + 1
+    print("cell_dims", cell_dims)
+    if comm is not None:
+        ts = comm.shard_trackset(tracks, sigmas, device=device)
+    else:
+        ts = TrackSet(tracks, sigmas, device=device)
+    try:
+        fit = minimize(cum_Proba_Cs, params,
+                       args=(ts, dt, cell_dims, sigmas, nb_states, nb_substeps, frame_len, verbose, workers, Matrix_type, threshold,
+                             max_nb_states, 2000, comm),
+                       method=method, nan_policy="propagate")
+    finally:
+        ts.close()
+    if verbose == 0:
+        print("")
+    return fit
+
+
+def predict_Bs(all_tracks, dt, params, cell_dims=[1], nb_states=4, frame_len=5, max_nb_states=200, threshold=0.1, workers=1,
+               input_LocErr=None, verbose=0, nb_max=1, device=0):
+    """Probability of each localisation to be in each state (extrack/tracking.py:792-906).
+
+    Returns {str(len): ndarray[n_tracks, len, nb_states]} keyed by every input key (empty arrays for empty
+    buckets), rows in input order.  ``nb_substeps`` is forced to 1 like the reference (:839); min/max length
+    come from ALL keys (:853-854)."""
+    keys, tracks, sigmas = engine.sort_buckets(all_tracks, input_LocErr)
+    if not is_parameters(params):
+        raise TypeError("params must be either of the class 'lmfit.parameter.Parameters' or a dictionary of the relevant parameters")
+    nb_substeps = 1
+    LocErr, ds, Fs, TrMat, pBL = extract_params(params, dt, nb_states, nb_substeps, None)
+    S = len(ds)
+    out = {l: np.empty((0, int(l), S)) for l in keys}
+    if not tracks:
+        return out
+    ts = TrackSet(tracks, sigmas, device=device, min_len=max(int(keys[0]), 2), max_len=int(keys[-1]))
+    try:
+        if sigmas is not None:
+            so = (params["slope_LocErr"].value, params["offset_LocErr"].value) if "slope_LocErr" in params else None
+            model = ts.make_model(None, ds, Fs, TrMat, pBL, cell_dims, 1, frame_len, slope_offset=so)
+        else:
+            model = ts.make_model(LocErr[0], ds, Fs, TrMat, pBL, cell_dims, 1, frame_len)
+        for arr, pr in zip(tracks, ts.predict(model)):
+            out[str(arr.shape[1])] = pr
+            if verbose:
+                print(".", end="")
+    finally:
+        ts.close()
+    return out

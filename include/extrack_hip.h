@@ -1,0 +1,117 @@
+/* extrack_hip.h - C ABI of libextrack_hip.so: the MI355X (gfx950) implementation of ExTrack's
+ * track-likelihood hot path.
+ *
+ * The reference (vanTeeffelenLab/ExTrack v1.6.3, pure Python/numpy) has no FFI seam for this path;
+ * the functions below are what a binding for it replaces (file:line relative to the reference root):
+ *
+ *   extrack_upload_bucket / extrack_attach_bucket
+ *       one length bucket of the {str(len): ndarray[N, len, D]} dict, as produced by
+ *       extrack/readers.py:82-97 and consumed at extrack/tracking.py:1346-1367 (param_fitting) and
+ *       :822-835 (predict_Bs); optional per-peak localisation errors = input_LocErr (tracking.py:1354).
+ *   extrack_loglik / extrack_loglik_async
+ *       sum over all buckets of Proba_Cs (extrack/tracking_0.py:440-458 -> P_Cs_inter_bound_stats,
+ *       extrack/tracking.py:109-318), i.e. the body of cum_Proba_Cs after extract_params
+ *       (extrack/tracking_0.py:654-700 / tracking.py:1009-1069): returns +sum(LL); the caller negates.
+ *   extrack_predict
+ *       P_Cs_inter_bound_stats(..., do_preds=1)[2] for one bucket (Pool_star_P_inter,
+ *       extrack/tracking_0.py:460-461, driven by predict_Bs :463-563).
+ *   extrack_p_stay_table
+ *       the field-of-view survival table, extrack/tracking.py:182-191.
+ *
+ * Conventions: plain C, no exceptions cross the boundary.  Every function returns 0 on success or a
+ * negative EXTRACK_E_* code; extrack_last_error() gives the message.  The caller owns every host
+ * buffer it passes; the library owns device copies made by extrack_upload_bucket.  A context is
+ * driven by one host thread at a time.  All arithmetic is IEEE fp64.
+ */
+#ifndef EXTRACK_HIP_H
+#define EXTRACK_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EXTRACK_ABI_VERSION 1
+
+#define EXTRACK_OK 0
+#define EXTRACK_E_INVALID (-1)     /* bad argument / unsupported configuration */
+#define EXTRACK_E_HIP (-2)         /* HIP runtime error (message has the HIP error string) */
+#define EXTRACK_E_NODEVICE (-3)    /* no usable gfx950 device */
+#define EXTRACK_E_UNSUPPORTED (-4) /* valid request outside the built kernel set (e.g. S^F too large for LDS) */
+
+typedef struct extrack_ctx extrack_ctx;
+
+/* Model parameters after extract_params (extrack/tracking.py:913-986) plus the dataset-global scalars
+ * that cum_Proba_Cs derives from the bucket list (tracking.py:1009-1010). */
+typedef struct extrack_model {
+    int32_t n_states;    /* S, 2..8 */
+    int32_t nb_substeps; /* ns, 1..4 */
+    int32_t frame_len;   /* F > ns, window of exactly enumerated states */
+    int32_t min_len;     /* smallest track length of the WHOLE dataset (all shards); the stay-in-FOV term starts at step max(min_len, 2) */
+    int32_t max_len;     /* largest track length of the WHOLE dataset: buckets of this length get isBL = 0 */
+    int32_t locerr_mode; /* 0: global locerr[]; 1: per-peak sigma uploaded with the bucket;
+                            2: per-peak, sigma' = clip(sigma*slope + offset, 1e-6, inf) (tracking.py:928-930) */
+    int32_t locerr_dims; /* mode 0: 1 (one value for all dims) or D (one per dim) */
+    int32_t reserved;
+    double locerr[3];    /* mode 0: localisation error (std) */
+    double slope, offset;
+    double pBL;          /* bleaching probability per step */
+    const double* ds;    /* [S] diffusion lengths sqrt(2 D dt), non-decreasing */
+    const double* Fs;    /* [S] initial fractions, > 0 */
+    const double* TrMat; /* [S*S] row-major per-substep transition probabilities P(i->j), > 0 */
+    const double* p_stay;/* [S^ns] probability of staying in the field of view; index r has digit c
+                            (r / S^c) % S with c = 0 the newest sub-state (extrack_p_stay_table) */
+} extrack_model;
+
+int extrack_abi_version(void);
+
+/* Creates a context on HIP device `device_id` (must be gfx950).  Owns one non-blocking stream. */
+int extrack_create(int device_id, extrack_ctx** out);
+void extrack_destroy(extrack_ctx* ctx);
+/* Message for the last error on ctx (or for a failed extrack_create when ctx == NULL). */
+const char* extrack_last_error(const extrack_ctx* ctx);
+
+/* Use an external HIP stream (hipStream_t) for all subsequent work, or NULL to go back to the
+ * context's own stream. */
+int extrack_set_stream(extrack_ctx* ctx, void* hip_stream);
+
+/* Copies one length bucket to the device.  tracks: host [n][len][dims] C-order fp64.
+ * sigma: NULL or host [n][len][sigma_dims] per-peak localisation errors, sigma_dims in {1, dims}.
+ * Buckets may be uploaded in any order; ids are dense from 0. */
+int extrack_upload_bucket(extrack_ctx* ctx, const double* tracks, int64_t n, int32_t len, int32_t dims,
+                          const double* sigma, int32_t sigma_dims, int32_t* bucket_id_out);
+/* Same, for buffers that already live on this device (e.g. torch tensors): no copy, caller keeps
+ * them alive until extrack_clear_buckets / extrack_destroy. */
+int extrack_attach_bucket(extrack_ctx* ctx, const double* d_tracks, int64_t n, int32_t len, int32_t dims,
+                          const double* d_sigma, int32_t sigma_dims, int32_t* bucket_id_out);
+int extrack_clear_buckets(extrack_ctx* ctx);
+int extrack_bucket_count(const extrack_ctx* ctx);
+
+/* One log-likelihood evaluation over every bucket of the context.
+ * total_ll (host, required): sum of per-track log-likelihoods (NOT negated).
+ * per_track (host, may be NULL): per-track log-likelihoods, buckets concatenated in id order. */
+int extrack_loglik(extrack_ctx* ctx, const extrack_model* model, double* total_ll, double* per_track);
+/* Enqueues the evaluation on the context's stream and leaves the scalar in device memory
+ * (d_total_ll, 8 bytes, device pointer) without synchronising - for a following RCCL all-reduce. */
+int extrack_loglik_async(extrack_ctx* ctx, const extrack_model* model, double* d_total_ll);
+
+/* State posteriors of one bucket: preds host [n][len][S].  model->nb_substeps must be 1
+ * (predict_Bs forces it, extrack/tracking.py:839). */
+int extrack_predict(extrack_ctx* ctx, const extrack_model* model, int32_t bucket_id, double* preds);
+
+/* Device time (ms, HIP events on the context's stream) spent in the track kernels of the last
+ * extrack_loglik / extrack_loglik_async / extrack_predict call (valid after the stream is idle). */
+int extrack_last_kernel_ms(extrack_ctx* ctx, float* ms);
+/* Launch geometry of the last track kernel: info[0] blocks, [1] threads/block, [2] LDS bytes/block,
+ * [3] tracks/block, [4] occupancy (blocks/CU), [5] compute units. */
+int extrack_last_launch_info(const extrack_ctx* ctx, int32_t info[6]);
+
+/* Host helper: p_stay table (extrack/tracking.py:182-191).  out has S^ns entries. */
+int extrack_p_stay_table(const double* ds, int32_t n_states, int32_t nb_substeps, const double* cell_dims,
+                         int32_t n_cell_dims, double* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EXTRACK_HIP_H */

@@ -1,0 +1,120 @@
+// TEST INFRASTRUCTURE ONLY: runs the kernel body of extrack_amd/csrc/xt_kernel.h on CPU threads
+// (one std::thread per GPU thread, a pthread barrier for __syncthreads) so that the index logic and
+// the extended-range arithmetic can be checked against the oracle without a GPU.  Never shipped,
+// never reachable from the product package.
+#include <pthread.h>
+#include <string.h>
+
+#include <thread>
+#include <vector>
+
+#include "../../extrack_amd/csrc/xt_dispatch.h"
+#include "../../extrack_amd/csrc/xt_tables.h"
+
+struct HostCtx {
+    int tid_, nthreads_, block_, nblocks_;
+    double* smem_;
+    pthread_barrier_t* bar_;
+    int tid() const { return tid_; }
+    int nthreads() const { return nthreads_; }
+    int block() const { return block_; }
+    int nblocks() const { return nblocks_; }
+    double* smem() const { return smem_; }
+    void sync() { pthread_barrier_wait(bar_); }
+    void atomic_max_i32(int* p, int v)
+    {
+        int old = __atomic_load_n(p, __ATOMIC_RELAXED);
+        while (old < v && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {
+        }
+    }
+    void atomic_add_f64(double* p, double v)
+    {
+        uint64_t* pi = (uint64_t*)p;
+        uint64_t old = __atomic_load_n(pi, __ATOMIC_RELAXED);
+        for (;;) {
+            double d;
+            memcpy(&d, &old, 8);
+            d += v;
+            uint64_t nw;
+            memcpy(&nw, &d, 8);
+            if (__atomic_compare_exchange_n(pi, &old, nw, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) break;
+        }
+    }
+};
+
+struct EmulLauncher {
+    XtKernelArgs a;
+    int threads, nblocks;
+    size_t lds_bytes;
+    template <int G_, int D, int K, bool PREDS>
+    bool run()
+    {
+        for (int b = 0; b < nblocks; ++b) {
+            std::vector<double> smem(lds_bytes / 8 + 16, 0.0);
+            pthread_barrier_t bar;
+            pthread_barrier_init(&bar, nullptr, threads);
+            std::vector<std::thread> th;
+            for (int t = 0; t < threads; ++t)
+                th.emplace_back([&, t]() {
+                    HostCtx cx{t, threads, b, nblocks, smem.data(), &bar};
+                    xt_track_body<G_, D, K, PREDS>(a, cx);
+                });
+            for (auto& x : th) x.join();
+            pthread_barrier_destroy(&bar);
+        }
+        return true;
+    }
+};
+
+extern "C" int xt_emul_run(const double* tracks, const double* sigma, long long N, int L, int D, int KS, int S, int NS, int F,
+                           int isBL, int min_len, int locerr_mode, int locerr_dims, const double* locerr, double slope,
+                           double offset, double pBL, const double* ds, const double* Fs, const double* TrMat,
+                           const double* p_stay, int preds, int nblocks, double* ll_out, double* preds_out, double* total,
+                           int* info /* [4]: tpb, threads, lds_bytes, E */)
+{
+    XtConfig cfg;
+    std::string err = xt_build_config(S, NS, F, cfg);
+    if (!err.empty()) return -1;
+    XtModelHost m{S, NS, locerr_dims, {0, 0, 0}, slope, offset, pBL, ds, Fs, TrMat, p_stay};
+    for (int k = 0; k < 3; ++k) m.locerr[k] = locerr ? locerr[k < locerr_dims ? k : 0] : 0.0;
+    std::vector<double> blob;
+    xt_build_blob(m, cfg, blob);
+    const int K = locerr_mode == 0 ? locerr_dims : KS;
+    EmulLauncher l;
+    memset(&l.a, 0, sizeof(l.a));
+    xt_fill_args_from_config(cfg, l.a);
+    int tpb, threads;
+    xt_geometry(cfg, D, K, tpb, threads);
+    if (threads > 1024) return -2;
+    std::vector<double> partials(nblocks, 0.0);
+    l.a.tracks = tracks;
+    l.a.sigma = locerr_mode ? sigma : nullptr;
+    l.a.blob = blob.data();
+    l.a.base_tab = cfg.base_tab.data();
+    l.a.off_tab = cfg.off_tab.data();
+    l.a.ll_out = ll_out;
+    l.a.partials = partials.data();
+    l.a.preds_out = preds_out;
+    l.a.N = N;
+    l.a.L = L;
+    l.a.TPB = tpb;
+    l.a.isBL = isBL;
+    l.a.min_len = min_len;
+    l.a.locerr_mode = locerr_mode;
+    l.a.KS = KS;
+    l.a.ll_const = -(double)(L - 1) * D * 0.5 * XT_LOG2PI;
+    l.threads = threads;
+    l.nblocks = nblocks;
+    l.lds_bytes = xt_lds_bytes(cfg, D, K, tpb);
+    if (info) {
+        info[0] = tpb;
+        info[1] = threads;
+        info[2] = (int)l.lds_bytes;
+        info[3] = cfg.E;
+    }
+    if (!xt_dispatch(cfg.G, D, K, preds != 0, l)) return -3;
+    double s = 0.0;
+    for (double p : partials) s += p;
+    if (total) *total = s;
+    return 0;
+}

@@ -1,0 +1,51 @@
+"""ctypes driver for tests/emul/libxt_emul.so (test infrastructure)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        so = os.path.join(HERE, "libxt_emul.so")
+        src = os.path.join(HERE, "emul.cpp")
+        hdrs = [os.path.join(HERE, "..", "..", "extrack_amd", "csrc", h) for h in ("xt_kernel.h", "xt_math.h", "xt_tables.h", "xt_dispatch.h")]
+        if not os.path.exists(so) or any(os.path.getmtime(f) > os.path.getmtime(so) for f in [src] + hdrs):
+            import subprocess
+            subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-pthread", "-o", so, src])
+        _lib = C.CDLL(so)
+    return _lib
+
+
+def dp(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def run(Cs, LE, ds, Fs, T, pBL, isBL, p_stay, ns, F, min_len, preds=False, nblocks=2, slope=None, offset=None):
+    Cs = np.ascontiguousarray(Cs, float)
+    N, L, D = Cs.shape
+    S = len(ds)
+    LE = np.ascontiguousarray(LE, float)
+    if LE.shape[1] == 1 and L != 1:
+        mode, K, KS = 0, LE.shape[2], 1
+        locerr = np.zeros(3)
+        locerr[:K] = LE[0, 0]
+        sigma = None
+    else:
+        mode, KS = (2 if slope is not None else 1), LE.shape[2]
+        K, locerr, sigma = KS, np.zeros(3), LE
+    ll = np.zeros(N)
+    pr = np.full((N, L, S), -1.0) if preds else None
+    tot = C.c_double(0)
+    info = (C.c_int * 4)()
+    ds, Fs, T, p_stay = [np.ascontiguousarray(x, float) for x in (ds, Fs, T, p_stay)]
+    rc = lib().xt_emul_run(dp(Cs), dp(sigma), C.c_longlong(N), L, D, KS, S, ns, F, int(isBL), int(min_len), mode, K, dp(locerr),
+                           C.c_double(slope or 0.0), C.c_double(offset or 0.0), C.c_double(pBL), dp(ds), dp(Fs), dp(T), dp(p_stay),
+                           int(preds), nblocks, dp(ll), dp(pr), C.byref(tot), info)
+    if rc != 0:
+        raise RuntimeError("emul rc=%d" % rc)
+    return ll, pr, tot.value, list(info)

@@ -1,0 +1,183 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI, against golden vectors produced by the
+reference and against the oracle on seeded inputs.  Tolerances (fp64): per-track LL abs 1e-10,
+total rel 1e-12, posteriors abs 1e-9 (BASELINE.json north_star)."""
+import numpy as np
+import pytest
+
+from conftest import case_inputs
+
+pytestmark = pytest.mark.gpu
+
+TOL_LL = 1e-10
+TOL_PRED = 1e-9
+
+
+def _params(vals):
+    from extrack_amd.lmfit_compat import Parameters
+    p = Parameters()
+    for k, v in vals.items():
+        p.add(k, value=v)
+    return p
+
+
+def test_library_loaded_and_device():
+    from extrack_amd import _lib
+    ctx = _lib.Context(0)
+    assert ctx._lib.extrack_abi_version() == 1
+    ctx.close()
+
+
+def test_appendix_b(appendix_b):
+    from extrack_amd import tracking as T
+    b = appendix_b
+    c = np.array(b["track"])[None]
+    LE = np.array([[[b["LocErr"]]]])
+    for row in b["rows"]:
+        lpc = T.Proba_Cs(c, LE, b["ds"], b["Fs"], b["TrMat"], b["pBL"], row["isBL"], b["cell_dims"], row["ns"], row["F"], b["min_len"])
+        assert abs(lpc[0] - row["LP_C"]) < TOL_LL
+        if "preds0" in row:
+            _, _, preds = T.P_Cs_inter_bound_stats(c, LE, b["ds"], b["Fs"], b["TrMat"], b["pBL"], row["isBL"], b["cell_dims"], 1,
+                                                   row["F"], 1, b["min_len"])
+            np.testing.assert_allclose(preds[0, :, 0], row["preds0"], atol=TOL_PRED, rtol=0)
+
+
+def test_kernel_cases_golden(kernel_cases):
+    """All 1004 reference-generated kernel cases: S in 2..5, ns in 1..3, D in 1..3, scalar / per-dim / per-peak
+    localisation error, isBL 0/1, L from 2 (shorter than the window) to 30."""
+    from extrack_amd import tracking as T
+    meta, data = kernel_cases
+    worst_ll = worst_pr = 0.0
+    n = 0
+    for row in meta:
+        x = case_inputs(row, data)
+        do_preds = row["ns"] == 1
+        lp, _, preds = T.P_Cs_inter_bound_stats(x["Cs"], x["LE"], x["ds"], x["Fs"], x["T"], row["pBL"], row["isBL"], row["cell_dims"],
+                                                row["ns"], row["F"], int(do_preds), row["min_len"])
+        d = np.abs(lp[:, 0] - x["LPC"]).max()
+        assert d < TOL_LL, (row, d)
+        worst_ll = max(worst_ll, d)
+        if do_preds:
+            dp = np.abs(preds - x["preds"]).max()
+            assert dp < TOL_PRED, (row, dp)
+            worst_pr = max(worst_pr, dp)
+        n += 1
+    print("cases", n, "worst |dLL|", worst_ll, "worst |dpred|", worst_pr)
+
+
+def _tracks(data, pre, keys):
+    return {k: data[pre + k] for k in keys}
+
+
+def test_end_to_end_objective_and_predict(end_to_end):
+    from extrack_amd import tracking as T
+    info, data = end_to_end
+    e1 = info["e1"]
+    tr = _tracks(data, "e1_tr_", e1["keys"])
+    p = _params(e1["values"])
+    _, lst, _ = T.engine.sort_buckets(tr)
+    for name, ref in e1["cum"].items():
+        F, ns = int(name[1]), int(name[-1])
+        val = T.cum_Proba_Cs(p, lst, e1["dt"], e1["cell_dims"], None, 2, ns, F, verbose=0)
+        assert abs(val - ref) < 1e-12 * abs(ref), (name, val, ref)
+    pr = T.predict_Bs(tr, e1["dt"], p, cell_dims=e1["cell_dims"], nb_states=2, frame_len=6)
+    for k in e1["keys"]:
+        np.testing.assert_allclose(pr[k], data["e1_pred_F6_" + k], atol=TOL_PRED, rtol=0)
+
+
+def test_end_to_end_per_peak_locerr(end_to_end):
+    from extrack_amd import tracking as T
+    info, data = end_to_end
+    e2 = info["e2"]
+    tr = _tracks(data, "e2_tr_", e2["keys"])
+    sig = _tracks(data, "e2_sig_", e2["keys"])
+    _, lst, lsig = T.engine.sort_buckets(tr, sig)
+    v = T.cum_Proba_Cs(_params(e2["values"]), lst, e2["dt"], e2["cell_dims"], lsig, 3, 1, 4, verbose=0)
+    assert abs(v - e2["cum_F4_ns1_affine"]) < 1e-12 * abs(v)
+    praw = _params(e2["values_raw"])
+    v = T.cum_Proba_Cs(praw, lst, e2["dt"], e2["cell_dims"], lsig, 3, 1, 4, verbose=0)
+    assert abs(v - e2["cum_F4_ns1_raw"]) < 1e-12 * abs(v)
+    v = T.cum_Proba_Cs(praw, lst, e2["dt"], e2["cell_dims"], lsig, 3, 2, 3, verbose=0)
+    assert abs(v - e2["cum_F3_ns2_raw"]) < 1e-12 * abs(v)
+    pr = T.predict_Bs(tr, e2["dt"], praw, cell_dims=e2["cell_dims"], nb_states=3, frame_len=4, input_LocErr=sig)
+    for k in e2["keys"]:
+        np.testing.assert_allclose(pr[k], data["e2_pred_F4_raw_" + k], atol=TOL_PRED, rtol=0)
+
+
+def test_invalid_params_inf(end_to_end):
+    from extrack_amd import tracking as T
+    _, data = end_to_end
+    bad = _params(dict(D0=0.25, D1=1e-3, LocErr=0.02, F0=0.6, F1=0.4, p01=0.1, p10=0.1, pBL=0.1))
+    assert T.cum_Proba_Cs(bad, [data["e1_tr_3"]], 0.02, [1], None, 2, 1, 4, verbose=0) == np.inf
+
+
+def test_c1_config_objective():
+    """BASELINE.json configs[0]: sim_FOV(10k) fixture, reference objective value."""
+    import json
+    import os
+    from conftest import GOLDEN
+    from extrack_amd import tracking as T
+    info = json.load(open(os.path.join(GOLDEN, "c1_simfov_10k.json")))
+    data = np.load(os.path.join(GOLDEN, "c1_simfov_10k.npz"))
+    tr = {k: data["tr_" + k] for k in info["keys"]}
+    _, lst, _ = T.engine.sort_buckets(tr)
+    v = T.cum_Proba_Cs(_params(info["values"]), lst, info["dt"], info["cell_dims"], None, 2, 1, info["frame_len"], verbose=0)
+    assert abs(v - info["cum_Proba_Cs"]) < 1e-12 * abs(v), (v, info["cum_Proba_Cs"])
+
+
+@pytest.mark.parametrize("S,ns,F,L,N", [(2, 1, 6, 30, 5000), (3, 1, 6, 17, 600), (4, 1, 5, 20, 200), (4, 3, 4, 12, 24), (2, 2, 6, 40, 500),
+                                         (3, 1, 4, 50, 700), (2, 1, 9, 25, 300), (4, 1, 6, 14, 40)])
+def test_seeded_vs_oracle(S, ns, F, L, N):
+    """Seeded synthetic batches at sizes the numpy oracle finishes in seconds (incl. multi-wave tracks:
+    S=3,F=6 -> 243 groups; S=4,F=6 -> 1024 groups; S=2,F=9 -> 256 groups)."""
+    from extrack_amd import synth, tracking as T
+    from oracle import oracle_np as O
+    rng = np.random.default_rng(S * 100 + F)
+    Ds = np.sort(rng.uniform(0.0, 0.3, S))
+    Ds[0] = 0.0
+    Tm = np.full((S, S), 0.05)
+    Tm[np.arange(S), np.arange(S)] = 1 - 0.05 * (S - 1)
+    Fs = np.full(S, 1.0 / S)
+    Cs = synth.brownian_tracks(N, L, Ds, Tm, Fs, seed=S + F)
+    ds = np.sqrt(2 * Ds * 0.02) + 1e-3
+    LE = np.array([[[0.02]]])
+    TT = Tm.copy()
+    ref = np.concatenate([O.proba_cs(Cs[a:a + 100], LE, ds, Fs, TT, 0.1, 1, [1.0], ns, F, 3) for a in range(0, N, 100)])
+    got = T.Proba_Cs(Cs, LE, ds, Fs, TT, 0.1, 1, [1.0], ns, F, 3)
+    assert np.abs(got - ref).max() < TOL_LL, np.abs(got - ref).max()
+    if ns == 1 and N <= 1000:
+        _, _, preds = T.P_Cs_inter_bound_stats(Cs[:100], LE, ds, Fs, TT, 0.1, 0, [1.0], 1, F, 1, 3)
+        _, pref = O.p_cs_inter_bound_stats(Cs[:100], LE, ds, Fs, TT, 0.1, 0, [1.0], 1, F, 1, 3)
+        assert np.abs(preds - pref).max() < TOL_PRED
+
+
+def test_full_size_properties():
+    """BASELINE.json configs[1] at full size (1e6 x 30): size-independent properties.
+    (a) total == sum of per-track values (rel 1e-12); (b) permutation invariance of the total;
+    (c) the total of a 5e5 + 5e5 split equals the whole (additivity over shards, what the multi-GPU path relies on);
+    (d) a 2000-track slice matches the oracle."""
+    from extrack_amd import synth, tracking as T
+    from oracle import oracle_np as O
+    N, L = 1000000, 30
+    Cs = synth.brownian_tracks(N, L, [0.0, 0.25], [[.9, .1], [.1, .9]], [.6, .4], seed=0)
+    vals = dict(D0=0.0, D1=0.25, LocErr=0.02, F0=0.6, F1=0.4, p01=0.1, p10=0.1, pBL=0.1)
+    p = _params(vals)
+    ts = T.TrackSet([Cs])
+    model = T._objective_model(p, ts, 0.02, [1], None, 2, 1, 6, 1)
+    tot, per = ts.loglik(model, per_track=True)
+    ts.close()
+    assert np.all(np.isfinite(per))
+    assert abs(tot - per.sum()) < 1e-12 * abs(tot)
+    ref = O.proba_cs(Cs[:2000], np.array([[[0.02]]]), np.sqrt(2 * np.array([0.0, 0.25]) * 0.02), [.6, .4],
+                     T.extract_params(p, 0.02, 2, 1)[3], 0.1, 0, [1], 1, 6, 30)
+    assert np.abs(per[:2000] - ref).max() < TOL_LL
+    perm = np.random.default_rng(1).permutation(N)
+    ts2 = T.TrackSet([Cs[perm]])
+    tot2 = ts2.loglik(T._objective_model(p, ts2, 0.02, [1], None, 2, 1, 6, 1))
+    ts2.close()
+    assert abs(tot2 - tot) < 1e-12 * abs(tot)
+    parts = 0.0
+    for a, b in ((0, N // 2), (N // 2, N)):
+        t3 = T.TrackSet([Cs[a:b]])
+        parts += t3.loglik(T._objective_model(p, t3, 0.02, [1], None, 2, 1, 6, 1))
+        t3.close()
+    assert abs(parts - tot) < 1e-12 * abs(tot)
