@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libextrack_hip.so")
+LIB_PATH = os.environ.get("EXTRACK_HIP_LIB", os.path.join(_HERE, "libextrack_hip.so"))
 
 EXPORTS = [
     "extrack_abi_version", "extrack_create", "extrack_destroy", "extrack_last_error", "extrack_set_stream",

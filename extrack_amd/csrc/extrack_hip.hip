@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <map>
@@ -11,6 +12,7 @@
 
 #include "../../include/extrack_hip.h"
 #include "xt_dispatch.h"
+#include "xt_fast2.h"
 #include "xt_tables.h"
 
 // ------------------------------------------------------------------------------------------------
@@ -25,6 +27,19 @@ struct DevCtx {
     __device__ __forceinline__ int nblocks() const { return gridDim.x; }
     __device__ __forceinline__ double* smem() const { return xt_smem; }
     __device__ __forceinline__ void sync() { __syncthreads(); }
+    __device__ __forceinline__ int lane() const { return threadIdx.x & 63; }
+    __device__ __forceinline__ int wave_in_block() const { return threadIdx.x >> 6; }
+    __device__ __forceinline__ int waves_per_block() const { return blockDim.x >> 6; }
+    // LDS operations of one wavefront execute in order; only the compiler must be kept from moving
+    // LDS accesses across the point where other lanes' data is consumed.
+    __device__ __forceinline__ void wave_sync()
+    {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    __device__ __forceinline__ int shfl_xor_i32(int v, int m) { return __shfl_xor(v, m, 64); }
+    __device__ __forceinline__ double shfl_xor_f64(double v, int m) { return __shfl_xor(v, m, 64); }
     __device__ __forceinline__ void atomic_max_i32(int* p, int v)
     {
         __hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -42,6 +57,13 @@ __global__ void __launch_bounds__(MAXT) xt_track_kernel(XtKernelArgs a)
 {
     DevCtx cx;
     xt_track_body<G_, D, K, PREDS>(a, cx);
+}
+
+template <int F, int D, int K>
+__global__ void __launch_bounds__(64 * XT_F2_WAVES) xt_ll_s2_kernel(XtKernelArgs a)
+{
+    DevCtx cx;
+    xt_ll_s2_body<F, D, K>(a, cx);
 }
 
 // Fixed-order reduction of the per-block partial sums (deterministic for a given launch geometry).
@@ -74,6 +96,7 @@ struct XtBucket {
 struct extrack_ctx {
     int device = 0;
     int n_cu = 0;
+    int oversub = 8;  // block generations per CU (EXTRACK_OVERSUB overrides; tuning knob)
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     std::vector<XtBucket> buckets;
@@ -141,6 +164,10 @@ extern "C" int extrack_create(int device_id, extrack_ctx** out)
     extrack_ctx* c = new extrack_ctx();
     c->device = device_id;
     c->n_cu = prop.multiProcessorCount;
+    if (const char* ev = getenv("EXTRACK_OVERSUB")) {
+        int v = atoi(ev);
+        if (v >= 1 && v <= 64) c->oversub = v;
+    }
 #define XT_CREATE(call)                                                             \
     if ((e = (call)) != hipSuccess) {                                               \
         g_create_err = std::string(#call) + ": " + hipGetErrorString(e);            \
@@ -335,6 +362,7 @@ struct DevLauncher {
     int threads;
     size_t lds;
     int grid_cap;  // upper bound on blocks (partials capacity reserved by the caller)
+    int tracks_per_block = 1;
     int grid = 0, occ = 0;
     hipError_t herr = hipSuccess;
 
@@ -343,6 +371,12 @@ struct DevLauncher {
     {
         if (threads <= 256) return launch(xt_track_kernel<G_, D, K, PREDS, 256>);
         return launch(xt_track_kernel<G_, D, K, PREDS, 1024>);
+    }
+
+    template <int F, int D, int K>
+    bool run_f2()
+    {
+        return launch(xt_ll_s2_kernel<F, D, K>);
     }
 
     template <class KernT>
@@ -362,8 +396,11 @@ struct DevLauncher {
             it = ctx->occ_cache.emplace(key, o < 1 ? 1 : o).first;
         }
         occ = it->second;
-        const int64_t nbatch = (a.N + a.TPB - 1) / a.TPB;
-        int64_t gmax = (int64_t)occ * ctx->n_cu;
+        // Oversubscribe the CUs: waves of equal work do NOT progress equally (VALU issue is arbitrated by age), so a
+        // static one-wave-set-per-CU split ends in an under-occupied tail; with several block generations per CU the
+        // hardware dispatcher backfills as blocks retire.
+        const int64_t nbatch = (a.N + tracks_per_block - 1) / tracks_per_block;
+        int64_t gmax = (int64_t)occ * ctx->n_cu * ctx->oversub;
         grid = (int)(nbatch < gmax ? nbatch : gmax);
         if (grid > grid_cap) grid = grid_cap;
         hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, ctx->stream, a);
@@ -384,7 +421,7 @@ static int xt_reserve_partials(extrack_ctx* ctx, size_t n)
     return EXTRACK_OK;
 }
 
-static const int XT_MAX_BLOCKS_PER_CU = 8;
+static const int XT_MAX_BLOCKS_PER_CU = 512;  // partial-sum slots reserved per bucket and CU
 
 // Launches the track kernel for one bucket; partial sums go to d_partials[poff .. poff+grid).
 static int xt_launch_bucket(extrack_ctx* ctx, const extrack_model* m, XtBucket& b, bool preds, double* d_ll, double* d_preds,
@@ -405,10 +442,19 @@ static int xt_launch_bucket(extrack_ctx* ctx, const extrack_model* m, XtBucket& 
     memset(&l.a, 0, sizeof(l.a));
     xt_fill_args_from_config(c, l.a);
     int tpb, threads;
-    xt_geometry(c, D, K, tpb, threads);
-    if (threads > 1024) return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "n_states^(frame_len-nb_substeps) > 1024 groups per track is not built");
+    const bool fast2 = xt_use_fast2(c.S, c.NS, c.F, preds);
+    if (fast2) {
+        const int tpw = 64 >> (c.F - 1);
+        tpb = tpw * XT_F2_WAVES;
+        threads = 64 * XT_F2_WAVES;
+        l.lds = (size_t)(((xt_tab_doubles(2, 2) + 1) & ~1) + XT_F2_WAVES * xt_f2_wave_doubles(D, K, m->locerr_mode ? b.KS : 0, tpw)) * sizeof(double);
+    } else {
+        xt_geometry(c, D, K, tpb, threads);
+        if (threads > 1024) return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "n_states^(frame_len-nb_substeps) > 1024 groups per track is not built");
+        l.lds = xt_lds_bytes(c, D, K, tpb);
+    }
     l.threads = threads;
-    l.lds = xt_lds_bytes(c, D, K, tpb);
+    l.tracks_per_block = tpb;
     if (l.lds > 160 * 1024) return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "sequence state does not fit the 160 KiB LDS of a CU");
     l.grid_cap = ctx->n_cu * XT_MAX_BLOCKS_PER_CU;
     l.a.tracks = b.d_tracks;
@@ -427,7 +473,8 @@ static int xt_launch_bucket(extrack_ctx* ctx, const extrack_model* m, XtBucket& 
     l.a.locerr_mode = m->locerr_mode;
     l.a.KS = b.KS ? b.KS : 1;
     l.a.ll_const = -(double)(b.L - 1) * D * 0.5 * XT_LOG2PI;
-    if (!xt_dispatch(c.G, D, K, preds, l))
+    const bool ok = fast2 ? xt_dispatch_f2(c.F, D, K, l) : xt_dispatch(c.G, D, K, preds, l);
+    if (!ok)
         return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, preds ? "posteriors are built for n_states <= 6" : "kernel variant not built");
     if (l.herr != hipSuccess) return xt_fail(ctx, EXTRACK_E_HIP, std::string("kernel launch: ") + hipGetErrorString(l.herr));
     ctx->launch_info[0] = l.grid;

@@ -36,3 +36,25 @@ static inline bool xt_dispatch(int G, int D, int K, bool preds, L& l)
     if (G == 4) return xt_dispatch_d<4, false>(D, K, l);
     return xt_dispatch_d<0, false>(D, K, l);
 }
+
+// ---- two-state wave-synchronous fast path (xt_fast2.h): run<F, D, K>()
+template <int FF, class L>
+static inline bool xt_dispatch_f2_dk(int D, int K, L& l)
+{
+    if (D == 1 && K == 1) return l.template run_f2<FF, 1, 1>();
+    if (D == 2 && K == 1) return l.template run_f2<FF, 2, 1>();
+    if (D == 2 && K == 2) return l.template run_f2<FF, 2, 2>();
+    if (D == 3 && K == 1) return l.template run_f2<FF, 3, 1>();
+    if (D == 3 && K == 3) return l.template run_f2<FF, 3, 3>();
+    return false;
+}
+
+template <class L>
+static inline bool xt_dispatch_f2(int F, int D, int K, L& l)
+{
+    if (F == 4) return xt_dispatch_f2_dk<4>(D, K, l);
+    if (F == 5) return xt_dispatch_f2_dk<5>(D, K, l);
+    if (F == 6) return xt_dispatch_f2_dk<6>(D, K, l);
+    if (F == 7) return xt_dispatch_f2_dk<7>(D, K, l);
+    return false;
+}

@@ -1,0 +1,428 @@
+// Wave-synchronous fast path of the track-likelihood recursion for TWO-STATE models with one
+// substep (S = 2, ns = 1: BASELINE configs[0], [1], [3]) and frame_len F <= 7, log-likelihood only.
+//
+// Same mathematics as xt_kernel.h (fuse -> expand -> integrate with extended-range linear weights);
+// what differs is the mapping onto the machine:
+//   * a track's 2^(F-1) groups are lanes of ONE wavefront (64 / 2^(F-1) tracks per wave), so a step
+//     needs no workgroup barrier - LDS operations of a wave complete in order;
+//   * the step loop is unrolled over the F phases of the circular digit buffer, so every LDS address
+//     is a loop-invariant register (no per-step index arithmetic, no index tables);
+//   * sequence storage is XOR-swizzled (index ^= 31 when bit 5 is set) so that the 32 lanes of an
+//     LDS access group hit 32 distinct 8-byte bank pairs in every phase (v1: 53 % of LDS cycles
+//     were bank conflicts);
+//   * the track's positions are staged through LDS in 32-position chunks with coalesced loads (one
+//     HBM read of the track, nothing else), and read back as a broadcast;
+//   * the three reciprocals of a step (1/W, 1/den_0, 1/den_1) come from ONE v_rcp_f64 of the
+//     product; means are carried as M/W implicitly until the single multiply that stores them;
+//   * per-track log() is replaced by a running product of the (mantissa, exponent) likelihoods -
+//     one log per track slot at the end of the kernel (unless per-track output is requested).
+#pragma once
+#include "xt_kernel.h"
+
+#define XT_F2_CHUNK 32  // positions staged per refill
+#define XT_F2_WAVES 4   // waves per block (independent of each other; they only share the table copy)
+
+static inline bool xt_use_fast2(int S, int NS, int F, bool preds) { return S == 2 && NS == 1 && F >= 4 && F <= 7 && !preds; }
+
+template <int F>
+struct XtF2Geom {
+    static constexpr int E = 1 << F;           // sequences per track
+    static constexpr int NG = E / 2;           // groups (= lanes) per track
+    static constexpr int TPW = 64 / NG;        // tracks per wave
+    static constexpr int EW = E * TPW;         // sequences per wave (always 128)
+};
+
+// doubles of LDS per wave
+XT_HD int xt_f2_wave_doubles(int D, int K, int KS, int tpw)
+{
+    return 128 * (1 + D + K) + 64 /* ze */ + tpw * XT_F2_CHUNK * (D + KS);
+}
+
+// GF(2)-linear storage swizzle s = B.w of the wave-level sequence index w = ts * 2^F + idx (7 bits), found by
+// tools/swizzle_search.py: for every phase and both group members, each 32-lane group of a wave hits 32
+// distinct 8-byte bank pairs (ds_read_b64/b32 banking) and each 16-lane group 16 distinct 8-byte units mod 16
+// (ds_write_b64 banking) - zero LDS bank conflicts in the step loop.  Column j = image of bit j of w.
+template <int F>
+XT_HD int xt_f2_swz(int w)
+{
+    const int c4[7] = {0x5, 0x12, 0x14, 0x2c, 0x4f, 0x41, 0x15};   // F = 4 and 5
+    const int c6[7] = {0x15, 0x36, 0x67, 0x1c, 0x2, 0x1a, 0x16};   // F = 6
+    const int c7[7] = {0x65, 0x72, 0x6, 0x69, 0x1c, 0x4, 0x5f};    // F = 7
+    int s = 0;
+    for (int j = 0; j < 7; ++j) {
+        const int col = F == 6 ? c6[j] : (F == 7 ? c7[j] : c4[j]);
+        s ^= ((w >> j) & 1) ? col : 0;
+    }
+    return s;
+}
+
+// exp(x), x <= 0, as p * 2^n (degree-12 Taylor after Cody-Waite reduction, |rel err| < 6e-16)
+XT_HD void xt_exp_split12(double x, double& p, int& n)
+{
+    x = x > XT_XCLAMP ? x : XT_XCLAMP;
+    const double kf = xt_rint(x * 1.44269504088896338700e+00);
+    double r = xt_fma(kf, -6.93147180369123816490e-01, x);
+    r = xt_fma(kf, -1.90821492927058770002e-10, r);
+    double q = 2.08767569878680989792e-09;         // 1/12!
+    q = xt_fma(q, r, 2.50521083854417187751e-08);  // 1/11!
+    q = xt_fma(q, r, 2.75573192239858906526e-07);
+    q = xt_fma(q, r, 2.75573192239858906526e-06);
+    q = xt_fma(q, r, 2.48015873015873015873e-05);
+    q = xt_fma(q, r, 1.98412698412698412698e-04);
+    q = xt_fma(q, r, 1.38888888888888888889e-03);
+    q = xt_fma(q, r, 8.33333333333333333333e-03);
+    q = xt_fma(q, r, 4.16666666666666666667e-02);
+    q = xt_fma(q, r, 1.66666666666666666667e-01);
+    q = xt_fma(q, r, 0.5);
+    q = xt_fma(q, r, 1.0);
+    p = xt_fma(q, r, 1.0);
+    n = (int)kf;
+}
+
+// Two independent exp_split12 evaluations interleaved instruction by instruction: a wave alone can only issue
+// a DEPENDENT fp64 FMA every ~4 issue slots, so the two Horner chains are run in lockstep to double the ILP.
+XT_HD void xt_exp_split12_x2(double x0, double x1, double& p0, double& p1, int& n0, int& n1)
+{
+    x0 = x0 > XT_XCLAMP ? x0 : XT_XCLAMP;
+    x1 = x1 > XT_XCLAMP ? x1 : XT_XCLAMP;
+    const double k0 = xt_rint(x0 * 1.44269504088896338700e+00);
+    const double k1 = xt_rint(x1 * 1.44269504088896338700e+00);
+    double r0 = xt_fma(k0, -6.93147180369123816490e-01, x0);
+    double r1 = xt_fma(k1, -6.93147180369123816490e-01, x1);
+    r0 = xt_fma(k0, -1.90821492927058770002e-10, r0);
+    r1 = xt_fma(k1, -1.90821492927058770002e-10, r1);
+    double q0 = 2.08767569878680989792e-09, q1 = 2.08767569878680989792e-09;
+#define XT_H2(C)              \
+    q0 = xt_fma(q0, r0, (C)); \
+    q1 = xt_fma(q1, r1, (C));
+    XT_H2(2.50521083854417187751e-08)
+    XT_H2(2.75573192239858906526e-07)
+    XT_H2(2.75573192239858906526e-06)
+    XT_H2(2.48015873015873015873e-05)
+    XT_H2(1.98412698412698412698e-04)
+    XT_H2(1.38888888888888888889e-03)
+    XT_H2(8.33333333333333333333e-03)
+    XT_H2(4.16666666666666666667e-02)
+    XT_H2(1.66666666666666666667e-01)
+    XT_H2(0.5)
+    XT_H2(1.0)
+    XT_H2(1.0)
+#undef XT_H2
+    p0 = q0;
+    p1 = q1;
+    n0 = (int)k0;
+    n1 = (int)k1;
+}
+
+template <int F, int D, int K>
+struct XtF2State {
+    // LDS element indices of this lane's two sequences per phase, packed s0 | s1 << 16 (one VGPR per phase)
+    int s01[F];
+};
+
+// Keeps the compiler from hoisting the (loop-invariant) unpacked addresses of all F phases out of the
+// step loop, which costs ~50 VGPRs and halves the occupancy.
+XT_HD int xt_opaque(int v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(v));
+#endif
+    return v;
+}
+
+// One recursion step at compile-time phase H.  c: position, l2: localisation variance(s).
+template <int F, int D, int K, int H>
+XT_HD void xt_f2_step(double* zm, double* mm, double* uu, int* ze, const XtF2State<F, D, K>& st, const double* c, const double* l2,
+                      const double* TT, const double* TD2)
+{
+    const int pk = xt_opaque(st.s01[H]);
+    const int i0 = pk & 0xffff, i1 = pk >> 16;
+    const double z0 = zm[i0], z1 = zm[i1];
+    const int e0 = ze[i0], e1 = ze[i1];
+    const int emax = e0 > e1 ? e0 : e1;
+    const double a0 = xt_ldexp(z0, e0 - emax), a1 = xt_ldexp(z1, e1 - emax);
+    const double W = a0 + a1;
+    double M[D], U[K];
+    for (int d = 0; d < D; ++d) M[d] = xt_fma(a1, mm[d * 128 + i1], a0 * mm[d * 128 + i0]);
+    for (int k = 0; k < K; ++k) U[k] = xt_fma(a1, uu[k * 128 + i1], a0 * uu[k * 128 + i0]);
+    const bool live = W > 0.0;
+    const double Ws = live ? W : 1.0;
+    const double Wm = xt_frexp_mant(W);  // 0 when W == 0
+    const int We = live ? emax + xt_frexp_exp(W) : XT_EMIN;
+
+    // Dq[k] = W * den_q[k] = W*(l2 + d2_q) + U
+    double Dq[2][K];
+    for (int q = 0; q < 2; ++q)
+        for (int k = 0; k < K; ++k) Dq[q][k] = xt_fma(Ws, l2[k] + TD2[q], U[k]);
+    // one reciprocal for 1/W and all 1/Dq
+    double prod = Ws;
+    for (int q = 0; q < 2; ++q)
+        for (int k = 0; k < K; ++k) prod *= Dq[q][k];
+    const double R = xt_rcp(prod);
+    double rD[2][K], rW;
+    if (K == 1) {
+        const double RW = R * Ws;
+        rW = R * (Dq[0][0] * Dq[1][0]);
+        rD[0][0] = RW * Dq[1][0];
+        rD[1][0] = RW * Dq[0][0];
+    } else {
+        // prefix/suffix products over the 2K+1 factors {Ws, Dq[0][*], Dq[1][*]}
+        double f[2 * K + 1], pre[2 * K + 2], suf[2 * K + 2];
+        f[0] = Ws;
+        for (int q = 0; q < 2; ++q)
+            for (int k = 0; k < K; ++k) f[1 + q * K + k] = Dq[q][k];
+        pre[0] = 1.0;
+        for (int i = 0; i < 2 * K + 1; ++i) pre[i + 1] = pre[i] * f[i];
+        suf[2 * K + 1] = 1.0;
+        for (int i = 2 * K; i >= 0; --i) suf[i] = suf[i + 1] * f[i];
+        rW = R * suf[1];
+        for (int q = 0; q < 2; ++q)
+            for (int k = 0; k < K; ++k) rD[q][k] = R * pre[1 + q * K + k] * suf[2 + q * K + k];
+    }
+    double dmW[D], dsqW = 0.0;
+    for (int d = 0; d < D; ++d) {
+        dmW[d] = xt_fma(c[d], Ws, -M[d]);
+        if (K == 1) dsqW = xt_fma(dmW[d], dmW[d], dsqW);
+    }
+    double x[2], gf[2], tt[2][K];
+    for (int q = 0; q < 2; ++q) {
+        if (K == 1) {
+            x[q] = (-0.5 * rW) * dsqW * rD[q][0];
+            tt[q][0] = xt_fma(Ws, TD2[q], U[0]) * rD[q][0];
+            gf[q] = xt_pow_half<D>(Ws * rD[q][0]);
+        } else {
+            double xx = 0.0, gg = 1.0;
+            for (int d = 0; d < D; ++d) {
+                xx = xt_fma(dmW[d] * dmW[d], rD[q][d], xx);
+                tt[q][d] = xt_fma(Ws, TD2[q], U[d]) * rD[q][d];
+                gg *= Ws * rD[q][d];
+            }
+            x[q] = xx * (-0.5 * rW);
+            gf[q] = sqrt(gg);
+        }
+    }
+    double p[2];
+    int n[2];
+    xt_exp_split12_x2(x[0], x[1], p[0], p[1], n[0], n[1]);
+    for (int q = 0; q < 2; ++q) {
+        const int iq = q ? i1 : i0;
+        const int en = We + n[q];
+        zm[iq] = Wm * TT[q] * gf[q] * p[q];
+        ze[iq] = en > XT_EMIN ? en : XT_EMIN;
+        for (int d = 0; d < D; ++d) mm[d * 128 + iq] = xt_fma(dmW[d], tt[q][K == 1 ? 0 : d], M[d]) * rW;
+        for (int k = 0; k < K; ++k) uu[k * 128 + iq] = l2[k] * tt[q][k];
+    }
+}
+
+template <int F, int D, int K, class Ctx>
+XT_HD void xt_ll_s2_body(const XtKernelArgs& a, Ctx& cx)
+{
+    typedef XtF2Geom<F> Gm;
+    constexpr int E = Gm::E, NG = Gm::NG, TPW = Gm::TPW;
+    const int lane = cx.lane();
+    const int wib = cx.wave_in_block();
+    const int nwb = cx.waves_per_block();
+    const int L = a.L;
+    const int KS = a.locerr_mode ? a.KS : 0;
+    double* smem = cx.smem();
+
+    // block-shared model tables
+    const int ntab = xt_tab_doubles(2, 2);
+    for (int i = cx.tid(); i < ntab; i += cx.nthreads()) smem[i] = a.blob[i];
+    cx.sync();
+    const double* hdr = smem;
+    const double* TAB = smem + XT_BLOB_HDR;
+
+    const int ts = lane / NG;        // track slot inside the wave
+    const int g = lane - ts * NG;    // group of that track
+    const int prev = g >> (F - 2 >= 0 ? F - 2 : 0);  // top digit of g (F >= 2)
+    double T0[2], T1[2], TD2[2], TFIN[2];
+    const int tlast = L - 1;
+    const int stay_from = a.min_len > 2 ? a.min_len : 2;
+    const int vfin = (a.isBL ? 2 : 0) + (tlast >= stay_from ? 1 : 0);
+    for (int q = 0; q < 2; ++q) {
+        T0[q] = TAB[(0 * 2 + prev) * 2 + q];
+        T1[q] = TAB[(1 * 2 + prev) * 2 + q];
+        TD2[q] = TAB[(4 * 2 + prev) * 2 + q];
+        TFIN[q] = TAB[(vfin * 2 + prev) * 2 + q];
+    }
+    double l2g[K];
+    for (int k = 0; k < K; ++k) l2g[k] = hdr[k];
+    const double slope = hdr[3], offset = hdr[4];
+    const double F0 = hdr[8], F1 = hdr[9];
+
+    // per-wave LDS
+    const int wdoubles = xt_f2_wave_doubles(D, K, KS, TPW);
+    double* wbase = smem + ((ntab + 1) & ~1) + wib * wdoubles;
+    double* zm = wbase;
+    double* mm = zm + 128;
+    double* uu = mm + D * 128;
+    int* ze = (int*)(uu + K * 128);
+    double* pos = uu + K * 128 + 64;                 // [TPW][CHUNK][D]
+    double* sig = pos + TPW * XT_F2_CHUNK * D;       // [TPW][CHUNK][KS]
+
+    XtF2State<F, D, K> st;
+    for (int h = 0; h < F; ++h) {
+        const int base = ((g << (h + 1)) | (g >> (F - 1 - h))) & (E - 1);  // g's digit i -> slot (h+1+i) mod F
+        st.s01[h] = xt_f2_swz<F>(ts * E + base) | (xt_f2_swz<F>(ts * E + (base | (1 << h))) << 16);
+    }
+
+    // running product of the tracks' likelihoods for this lane's track slot (identical in its NG lanes)
+    double accm = 1.0, acce = 0.0, ntr = 0.0;
+
+    const int64_t nbatch = (a.N + TPW - 1) / TPW;
+    const int64_t W0 = (int64_t)cx.block() * nwb + wib, NW = (int64_t)cx.nblocks() * nwb;
+    for (int64_t batch = W0; batch < nbatch; batch += NW) {
+        const int64_t trk = batch * TPW + ts;
+        const bool act = trk < a.N;
+
+        auto stage = [&](int p0) {  // positions [p0, p0 + CHUNK) of the wave's TPW tracks -> LDS (coalesced along the track)
+            for (int i = lane; i < TPW * XT_F2_CHUNK * D; i += 64) {
+                const int t_ = i / (XT_F2_CHUNK * D), r = i - t_ * (XT_F2_CHUNK * D);
+                const int64_t tk = batch * TPW + t_;
+                const int64_t tkc = tk < a.N ? tk : a.N - 1;
+                const int pp = p0 + r / D;
+                if (pp < L) pos[i] = a.tracks[(tkc * L + p0) * D + r];
+            }
+            if (KS)
+                for (int i = lane; i < TPW * XT_F2_CHUNK * KS; i += 64) {
+                    const int t_ = i / (XT_F2_CHUNK * KS), r = i - t_ * (XT_F2_CHUNK * KS);
+                    const int64_t tk = batch * TPW + t_;
+                    const int64_t tkc = tk < a.N ? tk : a.N - 1;
+                    const int pp = p0 + r / KS;
+                    if (pp < L) sig[i] = a.sigma[(tkc * L + p0) * KS + r];
+                }
+            cx.wave_sync();
+        };
+        auto getpos = [&](int t, double* c, double* l2) {
+            const int r = t & (XT_F2_CHUNK - 1);
+            for (int d = 0; d < D; ++d) c[d] = pos[(ts * XT_F2_CHUNK + r) * D + d];
+            if (KS == 0) {
+                for (int k = 0; k < K; ++k) l2[k] = l2g[k];
+            } else {
+                for (int k = 0; k < K; ++k) {
+                    double s = sig[(ts * XT_F2_CHUNK + r) * KS + (KS == 1 ? 0 : k)];
+                    if (a.locerr_mode == 2) {
+                        s = xt_fma(s, slope, offset);
+                        s = s < 1e-6 ? 1e-6 : s;
+                    }
+                    l2[k] = s * s;
+                }
+            }
+        };
+
+        XtAcc tot;
+        tot.clear();
+        int t = 1;
+        double TC[2] = {stay_from <= 1 ? T1[0] : T0[0], stay_from <= 1 ? T1[1] : T0[1]};  // transition row in use (stay factor from step stay_from on)
+        for (int p0 = 0; p0 < L; p0 += XT_F2_CHUNK) {  // one staged chunk of positions at a time
+            stage(p0);
+            if (p0 == 0) {
+                // ---- position 0: the initial-state digit in slot 0, every other sequence has zero weight
+                double c0[D], l20[K];
+                getpos(0, c0, l20);
+                for (int q = 0; q < 2; ++q) {
+                    const int w = ts * E + g * 2 + q;  // any bijection lanes x {0,1} -> the track's E sequences
+                    const int idx = w - ts * E;
+                    const int s = xt_f2_swz<F>(w);
+                    zm[s] = idx == 0 ? F0 : (idx == 1 ? F1 : 0.0);
+                    ze[s] = idx < 2 ? 0 : XT_EMIN;
+                    for (int d = 0; d < D; ++d) mm[d * 128 + s] = c0[d];
+                    for (int k = 0; k < K; ++k) uu[k * 128 + s] = l20[k];
+                }
+                cx.wave_sync();
+            }
+            // ---- positions 1 .. L-2 that lie in this chunk; phase h = t mod F, unrolled over the F phases
+            const int tend = (L - 2 < p0 + XT_F2_CHUNK - 1) ? L - 2 : p0 + XT_F2_CHUNK - 1;
+            while (t <= tend) {
+#define XT_F2_PHASE(H)                                                                         \
+    if (F > (H) && t <= tend && (t % F) == (H)) {                                              \
+        double c[D], l2[K];                                                                    \
+        getpos(t, c, l2);                                                                      \
+        if (t == stay_from) {                                                                  \
+            TC[0] = T1[0];                                                                     \
+            TC[1] = T1[1];                                                                     \
+        }                                                                                      \
+        xt_f2_step<F, D, K, ((H) < F ? (H) : 0)>(zm, mm, uu, ze, st, c, l2, TC, TD2);          \
+        cx.wave_sync();                                                                        \
+        ++t;                                                                                   \
+    }
+                XT_F2_PHASE(1)
+                XT_F2_PHASE(2)
+                XT_F2_PHASE(3)
+                XT_F2_PHASE(4)
+                XT_F2_PHASE(5)
+                XT_F2_PHASE(6)
+                XT_F2_PHASE(0)
+#undef XT_F2_PHASE
+            }
+            if (tlast < p0 || tlast >= p0 + XT_F2_CHUNK) continue;
+            // ---- last position (+ leaving/bleaching factor folded into TFIN): reduction over (Q, q)
+            double cl[D], l2l[K];
+            getpos(tlast, cl, l2l);
+            const int h = tlast % F;
+            // phase index is runtime here: pick the packed indices with a small select chain (once per track)
+            int pk = st.s01[0];
+            for (int hh = 1; hh < F; ++hh) pk = h == hh ? st.s01[hh] : pk;
+            const int i0 = pk & 0xffff, i1 = pk >> 16;
+            for (int Q = 0; Q < 2; ++Q) {
+                const int iq = Q ? i1 : i0;
+                const double zq = zm[iq];
+                const int eq = ze[iq];
+                double dq[D], dsq = 0.0;
+                for (int d = 0; d < D; ++d) {
+                    dq[d] = cl[d] - mm[d * 128 + iq];
+                    dsq = xt_fma(dq[d], dq[d], dsq);
+                }
+                for (int q = 0; q < 2; ++q) {
+                    double x, gf;
+                    if (K == 1) {
+                        const double r = xt_rcp(TD2[q] + uu[iq] + l2l[0]);
+                        x = -0.5 * dsq * r;
+                        gf = xt_pow_half<D>(r);
+                    } else {
+                        x = 0.0;
+                        gf = 1.0;
+                        for (int d = 0; d < D; ++d) {
+                            const double r = xt_rcp(TD2[q] + uu[d * 128 + iq] + l2l[d]);
+                            x = xt_fma(-0.5 * dq[d] * dq[d], r, x);
+                            gf *= r;
+                        }
+                        gf = sqrt(gf);
+                    }
+                    double p;
+                    int n;
+                    xt_exp_split12(x, p, n);
+                    tot.add(zq * TFIN[q] * gf * p, eq + n);
+                }
+            }
+        }
+        // reduce over the track's NG lanes (all lanes end with the same values)
+        int fe = tot.m != 0.0 ? tot.e : XT_EMIN;
+        for (int m = 1; m < NG; m <<= 1) {
+            const int o = cx.shfl_xor_i32(fe, m);
+            fe = o > fe ? o : fe;
+        }
+        double sum = tot.m != 0.0 ? xt_ldexp(tot.m, tot.e - fe) : 0.0;
+        for (int m = 1; m < NG; m <<= 1) sum += cx.shfl_xor_f64(sum, m);
+        if (act) {
+            if (a.ll_out && g == 0) a.ll_out[trk] = log(sum) + (double)fe * XT_LN2 + a.ll_const;
+            const double pm = accm * xt_frexp_mant(sum);
+            acce += (double)(fe + xt_frexp_exp(sum) + xt_frexp_exp(pm));
+            accm = xt_frexp_mant(pm);
+            ntr += 1.0;
+            if (sum == 0.0) acce = -INFINITY;  // zero likelihood: log = -inf, as the reference would produce
+        }
+        cx.wave_sync();
+    }
+
+    // ---- per-slot log-likelihood sums -> block partial (fixed order)
+    cx.sync();
+    if (g == 0) smem[wib * TPW + ts] = ntr > 0.0 ? log(accm) + acce * XT_LN2 + ntr * a.ll_const : 0.0;
+    cx.sync();
+    if (cx.tid() == 0) {
+        double s = 0.0;
+        for (int i = 0; i < nwb * TPW; ++i) s += smem[i];
+        a.partials[cx.block()] = s;
+    }
+}

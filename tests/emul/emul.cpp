@@ -3,18 +3,35 @@
 // the extended-range arithmetic can be checked against the oracle without a GPU.  Never shipped,
 // never reachable from the product package.
 #include <pthread.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <thread>
 #include <vector>
 
 #include "../../extrack_amd/csrc/xt_dispatch.h"
+#include "../../extrack_amd/csrc/xt_fast2.h"
 #include "../../extrack_amd/csrc/xt_tables.h"
 
 struct HostCtx {
     int tid_, nthreads_, block_, nblocks_;
     double* smem_;
     pthread_barrier_t* bar_;
+    pthread_barrier_t* wbar_ = nullptr;  // this wave's barrier
+    double* wscr_ = nullptr;             // this wave's 64-entry shuffle scratch
+    int lane() const { return tid_ & 63; }
+    int wave_in_block() const { return tid_ >> 6; }
+    int waves_per_block() const { return nthreads_ >> 6; }
+    void wave_sync() { pthread_barrier_wait(wbar_); }
+    double shfl_xor_f64(double v, int m)
+    {
+        wscr_[lane()] = v;
+        pthread_barrier_wait(wbar_);
+        double o = wscr_[lane() ^ m];
+        pthread_barrier_wait(wbar_);
+        return o;
+    }
+    int shfl_xor_i32(int v, int m) { return (int)shfl_xor_f64((double)v, m); }
     int tid() const { return tid_; }
     int nthreads() const { return nthreads_; }
     int block() const { return block_; }
@@ -46,6 +63,32 @@ struct EmulLauncher {
     XtKernelArgs a;
     int threads, nblocks;
     size_t lds_bytes;
+    template <int F, int D, int K>
+    bool run_f2()
+    {
+        const int nw = threads / 64;
+        for (int b = 0; b < nblocks; ++b) {
+            std::vector<double> smem(lds_bytes / 8 + 16, 0.0);
+            pthread_barrier_t bar;
+            pthread_barrier_init(&bar, nullptr, threads);
+            std::vector<pthread_barrier_t> wb(nw);
+            std::vector<std::vector<double>> ws(nw, std::vector<double>(64, 0.0));
+            for (auto& x : wb) pthread_barrier_init(&x, nullptr, 64);
+            std::vector<std::thread> th;
+            for (int t = 0; t < threads; ++t)
+                th.emplace_back([&, t]() {
+                    HostCtx cx{t, threads, b, nblocks, smem.data(), &bar};
+                    cx.wbar_ = &wb[t >> 6];
+                    cx.wscr_ = ws[t >> 6].data();
+                    xt_ll_s2_body<F, D, K>(a, cx);
+                });
+            for (auto& x : th) x.join();
+            pthread_barrier_destroy(&bar);
+            for (auto& x : wb) pthread_barrier_destroy(&x);
+        }
+        return true;
+    }
+
     template <int G_, int D, int K, bool PREDS>
     bool run()
     {
@@ -112,7 +155,17 @@ extern "C" int xt_emul_run(const double* tracks, const double* sigma, long long 
         info[2] = (int)l.lds_bytes;
         info[3] = cfg.E;
     }
-    if (!xt_dispatch(cfg.G, D, K, preds != 0, l)) return -3;
+    if (xt_use_fast2(S, NS, F, preds != 0) && !getenv("XT_EMUL_GENERIC")) {
+        l.threads = 64 * XT_F2_WAVES;
+        l.a.TPB = 0;
+        l.lds_bytes = (size_t)(((xt_tab_doubles(2, 2) + 1) & ~1) + XT_F2_WAVES * xt_f2_wave_doubles(D, K, locerr_mode ? KS : 0, 64 >> (F - 1))) * 8;
+        if (info) {
+            info[0] = 64 >> (F - 1);
+            info[1] = l.threads;
+            info[2] = (int)l.lds_bytes;
+        }
+        if (!xt_dispatch_f2(F, D, K, l)) return -3;
+    } else if (!xt_dispatch(cfg.G, D, K, preds != 0, l)) return -3;
     double s = 0.0;
     for (double p : partials) s += p;
     if (total) *total = s;
