@@ -34,11 +34,31 @@ def cpu_baseline_worker(args):
     return time.perf_counter() - t0
 
 
-def cpu_baseline(sample_tracks_per_core=4000):
-    """numpy port (oracle/oracle_np.py, parity-pinned to the reference) on a bounded sample, all host cores."""
+def _one_socket_cores():
+    """Physical cores of one socket (the north-star baseline is "single-socket numpy"), capped by the affinity mask."""
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        phys = set()
+        cur = {}
+        for line in open("/proc/cpuinfo"):
+            if ":" in line:
+                k, v = [x.strip() for x in line.split(":", 1)]
+                cur[k] = v
+            elif cur:
+                phys.add((cur.get("physical id", "0"), cur.get("core id", cur.get("processor"))))
+                cur = {}
+        sockets = len(set(p for p, _ in phys)) or 1
+        per_socket = max(1, len(phys) // sockets)
+        return max(1, min(per_socket, avail))
+    except Exception:
+        return avail
+
+
+def cpu_baseline(sample_tracks_per_core=8000):
+    """numpy port (oracle/oracle_np.py, parity-pinned to the reference) on a bounded sample, one socket's cores."""
     import multiprocessing as mp
     from extrack_amd import synth
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = _one_socket_cores()
     n = sample_tracks_per_core * cores
     Cs = synth.brownian_tracks(n, LEN, DS_COEF, TRMAT, FS, LOCERR, DT, DIMS, seed=123)
     ds = np.sqrt(2 * np.array(DS_COEF) * DT)
@@ -78,7 +98,7 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % a.gpus)
     torch.cuda.set_device(local)
     comm = None
-    if world > 1:
+    if world > 1 or os.environ.get("EXTRACK_BENCH_FORCE_COMM") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
@@ -123,13 +143,17 @@ def main():
     k_ms = float(np.mean(kernel_ms))
     alg_bytes = a.tracks * LEN * DIMS * 8          # one read of the track, LL reduced in-kernel
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
-    traffic = None
+    traffic = None   # HBM bytes per launch from the committed rocprofv3 PMC passes (tools/gpu_pmc.sh -> profiles/hbm_traffic.json)
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    if os.path.exists(tpath):
+    if os.path.exists(tpath) and a.tracks == N_TRACKS:
         try:
             traffic = json.load(open(tpath)).get("bytes_per_launch")
         except Exception:
             traffic = None
+    # secondary (honest) bound: fp64 vector issue.  Flop count per track-step from the kernel's ISA:
+    # 48 FMA + 49 other fp64 ops per wave-step of 2 tracks -> 145 flop x 64 lanes / 2 tracks.
+    flop_per_eval = a.tracks * (LEN - 1) * 4640.0
+    tflops = flop_per_eval / (k_ms * 1e-3) / 1e12
     out = {
         "metric": "log-likelihood evals/sec (1e6 tracks, 2-state, len=30)", "value": evals_per_s, "unit": "1e6-track LL evals/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
@@ -139,7 +163,9 @@ def main():
                    "tracks_per_gpu": a.tracks, "parallelism": "dp%d" % world, "launch": ts.ctx.last_launch_info()},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes,
-                     "note": "the recursion is FP64-VALU bound, not HBM bound (arithmetic intensity ~1e2 flop/B, DESIGN.md)"},
+                     "note": "the recursion is FP64-VALU bound, not HBM bound (arithmetic intensity ~300 flop/B, DESIGN.md)",
+                     "fp64_valu": {"achieved": tflops, "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s", "frac": tflops / FP64_VALU_PEAK_TF,
+                                   "flop_per_launch": flop_per_eval}},
         "neg_loglik": -val,
     }
     if not a.no_cpu_baseline and world == 1:

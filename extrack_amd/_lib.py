@@ -40,6 +40,26 @@ class ExtrackError(RuntimeError):
 _lib = None
 
 
+def _preload_torch_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own ``libamdhip64.so`` (soname
+    ``libamdhip64.so.7``) and link it by the unversioned name; if this extension pulled in the system copy first, a later
+    ``import torch`` would load a SECOND runtime that then finds no GPU.  Preloading torch's copy (when torch is installed,
+    without importing it) makes the extension's ``NEEDED libamdhip64.so.7`` resolve to that same object."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load():
     """Loads the shared library; raises if it has not been built (``python __graft_entry__.py``)."""
     global _lib
@@ -48,6 +68,7 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise ImportError("%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    _preload_torch_hip_runtime()
     lib = C.CDLL(LIB_PATH)
     vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
     lib.extrack_abi_version.restype = C.c_int
