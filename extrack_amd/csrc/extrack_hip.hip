@@ -447,7 +447,7 @@ static int xt_launch_bucket(extrack_ctx* ctx, const extrack_model* m, XtBucket& 
         const int tpw = 64 >> (c.F - 1);
         tpb = tpw * XT_F2_WAVES;
         threads = 64 * XT_F2_WAVES;
-        l.lds = (size_t)(((xt_tab_doubles(2, 2) + 1) & ~1) + XT_F2_WAVES * xt_f2_wave_doubles(D, K, m->locerr_mode ? b.KS : 0, tpw)) * sizeof(double);
+        l.lds = (size_t)xt_f2_block_bytes(D, K, m->locerr_mode ? b.KS : 0, tpw);
     } else {
         xt_geometry(c, D, K, tpb, threads);
         if (threads > 1024) return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "n_states^(frame_len-nb_substeps) > 1024 groups per track is not built");

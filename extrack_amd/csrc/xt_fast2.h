@@ -32,12 +32,6 @@ struct XtF2Geom {
     static constexpr int EW = E * TPW;         // sequences per wave (always 128)
 };
 
-// doubles of LDS per wave
-XT_HD int xt_f2_wave_doubles(int D, int K, int KS, int tpw)
-{
-    return 128 * (1 + D + K) + 64 /* ze */ + tpw * XT_F2_CHUNK * (D + KS);
-}
-
 // GF(2)-linear storage swizzle s = B.w of the wave-level sequence index w = ts * 2^F + idx (7 bits), found by
 // tools/swizzle_search.py: for every phase and both group members, each 32-lane group of a wave hits 32
 // distinct 8-byte bank pairs (ds_read_b64/b32 banking) and each 16-lane group 16 distinct 8-byte units mod 16
@@ -56,52 +50,25 @@ XT_HD int xt_f2_swz(int w)
     return s;
 }
 
-// exp(x), x <= 0, as p * 2^n (degree-12 Taylor after Cody-Waite reduction, |rel err| < 6e-16)
-XT_HD void xt_exp_split12(double x, double& p, int& n)
+// exp(x), x <= 0, table-driven: x = (64 e + j) ln2/64 + r, |r| <= ln2/128, exp(x) = 2^e * T64[j] * P5(r).
+// Two independent evaluations are interleaved instruction by instruction (a wave alone can only issue a DEPENDENT
+// fp64 FMA every few issue slots).  Returns p (without the table factor), the table index j and the exponent e.
+// |rel err| < 3e-16 (truncation r^6/720 < 4e-17).  Clamp: x >= -3e7 keeps 64x/ln2 inside int32.
+#define XT_F2_XCLAMP (-3.0e7)
+XT_HD void xt_exp_tab_x2(double x0, double x1, double& p0, double& p1, int& j0, int& j1, int& e0, int& e1)
 {
-    x = x > XT_XCLAMP ? x : XT_XCLAMP;
-    const double kf = xt_rint(x * 1.44269504088896338700e+00);
-    double r = xt_fma(kf, -6.93147180369123816490e-01, x);
-    r = xt_fma(kf, -1.90821492927058770002e-10, r);
-    double q = 2.08767569878680989792e-09;         // 1/12!
-    q = xt_fma(q, r, 2.50521083854417187751e-08);  // 1/11!
-    q = xt_fma(q, r, 2.75573192239858906526e-07);
-    q = xt_fma(q, r, 2.75573192239858906526e-06);
-    q = xt_fma(q, r, 2.48015873015873015873e-05);
-    q = xt_fma(q, r, 1.98412698412698412698e-04);
-    q = xt_fma(q, r, 1.38888888888888888889e-03);
-    q = xt_fma(q, r, 8.33333333333333333333e-03);
-    q = xt_fma(q, r, 4.16666666666666666667e-02);
-    q = xt_fma(q, r, 1.66666666666666666667e-01);
-    q = xt_fma(q, r, 0.5);
-    q = xt_fma(q, r, 1.0);
-    p = xt_fma(q, r, 1.0);
-    n = (int)kf;
-}
-
-// Two independent exp_split12 evaluations interleaved instruction by instruction: a wave alone can only issue
-// a DEPENDENT fp64 FMA every ~4 issue slots, so the two Horner chains are run in lockstep to double the ILP.
-XT_HD void xt_exp_split12_x2(double x0, double x1, double& p0, double& p1, int& n0, int& n1)
-{
-    x0 = x0 > XT_XCLAMP ? x0 : XT_XCLAMP;
-    x1 = x1 > XT_XCLAMP ? x1 : XT_XCLAMP;
-    const double k0 = xt_rint(x0 * 1.44269504088896338700e+00);
-    const double k1 = xt_rint(x1 * 1.44269504088896338700e+00);
-    double r0 = xt_fma(k0, -6.93147180369123816490e-01, x0);
-    double r1 = xt_fma(k1, -6.93147180369123816490e-01, x1);
-    r0 = xt_fma(k0, -1.90821492927058770002e-10, r0);
-    r1 = xt_fma(k1, -1.90821492927058770002e-10, r1);
-    double q0 = 2.08767569878680989792e-09, q1 = 2.08767569878680989792e-09;
+    x0 = x0 > XT_F2_XCLAMP ? x0 : XT_F2_XCLAMP;
+    x1 = x1 > XT_F2_XCLAMP ? x1 : XT_F2_XCLAMP;
+    const double k0 = xt_rint(x0 * 92.33248261689366);
+    const double k1 = xt_rint(x1 * 92.33248261689366);
+    double r0 = xt_fma(k0, -0.010830424493178725, x0);
+    double r1 = xt_fma(k1, -0.010830424493178725, x1);
+    r0 = xt_fma(k0, -2.030704202170295e-10, r0);
+    r1 = xt_fma(k1, -2.030704202170295e-10, r1);
+    double q0 = 8.33333333333333333333e-03, q1 = 8.33333333333333333333e-03;  // 1/120
 #define XT_H2(C)              \
     q0 = xt_fma(q0, r0, (C)); \
     q1 = xt_fma(q1, r1, (C));
-    XT_H2(2.50521083854417187751e-08)
-    XT_H2(2.75573192239858906526e-07)
-    XT_H2(2.75573192239858906526e-06)
-    XT_H2(2.48015873015873015873e-05)
-    XT_H2(1.98412698412698412698e-04)
-    XT_H2(1.38888888888888888889e-03)
-    XT_H2(8.33333333333333333333e-03)
     XT_H2(4.16666666666666666667e-02)
     XT_H2(1.66666666666666666667e-01)
     XT_H2(0.5)
@@ -110,15 +77,28 @@ XT_HD void xt_exp_split12_x2(double x0, double x1, double& p0, double& p1, int& 
 #undef XT_H2
     p0 = q0;
     p1 = q1;
-    n0 = (int)k0;
-    n1 = (int)k1;
+    const int n0 = (int)k0, n1 = (int)k1;
+    j0 = n0 & 63;
+    j1 = n1 & 63;
+    e0 = n0 >> 6;
+    e1 = n1 >> 6;
 }
 
 template <int F, int D, int K>
 struct XtF2State {
-    // LDS element indices of this lane's two sequences per phase, packed s0 | s1 << 16 (one VGPR per phase)
+    // absolute LDS byte addresses (of the zm element) of this lane's two sequences per phase, packed a0 | a1 << 16
     int s01[F];
 };
+
+// Fixed LDS map of the fast path (bytes).  One array per field over all waves of the block, so that a field is reached
+// from the zm address by a compile-time offset and ze (4-byte elements) by (a >> 1) + constant.
+#define XT_F2_TAB_BYTES 1024                                   /* model tables (288 B) + T64 exp table (512 B) */
+#define XT_F2_T64_OFF 320
+#define XT_F2_ARR (XT_F2_WAVES * 128 * 8)                      /* bytes of one double field for all waves */
+#define XT_F2_ZM0 XT_F2_TAB_BYTES
+XT_HD int xt_f2_ze0(int D, int K) { return XT_F2_ZM0 + (1 + D + K) * XT_F2_ARR; }
+XT_HD int xt_f2_pos0(int D, int K) { return xt_f2_ze0(D, K) + XT_F2_WAVES * 128 * 4; }
+XT_HD int xt_f2_block_bytes(int D, int K, int KS, int tpw) { return xt_f2_pos0(D, K) + XT_F2_WAVES * tpw * XT_F2_CHUNK * (D + KS) * 8; }
 
 // Keeps the compiler from hoisting the (loop-invariant) unpacked addresses of all F phases out of the
 // step loop, which costs ~50 VGPRs and halves the occupancy.
@@ -130,21 +110,29 @@ XT_HD int xt_opaque(int v)
     return v;
 }
 
-// One recursion step at compile-time phase H.  c: position, l2: localisation variance(s).
-template <int F, int D, int K, int H>
-XT_HD void xt_f2_step(double* zm, double* mm, double* uu, int* ze, const XtF2State<F, D, K>& st, const double* c, const double* l2,
-                      const double* TT, const double* TD2)
+template <class T>
+XT_HD T& xt_at(char* lds, int byte_off)
 {
+    return *(T*)(lds + byte_off);
+}
+
+// One recursion step at compile-time phase H.  c: position, l2: localisation variance(s), TT: transition row in use.
+template <int F, int D, int K, int H>
+XT_HD void xt_f2_step(char* lds, const XtF2State<F, D, K>& st, const double* c, const double* l2, const double* TT, const double* TD2)
+{
+    constexpr int ZEO = XT_F2_ZM0 + (1 + D + K) * XT_F2_ARR - XT_F2_ZM0 / 2;  // ze address = (a >> 1) + ZEO
     const int pk = xt_opaque(st.s01[H]);
-    const int i0 = pk & 0xffff, i1 = pk >> 16;
-    const double z0 = zm[i0], z1 = zm[i1];
-    const int e0 = ze[i0], e1 = ze[i1];
+    const int a0 = pk & 0xffff, a1 = (int)((unsigned)pk >> 16);
+    const double z0 = xt_at<double>(lds, a0), z1 = xt_at<double>(lds, a1);
+    const int e0 = xt_at<int>(lds, (a0 >> 1) + ZEO), e1 = xt_at<int>(lds, (a1 >> 1) + ZEO);
     const int emax = e0 > e1 ? e0 : e1;
-    const double a0 = xt_ldexp(z0, e0 - emax), a1 = xt_ldexp(z1, e1 - emax);
-    const double W = a0 + a1;
+    const double w0 = xt_ldexp(z0, e0 - emax), w1 = xt_ldexp(z1, e1 - emax);
+    const double W = w0 + w1;
     double M[D], U[K];
-    for (int d = 0; d < D; ++d) M[d] = xt_fma(a1, mm[d * 128 + i1], a0 * mm[d * 128 + i0]);
-    for (int k = 0; k < K; ++k) U[k] = xt_fma(a1, uu[k * 128 + i1], a0 * uu[k * 128 + i0]);
+    for (int d = 0; d < D; ++d)
+        M[d] = xt_fma(w1, xt_at<double>(lds, a1 + (1 + d) * XT_F2_ARR), w0 * xt_at<double>(lds, a0 + (1 + d) * XT_F2_ARR));
+    for (int k = 0; k < K; ++k)
+        U[k] = xt_fma(w1, xt_at<double>(lds, a1 + (1 + D + k) * XT_F2_ARR), w0 * xt_at<double>(lds, a0 + (1 + D + k) * XT_F2_ARR));
     const bool live = W > 0.0;
     const double Ws = live ? W : 1.0;
     const double Wm = xt_frexp_mant(W);  // 0 when W == 0
@@ -155,14 +143,12 @@ XT_HD void xt_f2_step(double* zm, double* mm, double* uu, int* ze, const XtF2Sta
     for (int q = 0; q < 2; ++q)
         for (int k = 0; k < K; ++k) Dq[q][k] = xt_fma(Ws, l2[k] + TD2[q], U[k]);
     // one reciprocal for 1/W and all 1/Dq
-    double prod = Ws;
-    for (int q = 0; q < 2; ++q)
-        for (int k = 0; k < K; ++k) prod *= Dq[q][k];
-    const double R = xt_rcp(prod);
     double rD[2][K], rW;
     if (K == 1) {
+        const double d01 = Dq[0][0] * Dq[1][0];
+        const double R = xt_rcp(Ws * d01);
         const double RW = R * Ws;
-        rW = R * (Dq[0][0] * Dq[1][0]);
+        rW = R * d01;
         rD[0][0] = RW * Dq[1][0];
         rD[1][0] = RW * Dq[0][0];
     } else {
@@ -175,6 +161,7 @@ XT_HD void xt_f2_step(double* zm, double* mm, double* uu, int* ze, const XtF2Sta
         for (int i = 0; i < 2 * K + 1; ++i) pre[i + 1] = pre[i] * f[i];
         suf[2 * K + 1] = 1.0;
         for (int i = 2 * K; i >= 0; --i) suf[i] = suf[i + 1] * f[i];
+        const double R = xt_rcp(pre[2 * K + 1]);
         rW = R * suf[1];
         for (int q = 0; q < 2; ++q)
             for (int k = 0; k < K; ++k) rD[q][k] = R * pre[1 + q * K + k] * suf[2 + q * K + k];
@@ -185,9 +172,10 @@ XT_HD void xt_f2_step(double* zm, double* mm, double* uu, int* ze, const XtF2Sta
         if (K == 1) dsqW = xt_fma(dmW[d], dmW[d], dsqW);
     }
     double x[2], gf[2], tt[2][K];
+    const double A = -0.5 * rW * dsqW;
     for (int q = 0; q < 2; ++q) {
         if (K == 1) {
-            x[q] = (-0.5 * rW) * dsqW * rD[q][0];
+            x[q] = A * rD[q][0];
             tt[q][0] = xt_fma(Ws, TD2[q], U[0]) * rD[q][0];
             gf[q] = xt_pow_half<D>(Ws * rD[q][0]);
         } else {
@@ -202,15 +190,16 @@ XT_HD void xt_f2_step(double* zm, double* mm, double* uu, int* ze, const XtF2Sta
         }
     }
     double p[2];
-    int n[2];
-    xt_exp_split12_x2(x[0], x[1], p[0], p[1], n[0], n[1]);
+    int j[2], n[2];
+    xt_exp_tab_x2(x[0], x[1], p[0], p[1], j[0], j[1], n[0], n[1]);
     for (int q = 0; q < 2; ++q) {
-        const int iq = q ? i1 : i0;
+        const int aq = q ? a1 : a0;
         const int en = We + n[q];
-        zm[iq] = Wm * TT[q] * gf[q] * p[q];
-        ze[iq] = en > XT_EMIN ? en : XT_EMIN;
-        for (int d = 0; d < D; ++d) mm[d * 128 + iq] = xt_fma(dmW[d], tt[q][K == 1 ? 0 : d], M[d]) * rW;
-        for (int k = 0; k < K; ++k) uu[k * 128 + iq] = l2[k] * tt[q][k];
+        const double tj = xt_at<double>(lds, XT_F2_T64_OFF + j[q] * 8);
+        xt_at<double>(lds, aq) = (Wm * TT[q]) * (gf[q] * tj) * p[q];
+        xt_at<int>(lds, (aq >> 1) + ZEO) = en > XT_EMIN ? en : XT_EMIN;
+        for (int d = 0; d < D; ++d) xt_at<double>(lds, aq + (1 + d) * XT_F2_ARR) = xt_fma(dmW[d], tt[q][K == 1 ? 0 : d], M[d]) * rW;
+        for (int k = 0; k < K; ++k) xt_at<double>(lds, aq + (1 + D + k) * XT_F2_ARR) = l2[k] * tt[q][k];
     }
 }
 
@@ -225,10 +214,12 @@ XT_HD void xt_ll_s2_body(const XtKernelArgs& a, Ctx& cx)
     const int L = a.L;
     const int KS = a.locerr_mode ? a.KS : 0;
     double* smem = cx.smem();
+    char* lds = (char*)smem;
 
-    // block-shared model tables
+    // block-shared model tables + the 2^(j/64) table of the exponential
     const int ntab = xt_tab_doubles(2, 2);
     for (int i = cx.tid(); i < ntab; i += cx.nthreads()) smem[i] = a.blob[i];
+    if (cx.tid() < 64) xt_at<double>(lds, XT_F2_T64_OFF + cx.tid() * 8) = exp2((double)cx.tid() * (1.0 / 64.0));
     cx.sync();
     const double* hdr = smem;
     const double* TAB = smem + XT_BLOB_HDR;
@@ -251,20 +242,17 @@ XT_HD void xt_ll_s2_body(const XtKernelArgs& a, Ctx& cx)
     const double slope = hdr[3], offset = hdr[4];
     const double F0 = hdr[8], F1 = hdr[9];
 
-    // per-wave LDS
-    const int wdoubles = xt_f2_wave_doubles(D, K, KS, TPW);
-    double* wbase = smem + ((ntab + 1) & ~1) + wib * wdoubles;
-    double* zm = wbase;
-    double* mm = zm + 128;
-    double* uu = mm + D * 128;
-    int* ze = (int*)(uu + K * 128);
-    double* pos = uu + K * 128 + 64;                 // [TPW][CHUNK][D]
-    double* sig = pos + TPW * XT_F2_CHUNK * D;       // [TPW][CHUNK][KS]
+    // LDS map (bytes): [tables 1 KiB][zm][m x D][u x K] (each XT_F2_WAVES x 128 doubles) [ze: XT_F2_WAVES x 128 ints][pos][sig]
+    constexpr int ZEO = XT_F2_ZM0 + (1 + D + K) * XT_F2_ARR - XT_F2_ZM0 / 2;
+    const int wave0 = XT_F2_ZM0 + wib * 128 * 8;  // byte address of this wave's zm[0]
+    double* pos = (double*)(lds + xt_f2_pos0(D, K)) + wib * TPW * XT_F2_CHUNK * (D + KS);  // [TPW][CHUNK][D]
+    double* sig = pos + TPW * XT_F2_CHUNK * D;                                             // [TPW][CHUNK][KS]
 
     XtF2State<F, D, K> st;
     for (int h = 0; h < F; ++h) {
         const int base = ((g << (h + 1)) | (g >> (F - 1 - h))) & (E - 1);  // g's digit i -> slot (h+1+i) mod F
-        st.s01[h] = xt_f2_swz<F>(ts * E + base) | (xt_f2_swz<F>(ts * E + (base | (1 << h))) << 16);
+        const int b0 = wave0 + xt_f2_swz<F>(ts * E + base) * 8, b1 = wave0 + xt_f2_swz<F>(ts * E + (base | (1 << h))) * 8;
+        st.s01[h] = b0 | (b1 << 16);
     }
 
     // running product of the tracks' likelihoods for this lane's track slot (identical in its NG lanes)
@@ -310,42 +298,17 @@ XT_HD void xt_ll_s2_body(const XtKernelArgs& a, Ctx& cx)
                 }
             }
         };
-
-        XtAcc tot;
-        tot.clear();
-        int t = 1;
-        double TC[2] = {stay_from <= 1 ? T1[0] : T0[0], stay_from <= 1 ? T1[1] : T0[1]};  // transition row in use (stay factor from step stay_from on)
-        for (int p0 = 0; p0 < L; p0 += XT_F2_CHUNK) {  // one staged chunk of positions at a time
-            stage(p0);
-            if (p0 == 0) {
-                // ---- position 0: the initial-state digit in slot 0, every other sequence has zero weight
-                double c0[D], l20[K];
-                getpos(0, c0, l20);
-                for (int q = 0; q < 2; ++q) {
-                    const int w = ts * E + g * 2 + q;  // any bijection lanes x {0,1} -> the track's E sequences
-                    const int idx = w - ts * E;
-                    const int s = xt_f2_swz<F>(w);
-                    zm[s] = idx == 0 ? F0 : (idx == 1 ? F1 : 0.0);
-                    ze[s] = idx < 2 ? 0 : XT_EMIN;
-                    for (int d = 0; d < D; ++d) mm[d * 128 + s] = c0[d];
-                    for (int k = 0; k < K; ++k) uu[k * 128 + s] = l20[k];
-                }
-                cx.wave_sync();
-            }
-            // ---- positions 1 .. L-2 that lie in this chunk; phase h = t mod F, unrolled over the F phases
-            const int tend = (L - 2 < p0 + XT_F2_CHUNK - 1) ? L - 2 : p0 + XT_F2_CHUNK - 1;
+        // steps t .. tend with transition row TT (the F phases of the circular digit buffer unrolled: every LDS
+        // address is a register, phase h = t mod F)
+        auto run_steps = [&](int& t, int tend, const double* TT) {
             while (t <= tend) {
-#define XT_F2_PHASE(H)                                                                         \
-    if (F > (H) && t <= tend && (t % F) == (H)) {                                              \
-        double c[D], l2[K];                                                                    \
-        getpos(t, c, l2);                                                                      \
-        if (t == stay_from) {                                                                  \
-            TC[0] = T1[0];                                                                     \
-            TC[1] = T1[1];                                                                     \
-        }                                                                                      \
-        xt_f2_step<F, D, K, ((H) < F ? (H) : 0)>(zm, mm, uu, ze, st, c, l2, TC, TD2);          \
-        cx.wave_sync();                                                                        \
-        ++t;                                                                                   \
+#define XT_F2_PHASE(H)                                                                 \
+    if (F > (H) && t <= tend && (t % F) == (H)) {                                      \
+        double c[D], l2[K];                                                            \
+        getpos(t, c, l2);                                                              \
+        xt_f2_step<F, D, K, ((H) < F ? (H) : 0)>(lds, st, c, l2, TT, TD2);             \
+        cx.wave_sync();                                                                \
+        ++t;                                                                           \
     }
                 XT_F2_PHASE(1)
                 XT_F2_PHASE(2)
@@ -356,45 +319,72 @@ XT_HD void xt_ll_s2_body(const XtKernelArgs& a, Ctx& cx)
                 XT_F2_PHASE(0)
 #undef XT_F2_PHASE
             }
+        };
+
+        XtAcc tot;
+        tot.clear();
+        int t = 1;
+        for (int p0 = 0; p0 < L; p0 += XT_F2_CHUNK) {  // one staged chunk of positions at a time
+            stage(p0);
+            if (p0 == 0) {
+                // ---- position 0: the initial-state digit in slot 0, every other sequence has zero weight
+                double c0[D], l20[K];
+                getpos(0, c0, l20);
+                for (int q = 0; q < 2; ++q) {
+                    const int w = ts * E + g * 2 + q;  // any bijection lanes x {0,1} -> the track's E sequences
+                    const int idx = w - ts * E;
+                    const int aq = wave0 + xt_f2_swz<F>(w) * 8;
+                    xt_at<double>(lds, aq) = idx == 0 ? F0 : (idx == 1 ? F1 : 0.0);
+                    xt_at<int>(lds, (aq >> 1) + ZEO) = idx < 2 ? 0 : XT_EMIN;
+                    for (int d = 0; d < D; ++d) xt_at<double>(lds, aq + (1 + d) * XT_F2_ARR) = c0[d];
+                    for (int k = 0; k < K; ++k) xt_at<double>(lds, aq + (1 + D + k) * XT_F2_ARR) = l20[k];
+                }
+                cx.wave_sync();
+            }
+            // ---- positions 1 .. L-2 that lie in this chunk: without the stay-in-FOV factor before step stay_from, with it after
+            const int tend = (L - 2 < p0 + XT_F2_CHUNK - 1) ? L - 2 : p0 + XT_F2_CHUNK - 1;
+            run_steps(t, tend < stay_from - 1 ? tend : stay_from - 1, T0);
+            run_steps(t, tend, T1);
             if (tlast < p0 || tlast >= p0 + XT_F2_CHUNK) continue;
             // ---- last position (+ leaving/bleaching factor folded into TFIN): reduction over (Q, q)
             double cl[D], l2l[K];
             getpos(tlast, cl, l2l);
             const int h = tlast % F;
-            // phase index is runtime here: pick the packed indices with a small select chain (once per track)
+            // phase index is runtime here: pick the packed addresses with a small select chain (once per track)
             int pk = st.s01[0];
             for (int hh = 1; hh < F; ++hh) pk = h == hh ? st.s01[hh] : pk;
-            const int i0 = pk & 0xffff, i1 = pk >> 16;
+            const int a0 = pk & 0xffff, a1 = (int)((unsigned)pk >> 16);
             for (int Q = 0; Q < 2; ++Q) {
-                const int iq = Q ? i1 : i0;
-                const double zq = zm[iq];
-                const int eq = ze[iq];
+                const int aq = Q ? a1 : a0;
+                const double zq = xt_at<double>(lds, aq);
+                const int eq = xt_at<int>(lds, (aq >> 1) + ZEO);
                 double dq[D], dsq = 0.0;
                 for (int d = 0; d < D; ++d) {
-                    dq[d] = cl[d] - mm[d * 128 + iq];
+                    dq[d] = cl[d] - xt_at<double>(lds, aq + (1 + d) * XT_F2_ARR);
                     dsq = xt_fma(dq[d], dq[d], dsq);
                 }
+                double x[2], gf[2];
                 for (int q = 0; q < 2; ++q) {
-                    double x, gf;
                     if (K == 1) {
-                        const double r = xt_rcp(TD2[q] + uu[iq] + l2l[0]);
-                        x = -0.5 * dsq * r;
-                        gf = xt_pow_half<D>(r);
+                        const double r = xt_rcp(TD2[q] + xt_at<double>(lds, aq + (1 + D) * XT_F2_ARR) + l2l[0]);
+                        x[q] = -0.5 * dsq * r;
+                        gf[q] = xt_pow_half<D>(r);
                     } else {
-                        x = 0.0;
-                        gf = 1.0;
+                        double xx = 0.0, gg = 1.0;
                         for (int d = 0; d < D; ++d) {
-                            const double r = xt_rcp(TD2[q] + uu[d * 128 + iq] + l2l[d]);
-                            x = xt_fma(-0.5 * dq[d] * dq[d], r, x);
-                            gf *= r;
+                            const double r = xt_rcp(TD2[q] + xt_at<double>(lds, aq + (1 + D + d) * XT_F2_ARR) + l2l[d]);
+                            xx = xt_fma(-0.5 * dq[d] * dq[d], r, xx);
+                            gg *= r;
                         }
-                        gf = sqrt(gf);
+                        x[q] = xx;
+                        gf[q] = sqrt(gg);
                     }
-                    double p;
-                    int n;
-                    xt_exp_split12(x, p, n);
-                    tot.add(zq * TFIN[q] * gf * p, eq + n);
                 }
+                double p[2];
+                int j[2], n[2];
+                xt_exp_tab_x2(x[0], x[1], p[0], p[1], j[0], j[1], n[0], n[1]);
+                for (int q = 0; q < 2; ++q)
+                    tot.add(zq * TFIN[q] * gf[q] * xt_at<double>(lds, XT_F2_T64_OFF + j[q] * 8) * p[q], eq + n[q]);
             }
         }
         // reduce over the track's NG lanes (all lanes end with the same values)

@@ -158,7 +158,7 @@ extern "C" int xt_emul_run(const double* tracks, const double* sigma, long long 
     if (xt_use_fast2(S, NS, F, preds != 0) && !getenv("XT_EMUL_GENERIC")) {
         l.threads = 64 * XT_F2_WAVES;
         l.a.TPB = 0;
-        l.lds_bytes = (size_t)(((xt_tab_doubles(2, 2) + 1) & ~1) + XT_F2_WAVES * xt_f2_wave_doubles(D, K, locerr_mode ? KS : 0, 64 >> (F - 1))) * 8;
+        l.lds_bytes = (size_t)xt_f2_block_bytes(D, K, locerr_mode ? KS : 0, 64 >> (F - 1));
         if (info) {
             info[0] = 64 >> (F - 1);
             info[1] = l.threads;
