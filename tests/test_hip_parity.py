@@ -124,6 +124,31 @@ def test_c1_config_objective():
     assert abs(v - info["cum_Proba_Cs"]) < 1e-12 * abs(v), (v, info["cum_Proba_Cs"])
 
 
+def test_c1_param_fitting_recovers_simulated_parameters(capsys):
+    """BASELINE.json configs[0] end to end: sim_FOV(10k) fixture -> param_fitting (own lmfit-compatible BFGS) on the GPU.
+    The reference validates the same way (Tutorial_ExTrack.ipynb:788-792: D1 0.2517 vs 0.25, LocErr 0.01998 vs 0.02,
+    p01 0.0951 vs 0.1); simulated truth: D=[0, 0.25], LocErr 0.02, F0 0.6, p01 = p10 = 0.1, pBL 0.1."""
+    import json
+    import os
+    from conftest import GOLDEN
+    from extrack_amd import tracking as T
+    info = json.load(open(os.path.join(GOLDEN, "c1_simfov_10k.json")))
+    data = np.load(os.path.join(GOLDEN, "c1_simfov_10k.npz"))
+    tr = {k: data["tr_" + k] for k in info["keys"]}
+    p0 = T.generate_params(nb_states=2, LocErr_type=1, LocErr_bounds=[0.005, 0.1], D_max=3, estimated_Ds=[0.0001, 0.1],
+                           estimated_Fs=[0.5], estimated_transition_rates=0.05)
+    fit = T.param_fitting(tr, info["dt"], params=p0, nb_states=2, nb_substeps=1, frame_len=6, verbose=0, method="bfgs", cell_dims=[1])
+    capsys.readouterr()
+    v = {k: fit.params[k].value for k in fit.params}
+    assert fit.residual.shape == (1,)
+    assert fit.residual[0] <= info["cum_Proba_Cs"] + 1e-6  # at least as good as the generating parameters
+    assert abs(v["D1"] - 0.25) < 0.02 and v["D0"] < 5e-3
+    assert abs(v["LocErr"] - 0.02) < 0.002
+    assert abs(v["F0"] - 0.6) < 0.05 and abs(v["F1"] - (1 - v["F0"])) < 1e-12
+    assert abs(v["p01"] - 0.1) < 0.03 and abs(v["p10"] - 0.1) < 0.03
+    assert 50 < fit.nfev < 5000
+
+
 @pytest.mark.parametrize("S,ns,F,L,N", [(2, 1, 6, 30, 5000), (3, 1, 6, 17, 600), (4, 1, 5, 20, 200), (4, 3, 4, 12, 24), (2, 2, 6, 40, 500),
                                          (3, 1, 4, 50, 700), (2, 1, 9, 25, 300), (4, 1, 6, 14, 40)])
 def test_seeded_vs_oracle(S, ns, F, L, N):
