@@ -12,6 +12,7 @@
 
 #include "../../include/extrack_hip.h"
 #include "xt_dispatch.h"
+#include "xt_entry.h"
 #include "xt_fast2.h"
 #include "xt_tables.h"
 
@@ -64,6 +65,13 @@ __global__ void __launch_bounds__(64 * XT_F2_WAVES) xt_ll_s2_kernel(XtKernelArgs
 {
     DevCtx cx;
     xt_ll_s2_body<F, D, K>(a, cx);
+}
+
+template <int GP, int D, int K, int MAXT>
+__global__ void __launch_bounds__(MAXT) xt_entry_kernel(XtKernelArgs a)
+{
+    DevCtx cx;
+    xt_entry_body<GP, D, K>(a, cx);
 }
 
 // Fixed-order reduction of the per-block partial sums (deterministic for a given launch geometry).
@@ -373,6 +381,13 @@ struct DevLauncher {
         return launch(xt_track_kernel<G_, D, K, PREDS, 1024>);
     }
 
+    template <int GP, int D, int K>
+    bool run_entry()
+    {
+        if (threads <= 256) return launch(xt_entry_kernel<GP, D, K, 256>);
+        return launch(xt_entry_kernel<GP, D, K, 1024>);
+    }
+
     template <int F, int D, int K>
     bool run_f2()
     {
@@ -443,7 +458,10 @@ static int xt_launch_bucket(extrack_ctx* ctx, const extrack_model* m, XtBucket& 
     xt_fill_args_from_config(c, l.a);
     int tpb, threads;
     const bool fast2 = xt_use_fast2(c.S, c.NS, c.F, preds);
-    if (fast2) {
+    const bool entry = !fast2 && xt_use_entry(c.NS, c.G, c.NG, preds);
+    if (entry) {
+        xt_entry_geometry(c.S, c.G, c.E, c.NG, D, K, tpb, threads, l.lds);
+    } else if (fast2) {
         const int tpw = 64 >> (c.F - 1);
         tpb = tpw * XT_F2_WAVES;
         threads = 64 * XT_F2_WAVES;
@@ -473,7 +491,8 @@ static int xt_launch_bucket(extrack_ctx* ctx, const extrack_model* m, XtBucket& 
     l.a.locerr_mode = m->locerr_mode;
     l.a.KS = b.KS ? b.KS : 1;
     l.a.ll_const = -(double)(b.L - 1) * D * 0.5 * XT_LOG2PI;
-    const bool ok = fast2 ? xt_dispatch_f2(c.F, D, K, l) : xt_dispatch(c.G, D, K, preds, l);
+    const bool ok = fast2 ? xt_dispatch_f2(c.F, D, K, l)
+                          : (entry ? xt_dispatch_entry(xt_entry_gp(c.G), D, K, l) : xt_dispatch(c.G, D, K, preds, l));
     if (!ok)
         return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, preds ? "posteriors are built for n_states <= 6" : "kernel variant not built");
     if (l.herr != hipSuccess) return xt_fail(ctx, EXTRACK_E_HIP, std::string("kernel launch: ") + hipGetErrorString(l.herr));

@@ -58,3 +58,26 @@ static inline bool xt_dispatch_f2(int F, int D, int K, L& l)
     if (F == 7) return xt_dispatch_f2_dk<7>(D, K, l);
     return false;
 }
+
+// ---- entry-parallel path for ns >= 2 (xt_entry.h): run_entry<GP, D, K>()
+template <int GP, class L>
+static inline bool xt_dispatch_entry_dk(int D, int K, L& l)
+{
+    if (D == 1 && K == 1) return l.template run_entry<GP, 1, 1>();
+    if (D == 2 && K == 1) return l.template run_entry<GP, 2, 1>();
+    if (D == 2 && K == 2) return l.template run_entry<GP, 2, 2>();
+    if (D == 3 && K == 1) return l.template run_entry<GP, 3, 1>();
+    if (D == 3 && K == 3) return l.template run_entry<GP, 3, 3>();
+    return false;
+}
+
+template <class L>
+static inline bool xt_dispatch_entry(int GP, int D, int K, L& l)
+{
+    if (GP == 4) return xt_dispatch_entry_dk<4>(D, K, l);
+    if (GP == 8) return xt_dispatch_entry_dk<8>(D, K, l);
+    if (GP == 16) return xt_dispatch_entry_dk<16>(D, K, l);
+    if (GP == 32) return xt_dispatch_entry_dk<32>(D, K, l);
+    if (GP == 64) return xt_dispatch_entry_dk<64>(D, K, l);
+    return false;
+}

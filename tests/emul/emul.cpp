@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "../../extrack_amd/csrc/xt_dispatch.h"
+#include "../../extrack_amd/csrc/xt_entry.h"
 #include "../../extrack_amd/csrc/xt_fast2.h"
 #include "../../extrack_amd/csrc/xt_tables.h"
 
@@ -81,6 +82,32 @@ struct EmulLauncher {
                     cx.wbar_ = &wb[t >> 6];
                     cx.wscr_ = ws[t >> 6].data();
                     xt_ll_s2_body<F, D, K>(a, cx);
+                });
+            for (auto& x : th) x.join();
+            pthread_barrier_destroy(&bar);
+            for (auto& x : wb) pthread_barrier_destroy(&x);
+        }
+        return true;
+    }
+
+    template <int GP, int D, int K>
+    bool run_entry()
+    {
+        const int nw = threads / 64;
+        for (int b = 0; b < nblocks; ++b) {
+            std::vector<double> smem(lds_bytes / 8 + 16, 0.0);
+            pthread_barrier_t bar;
+            pthread_barrier_init(&bar, nullptr, threads);
+            std::vector<pthread_barrier_t> wb(nw);
+            std::vector<std::vector<double>> ws(nw, std::vector<double>(64, 0.0));
+            for (auto& x : wb) pthread_barrier_init(&x, nullptr, 64);
+            std::vector<std::thread> th;
+            for (int t = 0; t < threads; ++t)
+                th.emplace_back([&, t]() {
+                    HostCtx cx{t, threads, b, nblocks, smem.data(), &bar};
+                    cx.wbar_ = &wb[t >> 6];
+                    cx.wscr_ = ws[t >> 6].data();
+                    xt_entry_body<GP, D, K>(a, cx);
                 });
             for (auto& x : th) x.join();
             pthread_barrier_destroy(&bar);
@@ -165,6 +192,19 @@ extern "C" int xt_emul_run(const double* tracks, const double* sigma, long long 
             info[2] = (int)l.lds_bytes;
         }
         if (!xt_dispatch_f2(F, D, K, l)) return -3;
+    } else if (xt_use_entry(NS, cfg.G, cfg.NG, preds != 0) && !getenv("XT_EMUL_GENERIC")) {
+        int tpb2, thr2;
+        size_t lds2;
+        xt_entry_geometry(S, cfg.G, cfg.E, cfg.NG, D, K, tpb2, thr2, lds2);
+        l.threads = thr2;
+        l.a.TPB = tpb2;
+        l.lds_bytes = lds2;
+        if (info) {
+            info[0] = tpb2;
+            info[1] = thr2;
+            info[2] = (int)lds2;
+        }
+        if (!xt_dispatch_entry(xt_entry_gp(cfg.G), D, K, l)) return -3;
     } else if (!xt_dispatch(cfg.G, D, K, preds != 0, l)) return -3;
     double s = 0.0;
     for (double p : partials) s += p;
