@@ -55,6 +55,8 @@ struct XtKernelArgs {
 XT_HD int xt_tab_doubles(int S, int G) { return XT_BLOB_HDR + XT_NTAB * S * G; }
 XT_HD int xt_region_doubles(int E, int D, int K) { return E * (1 + D + K) + (E + 1) / 2 + 2; }
 XT_HD int xt_pred_doubles(int S, int F) { return 2 * (S + 1) + (F + 1) * S + 2; }
+#define XT_STAGE 32  // positions of a track staged in LDS per refill (coalesced loads instead of a dependent global load per step)
+XT_HD int xt_stage_doubles(int D) { return XT_STAGE * (D + XT_MAX_DIMS); }
 
 template <int K, int D>
 struct XtL2 {
@@ -91,6 +93,8 @@ XT_HD void xt_track_body(const XtKernelArgs& a, Ctx& cx)
     int* pe = (int*)pbase;
     double* pacc = pbase + 2;
     double* facc = pacc + 2 * S;
+    double* spos = smem + ((ntab + 1) & ~1) + a.TPB * (rdoubles + xt_pred_doubles(S, F)) + (tvalid ? slot : 0) * xt_stage_doubles(D);
+    double* ssig = spos + XT_STAGE * D;
 
     const int prev = g / a.prev_div;
     const double* T0 = TAB + (0 * S + prev) * G;
@@ -101,6 +105,14 @@ XT_HD void xt_track_body(const XtKernelArgs& a, Ctx& cx)
     double block_ll = 0.0;  // meaningful in thread g == 0 of each slot
     const int64_t nbatch = (a.N + a.TPB - 1) / a.TPB;
     cx.sync();
+    // compile-time group size: the table rows of this thread's (constant) newest old digit live in registers
+    double T0r[G_ ? G_ : 1], T1r[G_ ? G_ : 1], D2r[G_ ? G_ : 1];
+    if (G_)
+        for (int q = 0; q < (G_ ? G_ : 1); ++q) {
+            T0r[q] = T0[q];
+            T1r[q] = T1[q];
+            D2r[q] = TD2[q];
+        }
 
     for (int64_t batch = cx.block(); batch < nbatch; batch += cx.nblocks()) {
         const int64_t trk = batch * a.TPB + slot;
@@ -108,12 +120,23 @@ XT_HD void xt_track_body(const XtKernelArgs& a, Ctx& cx)
         const double* c = a.tracks + (act ? trk : 0) * (int64_t)L * D;
         const double* sg = a.sigma ? a.sigma + (act ? trk : 0) * (int64_t)L * a.KS : nullptr;
 
+        // positions [p0, p0 + XT_STAGE) of this track -> LDS, by the track's own threads (coalesced along the track)
+        auto stage = [&](int p0) {
+            if (act) {
+                for (int i = g; i < XT_STAGE * D; i += NG)
+                    if (p0 + i / D < L) spos[i] = c[p0 * D + i];
+                if (sg)
+                    for (int i = g; i < XT_STAGE * a.KS; i += NG)
+                        if (p0 + i / a.KS < L) ssig[i] = sg[p0 * a.KS + i];
+            }
+            cx.sync();
+        };
         auto load_l2 = [&](int pos, double* l2) {
             if (a.locerr_mode == 0) {
                 for (int k = 0; k < K; ++k) l2[k] = hdr[k];
             } else {
                 for (int k = 0; k < K; ++k) {
-                    double s = sg[pos * a.KS + (a.KS == 1 ? 0 : k)];
+                    double s = ssig[(pos & (XT_STAGE - 1)) * a.KS + (a.KS == 1 ? 0 : k)];
                     if (a.locerr_mode == 2) {
                         s = xt_fma(s, hdr[3], hdr[4]);
                         s = s < 1e-6 ? 1e-6 : s;
@@ -123,11 +146,12 @@ XT_HD void xt_track_body(const XtKernelArgs& a, Ctx& cx)
             }
         };
 
+        stage(0);
         // ---- position 0: one digit (initial state) in slot 0, everything else zero weight
         if (act) {
             double l20[K], c0[D];
             load_l2(0, l20);
-            for (int d = 0; d < D; ++d) c0[d] = c[d];
+            for (int d = 0; d < D; ++d) c0[d] = spos[d];
             for (int i = g; i < E; i += NG) {
                 const bool live = i < S;
                 zm[i] = live ? hdr[8 + i] : 0.0;
@@ -147,6 +171,7 @@ XT_HD void xt_track_body(const XtKernelArgs& a, Ctx& cx)
 
         // ---- positions 1 .. L-2: fuse the group, expand by the new digits, integrate position t
         for (int t = 1; t <= L - 2; ++t) {
+            if ((t & (XT_STAGE - 1)) == 0) stage(t);
             const int ph = (t - 1) % a.P;
             const bool do_pred = PREDS && t >= F;
             const int par = t & 1;
@@ -155,9 +180,12 @@ XT_HD void xt_track_body(const XtKernelArgs& a, Ctx& cx)
                 const int base = a.base_tab[ph * NG + g];
                 const int32_t* off = a.off_tab + ph * G;
                 double ct[D], l2t[K];
-                for (int d = 0; d < D; ++d) ct[d] = c[t * D + d];
+                for (int d = 0; d < D; ++d) ct[d] = spos[(t & (XT_STAGE - 1)) * D + d];
                 load_l2(t, l2t);
-                const double* TT = (t >= stay_from) ? T1 : T0;
+                const bool stay = t >= stay_from;
+                const double* TTl = stay ? T1 : T0;
+                auto TT = [&](int q) { return G_ ? (stay ? T1r[G_ ? q : 0] : T0r[G_ ? q : 0]) : TTl[q]; };
+                auto TDD = [&](int q) { return G_ ? D2r[G_ ? q : 0] : TD2[q]; };
 
                 int emax = XT_EMIN;
                 for (int q = 0; q < G; ++q) {
@@ -193,7 +221,7 @@ XT_HD void xt_track_body(const XtKernelArgs& a, Ctx& cx)
                             for (int q = 0; q < G; ++q) {
                                 double quad, gf;
                                 if (K == 1) {
-                                    const double r = xt_rcp(TD2[q] + uq[0] + l2t[0]);
+                                    const double r = xt_rcp(TDD(q) + uq[0] + l2t[0]);
                                     quad = 0.5 * dsq * r;
                                     gf = r;
                                     for (int d = 1; d < D; ++d) gf *= r;
@@ -201,7 +229,7 @@ XT_HD void xt_track_body(const XtKernelArgs& a, Ctx& cx)
                                     quad = 0.0;
                                     gf = 1.0;
                                     for (int d = 0; d < D; ++d) {
-                                        const double r = xt_rcp(TD2[q] + uq[d] + l2t[d]);
+                                        const double r = xt_rcp(TDD(q) + uq[d] + l2t[d]);
                                         quad = xt_fma(0.5 * dq[d] * dq[d], r, quad);
                                         gf *= r;
                                     }
@@ -209,7 +237,7 @@ XT_HD void xt_track_body(const XtKernelArgs& a, Ctx& cx)
                                 double p;
                                 int n;
                                 xt_exp_split(-quad, p, n);
-                                pq[Q].add(zq * TT[q] * gf * p, ze[idx] + n);
+                                pq[Q].add(zq * TT(q) * gf * p, ze[idx] + n);
                             }
                         }
                         pemax = pq[Q].e > pemax ? pq[Q].e : pemax;
@@ -230,7 +258,7 @@ XT_HD void xt_track_body(const XtKernelArgs& a, Ctx& cx)
                 }
                 for (int q = 0; q < G; ++q) {
                     const int idx = base + off[q];
-                    const double d2 = TD2[q];
+                    const double d2 = TDD(q);
                     double quad, gf, tt[K];
                     if (K == 1) {
                         const double s2 = d2 + ub[0];
@@ -253,7 +281,7 @@ XT_HD void xt_track_body(const XtKernelArgs& a, Ctx& cx)
                     double p;
                     int n;
                     xt_exp_split(-quad, p, n);
-                    double zn = Wm * TT[q] * gf * p;
+                    double zn = Wm * TT(q) * gf * p;
                     int en = We + n;
                     if (zn == 0.0 || en <= XT_EMIN) {
                         zn = 0.0;
@@ -284,6 +312,7 @@ XT_HD void xt_track_body(const XtKernelArgs& a, Ctx& cx)
         }
 
         // ---- last position (+ leaving/bleaching term): pure reduction over (old entry Q, new digits q)
+        if (((L - 1) & (XT_STAGE - 1)) == 0) stage(L - 1);
         XtAcc tot;
         tot.clear();
         XtAcc accQ[PREDS ? (G_ ? G_ : 1) : 1], accq[PREDS ? (G_ ? G_ : 1) : 1];
@@ -295,7 +324,7 @@ XT_HD void xt_track_body(const XtKernelArgs& a, Ctx& cx)
             const int vfin = (a.isBL ? 2 : 0) + (tl >= stay_from ? 1 : 0);
             const double* TF = TAB + (vfin * S + prev) * G;
             double cl[D], l2l[K];
-            for (int d = 0; d < D; ++d) cl[d] = c[tl * D + d];
+            for (int d = 0; d < D; ++d) cl[d] = spos[(tl & (XT_STAGE - 1)) * D + d];
             load_l2(tl, l2l);
             if (PREDS)
                 for (int q = 0; q < G; ++q) {

@@ -157,7 +157,7 @@ static inline void xt_fill_args_from_config(const XtConfig& c, XtKernelArgs& a)
 static inline size_t xt_lds_bytes(const XtConfig& c, int D, int K, int tpb)
 {
     size_t d = (size_t)((xt_tab_doubles(c.S, c.G) + 1) & ~1) + (size_t)tpb * xt_region_doubles(c.E, D, K);
-    d += (size_t)tpb * xt_pred_doubles(c.S, c.F);  // posterior accumulators are laid out for both kernels (small)
+    d += (size_t)tpb * (xt_pred_doubles(c.S, c.F) + xt_stage_doubles(D));  // posterior accumulators + staged positions
     return d * sizeof(double);
 }
 

@@ -74,3 +74,44 @@ def test_fast2_multi_chunk_tracks(F, L, N, monkeypatch):
     ll, _, tot, _ = E.run(Cs, LE, ds, Fs, T, 0.1, 1, ps, 1, F, 3, nblocks=2)
     assert np.abs(ll - ref).max() < 1e-10
     assert abs(tot - ref.sum()) < 1e-9
+
+
+@pytest.mark.parametrize("S,ns,F,L,N,pred", [(3, 1, 3, 40, 7, True), (2, 1, 4, 70, 9, True), (2, 2, 3, 66, 5, False), (3, 1, 4, 33, 4, True)])
+def test_generic_body_multi_chunk_and_per_peak(S, ns, F, L, N, pred, monkeypatch):
+    """General kernel body with tracks longer than one 32-position staging chunk, per-peak localisation errors,
+    likelihood and posteriors, against the oracle."""
+    monkeypatch.setenv("XT_EMUL_GENERIC", "1")
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "emul"))
+    import run_emul as E
+    rng = np.random.default_rng(S * 1000 + L)
+    ds = np.sort(rng.uniform(0.01, 0.15, S))
+    Fs = np.full(S, 1 / S)
+    T = np.full((S, S), 0.08)
+    T[np.arange(S), np.arange(S)] = 1 - 0.08 * (S - 1)
+    Cs = np.cumsum(rng.normal(0, 0.05, (N, L, 2)), 1)
+    LE = rng.uniform(0.01, 0.03, (N, L, 2))
+    ps = O.p_stay_table(ds, S, ns, [1.0])
+    LPr, pr = O.p_cs_inter_bound_stats(Cs, LE, ds, Fs, T, 0.1, 1, [1.0], ns, F, 1 if pred else 0, 3)
+    mx = LPr.max(1, keepdims=True)
+    ref = np.log(np.exp(LPr - mx).sum(1)) + mx[:, 0]
+    ll, p, tot, _ = E.run(Cs, LE, ds, Fs, T, 0.1, 1, ps, ns, F, 3, preds=pred, nblocks=2)
+    assert np.abs(ll - ref).max() < 1e-10
+    if pred:
+        assert np.abs(p - pr).max() < 1e-9
+
+
+def test_entry_parallel_body_on_multi_substep_cases(kernel_cases, monkeypatch):
+    """nb_substeps >= 2 goes through the entry-parallel kernel body (xt_entry.h)."""
+    monkeypatch.delenv("XT_EMUL_GENERIC", raising=False)
+    meta, data = kernel_cases
+    worst, n = 0.0, 0
+    for row in meta:
+        if row["ns"] < 2 or row["id"] % 6:
+            continue
+        x = case_inputs(row, data)
+        ll, _, tot, _ = _run(row, x, False, nblocks=2)
+        worst = max(worst, np.abs(ll - x["LPC"]).max())
+        assert abs(tot - ll.sum()) < 1e-9
+        n += 1
+    assert n > 60 and worst < 1e-10, (n, worst)
