@@ -101,6 +101,10 @@ def main():
     if world > 1 or os.environ.get("EXTRACK_BENCH_FORCE_COMM") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", str(rank))
+        os.environ.setdefault("WORLD_SIZE", str(world))
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         from extrack_amd.distributed import Comm
         comm = Comm()
@@ -136,6 +140,9 @@ def main():
         dt_all = comm.allreduce_scalar(dt_loc, "max")
     else:
         dt_all = dt_loc
+    if comm is not None:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
     if rank != 0:
         return
     ms_per_step = dt_all / a.steps * 1e3
@@ -171,7 +178,13 @@ def main():
     if not a.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline()
         out["speedup_vs_cpu_baseline"] = evals_per_s / out["cpu_baseline"]["value"]
-    print(json.dumps(out))
+    try:  # RCCL's version banner (NCCL_DEBUG=VERSION) sits in the C stdio buffer: flush it so the JSON line comes last
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+    print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
