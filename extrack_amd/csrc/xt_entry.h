@@ -94,6 +94,7 @@ XT_HD void xt_entry_body(const XtKernelArgs& a, Ctx& cx)
         }
         cx.sync();
 
+        bool bad = false;  // NaN position / sigma seen by this thread
         // ---- positions 1 .. L-2
         for (int t = 1; t <= L - 2; ++t) {
             const int ph = (t - 1) % a.P;
@@ -106,8 +107,12 @@ XT_HD void xt_entry_body(const XtKernelArgs& a, Ctx& cx)
             for (int d = 0; d < D; ++d) ct[d] = 0.0;
             for (int k = 0; k < K; ++k) l2t[k] = 1.0;
             if (act) {
-                for (int d = 0; d < D; ++d) ct[d] = c[t * D + d];
+                for (int d = 0; d < D; ++d) {
+                    ct[d] = c[t * D + d];
+                    bad = bad || ct[d] != ct[d];
+                }
                 load_l2(t, l2t);
+                for (int k = 0; k < K; ++k) bad = bad || l2t[k] != l2t[k];
                 if (qvalid) {
                     idx = a.base_tab[ph * NG + g] + a.off_tab[ph * G + q];
                     z = zm[idx];
@@ -189,8 +194,12 @@ XT_HD void xt_entry_body(const XtKernelArgs& a, Ctx& cx)
             const double* TF = TAB + (vfin * S + prev) * G;
             const double* TD2 = TAB + (4 * S + prev) * G;
             double cl[D], l2l[K];
-            for (int d = 0; d < D; ++d) cl[d] = c[tl * D + d];
+            for (int d = 0; d < D; ++d) {
+                cl[d] = c[tl * D + d];
+                bad = bad || cl[d] != cl[d] || c[d] != c[d];
+            }
             load_l2(tl, l2l);
+            for (int k = 0; k < K; ++k) bad = bad || l2l[k] != l2l[k];
             const double zq = zm[idx];
             if (zq != 0.0) {
                 const int eq = ze[idx];
@@ -223,6 +232,7 @@ XT_HD void xt_entry_body(const XtKernelArgs& a, Ctx& cx)
                 }
             }
         }
+        if (bad) tot.add(NAN, 0);  // NaN input -> NaN likelihood, as in the reference
         // track-level reduction: butterfly over each wave, then the (<= 16) per-wave partials in fixed order
         int fe = tot.m != 0.0 ? tot.e : XT_EMIN;
         for (int m = 1; m < RW; m <<= 1) {

@@ -94,6 +94,7 @@ struct XtF2State {
 // from the zm address by a compile-time offset and ze (4-byte elements) by (a >> 1) + constant.
 #define XT_F2_TAB_BYTES 1024                                   /* model tables (288 B) + T64 exp table (512 B) */
 #define XT_F2_T64_OFF 320
+#define XT_F2_NAN_OFF 832                                      /* int[XT_F2_WAVES][8]: track has a NaN position / sigma */
 #define XT_F2_ARR (XT_F2_WAVES * 128 * 8)                      /* bytes of one double field for all waves */
 #define XT_F2_ZM0 XT_F2_TAB_BYTES
 XT_HD int xt_f2_ze0(int D, int K) { return XT_F2_ZM0 + (1 + D + K) * XT_F2_ARR; }
@@ -270,7 +271,11 @@ XT_HD void xt_ll_s2_body(const XtKernelArgs& a, Ctx& cx)
                 const int64_t tk = batch * TPW + t_;
                 const int64_t tkc = tk < a.N ? tk : a.N - 1;
                 const int pp = p0 + r / D;
-                if (pp < L) pos[i] = a.tracks[(tkc * L + p0) * D + r];
+                if (pp < L) {
+                    const double v = a.tracks[(tkc * L + p0) * D + r];
+                    pos[i] = v;
+                    if (v != v) xt_at<int>(lds, XT_F2_NAN_OFF + (wib * 8 + t_) * 4) = 1;
+                }
             }
             if (KS)
                 for (int i = lane; i < TPW * XT_F2_CHUNK * KS; i += 64) {
@@ -278,7 +283,11 @@ XT_HD void xt_ll_s2_body(const XtKernelArgs& a, Ctx& cx)
                     const int64_t tk = batch * TPW + t_;
                     const int64_t tkc = tk < a.N ? tk : a.N - 1;
                     const int pp = p0 + r / KS;
-                    if (pp < L) sig[i] = a.sigma[(tkc * L + p0) * KS + r];
+                    if (pp < L) {
+                        const double v = a.sigma[(tkc * L + p0) * KS + r];
+                        sig[i] = v;
+                        if (v != v) xt_at<int>(lds, XT_F2_NAN_OFF + (wib * 8 + t_) * 4) = 1;
+                    }
                 }
             cx.wave_sync();
         };
@@ -324,6 +333,8 @@ XT_HD void xt_ll_s2_body(const XtKernelArgs& a, Ctx& cx)
         XtAcc tot;
         tot.clear();
         int t = 1;
+        if (lane < 8) xt_at<int>(lds, XT_F2_NAN_OFF + (wib * 8 + lane) * 4) = 0;
+        cx.wave_sync();
         for (int p0 = 0; p0 < L; p0 += XT_F2_CHUNK) {  // one staged chunk of positions at a time
             stage(p0);
             if (p0 == 0) {
@@ -395,6 +406,7 @@ XT_HD void xt_ll_s2_body(const XtKernelArgs& a, Ctx& cx)
         }
         double sum = tot.m != 0.0 ? xt_ldexp(tot.m, tot.e - fe) : 0.0;
         for (int m = 1; m < NG; m <<= 1) sum += cx.shfl_xor_f64(sum, m);
+        if (xt_at<int>(lds, XT_F2_NAN_OFF + (wib * 8 + ts) * 4)) sum = NAN;  // NaN input -> NaN likelihood, as in the reference
         if (act) {
             if (a.ll_out && g == 0) a.ll_out[trk] = log(sum) + (double)fe * XT_LN2 + a.ll_const;
             const double pm = accm * xt_frexp_mant(sum);

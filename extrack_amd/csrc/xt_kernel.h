@@ -104,6 +104,7 @@ XT_HD void xt_track_body(const XtKernelArgs& a, Ctx& cx)
 
     double block_ll = 0.0;  // meaningful in thread g == 0 of each slot
     const int64_t nbatch = (a.N + a.TPB - 1) / a.TPB;
+    if (tvalid && g == 0) red_e[1] = 0;
     cx.sync();
     // compile-time group size: the table rows of this thread's (constant) newest old digit live in registers
     double T0r[G_ ? G_ : 1], T1r[G_ ? G_ : 1], D2r[G_ ? G_ : 1];
@@ -124,10 +125,18 @@ XT_HD void xt_track_body(const XtKernelArgs& a, Ctx& cx)
         auto stage = [&](int p0) {
             if (act) {
                 for (int i = g; i < XT_STAGE * D; i += NG)
-                    if (p0 + i / D < L) spos[i] = c[p0 * D + i];
+                    if (p0 + i / D < L) {
+                        const double v = c[p0 * D + i];
+                        spos[i] = v;
+                        if (v != v) red_e[1] = 1;  // NaN input: the track's results become NaN, as in the reference
+                    }
                 if (sg)
                     for (int i = g; i < XT_STAGE * a.KS; i += NG)
-                        if (p0 + i / a.KS < L) ssig[i] = sg[p0 * a.KS + i];
+                        if (p0 + i / a.KS < L) {
+                            const double v = sg[p0 * a.KS + i];
+                            ssig[i] = v;
+                            if (v != v) red_e[1] = 1;
+                        }
             }
             cx.sync();
         };
@@ -392,10 +401,11 @@ XT_HD void xt_track_body(const XtKernelArgs& a, Ctx& cx)
             }
         }
         cx.sync();
+        const bool poisoned = act && red_e[1] != 0;
         if (act && g == 0) {
             double sum = 0.0;
             for (int i = 0; i < NG; ++i) sum += zm[i];
-            const double ll = log(sum) + (double)fe * XT_LN2 + a.ll_const;
+            const double ll = poisoned ? NAN : log(sum) + (double)fe * XT_LN2 + a.ll_const;
             if (a.ll_out) a.ll_out[trk] = ll;
             block_ll += ll;
         }
@@ -407,8 +417,11 @@ XT_HD void xt_track_body(const XtKernelArgs& a, Ctx& cx)
                 for (int s = 0; s < S; ++s) tots += facc[j * S + s];
                 a.preds_out[(trk * L + (L - 1 - j)) * S + (i - j * S)] = facc[i] / tots;
             }
+            if (poisoned)
+                for (int i = g; i < L * S; i += NG) a.preds_out[trk * L * S + i] = NAN;
         }
         cx.sync();  // scratch (zm) and accumulators are re-initialised by the next batch
+        if (act && g == 0) red_e[1] = 0;
     }
 
     // ---- block partial: fixed-order sum over the block's track slots

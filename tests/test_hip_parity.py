@@ -224,3 +224,107 @@ def test_rccl_single_rank_allreduce_path():
         pytest.skip("RCCL bootstrap did not complete within 240 s on this host")
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "RCCL_PATH_OK" in r.stdout
+
+
+def _oracle_total(vals, tracks, dt, cell_dims, F, ns=1, sig=None):
+    from oracle import oracle_np as O
+    return O.cum_proba_cs(vals, tracks, dt, cell_dims, sig, ns, F)
+
+
+def test_input_layouts_and_dtypes_give_identical_results():
+    """float32 / Fortran-ordered / strided views of the same numbers must give the result of the contiguous fp64 copy."""
+    from extrack_amd import synth, tracking as T
+    base = synth.brownian_tracks(500, 12, [0.0, 0.25], [[.9, .1], [.1, .9]], [.6, .4], seed=3).astype(np.float32).astype(np.float64)
+    p = _params(dict(D0=1e-3, D1=0.25, LocErr=0.02, F0=0.6, F1=0.4, p01=0.1, p10=0.1, pBL=0.1))
+    ref = T.cum_Proba_Cs(p, [base], 0.02, [1], None, 2, 1, 6, verbose=0)
+    big = np.zeros((500, 24, 2))
+    big[:, ::2] = base
+    for variant in (base.astype(np.float32), np.asfortranarray(base), big[:, ::2]):
+        _, lst, _ = T.engine.sort_buckets({"12": variant})
+        assert T.cum_Proba_Cs(p, lst, 0.02, [1], None, 2, 1, 6, verbose=0) == ref
+
+
+def test_nan_input_maps_to_inf_like_the_reference(capsys):
+    from extrack_amd import synth, tracking as T
+    Cs = synth.brownian_tracks(64, 9, [0.0, 0.25], [[.9, .1], [.1, .9]], [.6, .4], seed=4)
+    Cs[17, 3, 1] = np.nan
+    p = _params(dict(D0=1e-3, D1=0.25, LocErr=0.02, F0=0.6, F1=0.4, p01=0.1, p10=0.1, pBL=0.1))
+    assert T.cum_Proba_Cs(p, [Cs], 0.02, [1], None, 2, 1, 6, verbose=0) == np.inf  # tracking.py:1084-1086
+    capsys.readouterr()
+
+
+@pytest.mark.parametrize("S,F", [(2, 6), (3, 4)])
+def test_extreme_displacements_do_not_underflow(S, F):
+    """A 40 um jump with 20 nm localisation error has a Gaussian exponent of about -1e6: exp() underflows in a naive linear-domain
+    implementation; the extended-range weights must reproduce the reference's (finite) log-domain value."""
+    from extrack_amd import synth, tracking as T
+    from oracle import oracle_np as O
+    rng = np.random.default_rng(9)
+    Ds = [0.0, 0.25, 1.0][:S]
+    Tm = np.full((S, S), 0.1)
+    Tm[np.arange(S), np.arange(S)] = 1 - 0.1 * (S - 1)
+    Fs = np.full(S, 1.0 / S)
+    Cs = synth.brownian_tracks(40, 15, Ds, Tm, Fs, seed=5)
+    Cs[::4, 7:] += 40.0                      # one huge jump in a quarter of the tracks
+    Cs[1::4, 3] += rng.normal(0, 5.0, (10, 2))  # an outlier position
+    ds = np.sqrt(2 * np.array(Ds) * 0.02) + 1e-4
+    LE = np.array([[[0.02]]])
+    ref = O.proba_cs(Cs, LE, ds, Fs, Tm, 0.1, 1, [1.0], 1, F, 3)
+    got = T.Proba_Cs(Cs, LE, ds, Fs, Tm, 0.1, 1, [1.0], 1, F, 3)
+    assert np.all(np.isfinite(got)) and ref.min() < -1e4
+    np.testing.assert_allclose(got, ref, rtol=1e-13, atol=1e-10)
+
+
+def test_large_coordinate_offsets():
+    """Positions around 1e4 um (pixel-like coordinates): both implementations difference nearby fp64 numbers; parity must hold to the
+    conditioning of the problem (|c| * eps / sigma^2 ~ 1e-12 * 1e4 / 4e-4 per step)."""
+    from extrack_amd import synth, tracking as T
+    from oracle import oracle_np as O
+    Cs = synth.brownian_tracks(200, 20, [0.0, 0.25], [[.9, .1], [.1, .9]], [.6, .4], seed=6) + 1.0e4
+    ds = np.sqrt(2 * np.array([0.0, 0.25]) * 0.02) + 1e-4
+    LE = np.array([[[0.02]]])
+    Tm = np.array([[.9, .1], [.1, .9]])
+    ref = O.proba_cs(Cs, LE, ds, [.6, .4], Tm, 0.1, 1, [1.0], 1, 6, 3)
+    got = T.Proba_Cs(Cs, LE, ds, [.6, .4], Tm, 0.1, 1, [1.0], 1, 6, 3)
+    assert np.abs(got - ref).max() < 1e-6
+
+
+def test_per_dimension_locerr_and_3d_through_public_api():
+    from extrack_amd import synth, tracking as T
+    tr = {str(L): synth.brownian_tracks(150, L, [0.0, 0.1, 0.4], [[.9, .05, .05], [.05, .9, .05], [.05, .05, .9]], [.3, .3, .4], dims=3, seed=L)
+          for L in (4, 8, 13)}
+    vals = dict(D0=1e-4, D1=0.1, D2=0.4, LocErr0=0.02, LocErr1=0.02, LocErr2=0.05, F0=0.3, F1=0.3, F2=0.4, p01=0.05, p02=0.05, p10=0.05,
+                p12=0.05, p20=0.05, p21=0.05, pBL=0.1)
+    p = _params(vals)
+    _, lst, _ = T.engine.sort_buckets(tr)
+    for ns, F in ((1, 4), (2, 3)):
+        got = T.cum_Proba_Cs(p, lst, 0.03, [1.0, 2.0], None, 3, ns, F, verbose=0)
+        ref = _oracle_total(vals, tr, 0.03, [1.0, 2.0], F, ns)
+        assert abs(got - ref) < 1e-12 * abs(ref)
+    pr = T.predict_Bs(tr, 0.03, p, cell_dims=[1.0, 2.0], nb_states=3, frame_len=4)
+    from oracle import oracle_np as O
+    pro = O.predict_bs(vals, tr, 0.03, [1.0, 2.0], 4)
+    for k in tr:
+        assert pr[k].shape == (150, int(k), 3)
+        np.testing.assert_allclose(pr[k], pro[k], atol=TOL_PRED, rtol=0)
+
+
+def test_tiny_and_ragged_datasets():
+    """One track; buckets smaller than a wave; a bucket with a single 2-position track; empty bucket keys preserved by predict_Bs."""
+    from extrack_amd import synth, tracking as T
+    from oracle import oracle_np as O
+    vals = dict(D0=1e-3, D1=0.25, LocErr=0.02, F0=0.6, F1=0.4, p01=0.1, p10=0.1, pBL=0.1)
+    p = _params(vals)
+    tr = {"2": synth.brownian_tracks(1, 2, [0.0, 0.25], [[.9, .1], [.1, .9]], [.6, .4], seed=1),
+          "3": np.zeros((0, 3, 2)),
+          "7": synth.brownian_tracks(3, 7, [0.0, 0.25], [[.9, .1], [.1, .9]], [.6, .4], seed=2),
+          "31": synth.brownian_tracks(65, 31, [0.0, 0.25], [[.9, .1], [.1, .9]], [.6, .4], seed=3)}
+    _, lst, _ = T.engine.sort_buckets(tr)
+    got = T.cum_Proba_Cs(p, lst, 0.02, [1], None, 2, 1, 6, verbose=0)
+    ref = O.cum_proba_cs(vals, tr, 0.02, [1], None, 1, 6)
+    assert abs(got - ref) < 1e-12 * abs(ref)
+    pr = T.predict_Bs(tr, 0.02, p, cell_dims=[1], nb_states=2, frame_len=5)
+    pro = O.predict_bs(vals, tr, 0.02, [1], 5)
+    assert sorted(pr.keys(), key=int) == ["2", "3", "7", "31"] and pr["3"].shape == (0, 3, 2)
+    for k in ("2", "7", "31"):
+        np.testing.assert_allclose(pr[k], pro[k], atol=TOL_PRED, rtol=0)
