@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <map>
 #include <string>
 #include <vector>
@@ -118,12 +119,16 @@ struct extrack_ctx {
     size_t partials_cap = 0;
     double* d_total = nullptr;
     double* h_total = nullptr;  // pinned
+    XtBucketDesc* d_desc = nullptr;  // [XT_DESC_CAP] bucket descriptors of the launches of one evaluation
+    XtBucketDesc* h_desc = nullptr;  // pinned staging
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
     int32_t launch_info[6] = {0, 0, 0, 0, 0, 0};
     std::map<std::pair<const void*, std::pair<int, size_t>>, int> occ_cache;
     std::string err;
 };
+
+static const int XT_DESC_CAP = 4096;  // bucket descriptors per evaluation (buckets beyond 64 per launch group are chunked)
 
 static std::string g_create_err;
 
@@ -189,6 +194,8 @@ extern "C" int extrack_create(int device_id, extrack_ctx** out)
     XT_CREATE(hipEventCreate(&c->ev1));
     XT_CREATE(hipMalloc(&c->d_total, sizeof(double)));
     XT_CREATE(hipHostMalloc(&c->h_total, sizeof(double), hipHostMallocDefault));
+    XT_CREATE(hipMalloc(&c->d_desc, XT_DESC_CAP * sizeof(XtBucketDesc)));
+    XT_CREATE(hipHostMalloc(&c->h_desc, XT_DESC_CAP * sizeof(XtBucketDesc), hipHostMallocDefault));
 #undef XT_CREATE
     *out = c;
     return EXTRACK_OK;
@@ -225,6 +232,8 @@ extern "C" void extrack_destroy(extrack_ctx* ctx)
     if (ctx->d_partials) (void)hipFree(ctx->d_partials);
     if (ctx->d_total) (void)hipFree(ctx->d_total);
     if (ctx->h_total) (void)hipHostFree(ctx->h_total);
+    if (ctx->d_desc) (void)hipFree(ctx->d_desc);
+    if (ctx->h_desc) (void)hipHostFree(ctx->h_desc);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -369,8 +378,10 @@ struct DevLauncher {
     XtKernelArgs a;
     int threads;
     size_t lds;
-    int grid_cap;  // upper bound on blocks (partials capacity reserved by the caller)
     int tracks_per_block = 1;
+    // buckets served by this launch (<= XT_MAX_BUCKETS), their descriptors are written at ctx->h_desc[desc_off ...]
+    std::vector<XtBucketDesc> descs;
+    size_t desc_off = 0;
     int grid = 0, occ = 0;
     hipError_t herr = hipSuccess;
 
@@ -411,13 +422,31 @@ struct DevLauncher {
             it = ctx->occ_cache.emplace(key, o < 1 ? 1 : o).first;
         }
         occ = it->second;
-        // Oversubscribe the CUs: waves of equal work do NOT progress equally (VALU issue is arbitrated by age), so a
-        // static one-wave-set-per-CU split ends in an under-occupied tail; with several block generations per CU the
-        // hardware dispatcher backfills as blocks retire.
-        const int64_t nbatch = (a.N + tracks_per_block - 1) / tracks_per_block;
-        int64_t gmax = (int64_t)occ * ctx->n_cu * ctx->oversub;
-        grid = (int)(nbatch < gmax ? nbatch : gmax);
-        if (grid > grid_cap) grid = grid_cap;
+        // Split the grid over the buckets in proportion to their work (track batches x positions).  The CUs are
+        // oversubscribed: waves of equal work do NOT progress equally (VALU issue is arbitrated by age), so a static
+        // one-wave-set-per-CU split ends in an under-occupied tail; with several block generations per CU the hardware
+        // dispatcher backfills as blocks retire.
+        const int nb = (int)descs.size();
+        const double target = (double)occ * ctx->n_cu * ctx->oversub;
+        std::vector<int64_t> nbatch(nb);
+        double wsum = 0.0;
+        for (int i = 0; i < nb; ++i) {
+            nbatch[i] = (descs[i].N + tracks_per_block - 1) / tracks_per_block;
+            wsum += (double)nbatch[i] * (descs[i].L - 1);
+        }
+        int64_t acc = 0;
+        for (int i = 0; i < nb; ++i) {
+            int64_t n = (int64_t)ceil(target * ((double)nbatch[i] * (descs[i].L - 1)) / wsum);
+            n = n < 1 ? 1 : (n > nbatch[i] ? nbatch[i] : n);
+            acc += n;
+            a.blk_end[i] = (int32_t)acc;
+        }
+        grid = (int)acc;
+        memcpy(ctx->h_desc + desc_off, descs.data(), nb * sizeof(XtBucketDesc));
+        herr = hipMemcpyAsync(ctx->d_desc + desc_off, ctx->h_desc + desc_off, nb * sizeof(XtBucketDesc), hipMemcpyHostToDevice, ctx->stream);
+        if (herr != hipSuccess) return true;
+        a.desc = ctx->d_desc + desc_off;
+        a.ndesc = nb;
         hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, ctx->stream, a);
         herr = hipGetLastError();
         return true;
@@ -436,21 +465,20 @@ static int xt_reserve_partials(extrack_ctx* ctx, size_t n)
     return EXTRACK_OK;
 }
 
-static const int XT_MAX_BLOCKS_PER_CU = 512;  // partial-sum slots reserved per bucket and CU
-
-// Launches the track kernel for one bucket; partial sums go to d_partials[poff .. poff+grid).
-static int xt_launch_bucket(extrack_ctx* ctx, const extrack_model* m, XtBucket& b, bool preds, double* d_ll, double* d_preds,
-                            size_t poff, int* grid_out)
+// Launches ONE kernel for a set of buckets that share (dims, sigma dims): partial sums go to d_partials[poff .. poff+grid).
+static int xt_launch_group(extrack_ctx* ctx, const extrack_model* m, const std::vector<XtBucket*>& bks, bool preds, bool per_track,
+                           double* d_preds, size_t poff, size_t desc_off, int* grid_out)
 {
     const XtConfig& c = ctx->cfg;
-    const int D = b.D;
+    const XtBucket& b0 = *bks[0];
+    const int D = b0.D;
     int K;
     if (m->locerr_mode == 0) {
         K = m->locerr_dims;
         if (K != 1 && K != D) return xt_fail(ctx, EXTRACK_E_INVALID, "locerr_dims must be 1 or the track dimensionality");
     } else {
-        if (!b.d_sigma) return xt_fail(ctx, EXTRACK_E_INVALID, "per-peak localisation error mode but the bucket has no sigma");
-        K = b.KS;
+        if (!b0.d_sigma) return xt_fail(ctx, EXTRACK_E_INVALID, "per-peak localisation error mode but the bucket has no sigma");
+        K = b0.KS;
     }
     DevLauncher l;
     l.ctx = ctx;
@@ -465,7 +493,7 @@ static int xt_launch_bucket(extrack_ctx* ctx, const extrack_model* m, XtBucket& 
         const int tpw = 64 >> (c.F - 1);
         tpb = tpw * XT_F2_WAVES;
         threads = 64 * XT_F2_WAVES;
-        l.lds = (size_t)xt_f2_block_bytes(D, K, m->locerr_mode ? b.KS : 0, tpw);
+        l.lds = (size_t)xt_f2_block_bytes(D, K, m->locerr_mode ? b0.KS : 0, tpw);
     } else {
         xt_geometry(c, D, K, tpb, threads);
         if (threads > 1024) return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "n_states^(frame_len-nb_substeps) > 1024 groups per track is not built");
@@ -474,23 +502,27 @@ static int xt_launch_bucket(extrack_ctx* ctx, const extrack_model* m, XtBucket& 
     l.threads = threads;
     l.tracks_per_block = tpb;
     if (l.lds > 160 * 1024) return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "sequence state does not fit the 160 KiB LDS of a CU");
-    l.grid_cap = ctx->n_cu * XT_MAX_BLOCKS_PER_CU;
-    l.a.tracks = b.d_tracks;
-    l.a.sigma = m->locerr_mode ? b.d_sigma : nullptr;
+    l.desc_off = desc_off;
+    for (XtBucket* b : bks) {
+        XtBucketDesc d;
+        d.tracks = b->d_tracks;
+        d.sigma = m->locerr_mode ? b->d_sigma : nullptr;
+        d.ll_out = per_track ? b->d_ll : nullptr;
+        d.preds_out = d_preds;
+        d.N = b->N;
+        d.L = b->L;
+        d.isBL = (b->L != m->max_len) ? 1 : 0;  // tracking.py:1037-1040
+        d.ll_const = -(double)(b->L - 1) * D * 0.5 * XT_LOG2PI;
+        l.descs.push_back(d);
+    }
     l.a.blob = ctx->d_blob;
     l.a.base_tab = ctx->d_base_tab;
     l.a.off_tab = ctx->d_off_tab;
-    l.a.ll_out = d_ll;
     l.a.partials = ctx->d_partials + poff;
-    l.a.preds_out = d_preds;
-    l.a.N = b.N;
-    l.a.L = b.L;
     l.a.TPB = tpb;
-    l.a.isBL = (b.L != m->max_len) ? 1 : 0;  // tracking.py:1037-1040
     l.a.min_len = m->min_len;
     l.a.locerr_mode = m->locerr_mode;
-    l.a.KS = b.KS ? b.KS : 1;
-    l.a.ll_const = -(double)(b.L - 1) * D * 0.5 * XT_LOG2PI;
+    l.a.KS = b0.KS ? b0.KS : 1;
     const bool ok = fast2 ? xt_dispatch_f2(c.F, D, K, l)
                           : (entry ? xt_dispatch_entry(xt_entry_gp(c.G), D, K, l) : xt_dispatch(c.G, D, K, preds, l));
     if (!ok)
@@ -506,6 +538,9 @@ static int xt_launch_bucket(extrack_ctx* ctx, const extrack_model* m, XtBucket& 
     return EXTRACK_OK;
 }
 
+// Upper bound of the blocks of one launch (= partial-sum slots to reserve).
+static size_t xt_max_grid(const extrack_ctx* ctx) { return (size_t)ctx->n_cu * 8 * ctx->oversub + XT_MAX_BUCKETS; }
+
 static int xt_loglik_enqueue(extrack_ctx* ctx, const extrack_model* m, double* d_total, bool per_track)
 {
     int rc = xt_validate_model(ctx, m);
@@ -513,16 +548,32 @@ static int xt_loglik_enqueue(extrack_ctx* ctx, const extrack_model* m, double* d
     if (ctx->buckets.empty()) return xt_fail(ctx, EXTRACK_E_INVALID, "no bucket uploaded");
     XT_HIP(ctx, hipSetDevice(ctx->device));
     if ((rc = xt_prepare(ctx, m))) return rc;
-    if ((rc = xt_reserve_partials(ctx, ctx->buckets.size() * (size_t)ctx->n_cu * XT_MAX_BLOCKS_PER_CU))) return rc;
+    // launch groups: buckets with the same (dims, sigma dims), longest first, at most XT_MAX_BUCKETS per launch
+    std::vector<XtBucket*> order;
+    for (auto& b : ctx->buckets) order.push_back(&b);
+    std::stable_sort(order.begin(), order.end(), [](const XtBucket* x, const XtBucket* y) {
+        if (x->D != y->D) return x->D < y->D;
+        if (x->KS != y->KS) return x->KS < y->KS;
+        return x->L > y->L;
+    });
+    std::vector<std::vector<XtBucket*>> groups;
+    for (XtBucket* b : order) {
+        if (groups.empty() || groups.back().size() >= XT_MAX_BUCKETS || groups.back()[0]->D != b->D || groups.back()[0]->KS != b->KS)
+            groups.emplace_back();
+        groups.back().push_back(b);
+    }
+    if (order.size() > (size_t)XT_DESC_CAP) return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "too many buckets");
+    if ((rc = xt_reserve_partials(ctx, groups.size() * xt_max_grid(ctx)))) return rc;
     if (per_track)
         for (auto& b : ctx->buckets)
             if (!b.d_ll) XT_HIP(ctx, hipMalloc(&b.d_ll, (size_t)b.N * sizeof(double)));
-    size_t poff = 0;
+    size_t poff = 0, doff = 0;
     XT_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-    for (auto& b : ctx->buckets) {
+    for (auto& g : groups) {
         int grid = 0;
-        if ((rc = xt_launch_bucket(ctx, m, b, false, per_track ? b.d_ll : nullptr, nullptr, poff, &grid))) return rc;
+        if ((rc = xt_launch_group(ctx, m, g, false, per_track, nullptr, poff, doff, &grid))) return rc;
         poff += (size_t)grid;
+        doff += g.size();
     }
     XT_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     ctx->timed = true;
@@ -564,14 +615,15 @@ extern "C" int extrack_predict(extrack_ctx* ctx, const extrack_model* m, int32_t
     if (m->nb_substeps != 1) return xt_fail(ctx, EXTRACK_E_INVALID, "state predictions require nb_substeps == 1");
     XT_HIP(ctx, hipSetDevice(ctx->device));
     if ((rc = xt_prepare(ctx, m))) return rc;
-    if ((rc = xt_reserve_partials(ctx, (size_t)ctx->n_cu * XT_MAX_BLOCKS_PER_CU))) return rc;
+    if ((rc = xt_reserve_partials(ctx, xt_max_grid(ctx)))) return rc;
     XtBucket& b = ctx->buckets[bucket_id];
     const size_t nb = (size_t)b.N * b.L * m->n_states * sizeof(double);
     double* d_preds = nullptr;
     XT_HIP(ctx, hipMalloc(&d_preds, nb));
     int grid = 0;
     hipError_t e = hipEventRecord(ctx->ev0, ctx->stream);
-    rc = xt_launch_bucket(ctx, m, b, true, nullptr, d_preds, 0, &grid);
+    std::vector<XtBucket*> one(1, &b);
+    rc = xt_launch_group(ctx, m, one, true, false, d_preds, 0, 0, &grid);
     if (rc == EXTRACK_OK) {
         if (e == hipSuccess) e = hipEventRecord(ctx->ev1, ctx->stream);
         ctx->timed = true;

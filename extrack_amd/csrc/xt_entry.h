@@ -24,7 +24,9 @@ XT_HD int xt_entry_tptp(int NG, int GP)
 template <int GP, int D, int K, class Ctx>
 XT_HD void xt_entry_body(const XtKernelArgs& a, Ctx& cx)
 {
-    const int G = a.G, S = a.S, E = a.E, NG = a.NG, L = a.L;
+    int lb, nb;
+    const XtBucketDesc b = xt_bind_bucket(a, cx.block(), cx.nblocks(), lb, nb);
+    const int G = a.G, S = a.S, E = a.E, NG = a.NG, L = b.L;
     const int tid = cx.tid();
     double* smem = cx.smem();
     const int ntab = xt_tab_doubles(S, G);
@@ -57,12 +59,12 @@ XT_HD void xt_entry_body(const XtKernelArgs& a, Ctx& cx)
     const double t0q = TAB[(0 * S + prev) * G + qq], t1q = TAB[(1 * S + prev) * G + qq], d2q = TAB[(4 * S + prev) * G + qq];
 
     double block_ll = 0.0;
-    const int64_t nbatch = (a.N + a.TPB - 1) / a.TPB;
-    for (int64_t batch = cx.block(); batch < nbatch; batch += cx.nblocks()) {
+    const int64_t nbatch = (b.N + a.TPB - 1) / a.TPB;
+    for (int64_t batch = lb; batch < nbatch; batch += nb) {
         const int64_t trk = batch * a.TPB + slot;
-        const bool act = tvalid && trk < a.N;
-        const double* c = a.tracks + (act ? trk : 0) * (int64_t)L * D;
-        const double* sg = a.sigma ? a.sigma + (act ? trk : 0) * (int64_t)L * a.KS : nullptr;
+        const bool act = tvalid && trk < b.N;
+        const double* c = b.tracks + (act ? trk : 0) * (int64_t)L * D;
+        const double* sg = b.sigma ? b.sigma + (act ? trk : 0) * (int64_t)L * a.KS : nullptr;
         auto load_l2 = [&](int pos, double* l2) {
             if (a.locerr_mode == 0) {
                 for (int k = 0; k < K; ++k) l2[k] = hdr[k];
@@ -190,7 +192,7 @@ XT_HD void xt_entry_body(const XtKernelArgs& a, Ctx& cx)
             const int tl = L - 1;
             const int ph = (tl - 1) % a.P;
             const int idx = a.base_tab[ph * NG + g] + a.off_tab[ph * G + q];
-            const int vfin = (a.isBL ? 2 : 0) + (tl >= stay_from ? 1 : 0);
+            const int vfin = (b.isBL ? 2 : 0) + (tl >= stay_from ? 1 : 0);
             const double* TF = TAB + (vfin * S + prev) * G;
             const double* TD2 = TAB + (4 * S + prev) * G;
             double cl[D], l2l[K];
@@ -249,8 +251,8 @@ XT_HD void xt_entry_body(const XtKernelArgs& a, Ctx& cx)
         if (act && r == 0) {
             double sum = 0.0;
             for (int i = 0; i < TPTP / RW; ++i) sum += wsum[i];
-            const double ll = log(sum) + (double)fE * XT_LN2 + a.ll_const;
-            if (a.ll_out) a.ll_out[trk] = ll;
+            const double ll = log(sum) + (double)fE * XT_LN2 + b.ll_const;
+            if (b.ll_out) b.ll_out[trk] = ll;
             block_ll += ll;
         }
         cx.sync();

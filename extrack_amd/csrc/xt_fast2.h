@@ -207,12 +207,14 @@ XT_HD void xt_f2_step(char* lds, const XtF2State<F, D, K>& st, const double* c, 
 template <int F, int D, int K, class Ctx>
 XT_HD void xt_ll_s2_body(const XtKernelArgs& a, Ctx& cx)
 {
+    int lb, nb;
+    const XtBucketDesc b = xt_bind_bucket(a, cx.block(), cx.nblocks(), lb, nb);
     typedef XtF2Geom<F> Gm;
     constexpr int E = Gm::E, NG = Gm::NG, TPW = Gm::TPW;
     const int lane = cx.lane();
     const int wib = cx.wave_in_block();
     const int nwb = cx.waves_per_block();
-    const int L = a.L;
+    const int L = b.L;
     const int KS = a.locerr_mode ? a.KS : 0;
     double* smem = cx.smem();
     char* lds = (char*)smem;
@@ -231,7 +233,7 @@ XT_HD void xt_ll_s2_body(const XtKernelArgs& a, Ctx& cx)
     double T0[2], T1[2], TD2[2], TFIN[2];
     const int tlast = L - 1;
     const int stay_from = a.min_len > 2 ? a.min_len : 2;
-    const int vfin = (a.isBL ? 2 : 0) + (tlast >= stay_from ? 1 : 0);
+    const int vfin = (b.isBL ? 2 : 0) + (tlast >= stay_from ? 1 : 0);
     for (int q = 0; q < 2; ++q) {
         T0[q] = TAB[(0 * 2 + prev) * 2 + q];
         T1[q] = TAB[(1 * 2 + prev) * 2 + q];
@@ -259,20 +261,20 @@ XT_HD void xt_ll_s2_body(const XtKernelArgs& a, Ctx& cx)
     // running product of the tracks' likelihoods for this lane's track slot (identical in its NG lanes)
     double accm = 1.0, acce = 0.0, ntr = 0.0;
 
-    const int64_t nbatch = (a.N + TPW - 1) / TPW;
-    const int64_t W0 = (int64_t)cx.block() * nwb + wib, NW = (int64_t)cx.nblocks() * nwb;
+    const int64_t nbatch = (b.N + TPW - 1) / TPW;
+    const int64_t W0 = (int64_t)lb * nwb + wib, NW = (int64_t)nb * nwb;
     for (int64_t batch = W0; batch < nbatch; batch += NW) {
         const int64_t trk = batch * TPW + ts;
-        const bool act = trk < a.N;
+        const bool act = trk < b.N;
 
         auto stage = [&](int p0) {  // positions [p0, p0 + CHUNK) of the wave's TPW tracks -> LDS (coalesced along the track)
             for (int i = lane; i < TPW * XT_F2_CHUNK * D; i += 64) {
                 const int t_ = i / (XT_F2_CHUNK * D), r = i - t_ * (XT_F2_CHUNK * D);
                 const int64_t tk = batch * TPW + t_;
-                const int64_t tkc = tk < a.N ? tk : a.N - 1;
+                const int64_t tkc = tk < b.N ? tk : b.N - 1;
                 const int pp = p0 + r / D;
                 if (pp < L) {
-                    const double v = a.tracks[(tkc * L + p0) * D + r];
+                    const double v = b.tracks[(tkc * L + p0) * D + r];
                     pos[i] = v;
                     if (v != v) xt_at<int>(lds, XT_F2_NAN_OFF + (wib * 8 + t_) * 4) = 1;
                 }
@@ -281,10 +283,10 @@ XT_HD void xt_ll_s2_body(const XtKernelArgs& a, Ctx& cx)
                 for (int i = lane; i < TPW * XT_F2_CHUNK * KS; i += 64) {
                     const int t_ = i / (XT_F2_CHUNK * KS), r = i - t_ * (XT_F2_CHUNK * KS);
                     const int64_t tk = batch * TPW + t_;
-                    const int64_t tkc = tk < a.N ? tk : a.N - 1;
+                    const int64_t tkc = tk < b.N ? tk : b.N - 1;
                     const int pp = p0 + r / KS;
                     if (pp < L) {
-                        const double v = a.sigma[(tkc * L + p0) * KS + r];
+                        const double v = b.sigma[(tkc * L + p0) * KS + r];
                         sig[i] = v;
                         if (v != v) xt_at<int>(lds, XT_F2_NAN_OFF + (wib * 8 + t_) * 4) = 1;
                     }
@@ -408,7 +410,7 @@ XT_HD void xt_ll_s2_body(const XtKernelArgs& a, Ctx& cx)
         for (int m = 1; m < NG; m <<= 1) sum += cx.shfl_xor_f64(sum, m);
         if (xt_at<int>(lds, XT_F2_NAN_OFF + (wib * 8 + ts) * 4)) sum = NAN;  // NaN input -> NaN likelihood, as in the reference
         if (act) {
-            if (a.ll_out && g == 0) a.ll_out[trk] = log(sum) + (double)fe * XT_LN2 + a.ll_const;
+            if (b.ll_out && g == 0) b.ll_out[trk] = log(sum) + (double)fe * XT_LN2 + b.ll_const;
             const double pm = accm * xt_frexp_mant(sum);
             acce += (double)(fe + xt_frexp_exp(sum) + xt_frexp_exp(pm));
             accm = xt_frexp_mant(pm);
@@ -420,7 +422,7 @@ XT_HD void xt_ll_s2_body(const XtKernelArgs& a, Ctx& cx)
 
     // ---- per-slot log-likelihood sums -> block partial (fixed order)
     cx.sync();
-    if (g == 0) smem[wib * TPW + ts] = ntr > 0.0 ? log(accm) + acce * XT_LN2 + ntr * a.ll_const : 0.0;
+    if (g == 0) smem[wib * TPW + ts] = ntr > 0.0 ? log(accm) + acce * XT_LN2 + ntr * b.ll_const : 0.0;
     cx.sync();
     if (cx.tid() == 0) {
         double s = 0.0;

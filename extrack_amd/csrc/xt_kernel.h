@@ -31,7 +31,24 @@
 #define XT_BLOB_HDR 16  // doubles: [0..2] l2 (global loc. error^2 per dim), [3] slope, [4] offset, [8..15] Fs
 #define XT_NTAB 5       // tables [v][prev][q]: 0 T, 1 T*stay, 2 T*Eend, 3 T*stay*Eend, 4 d2
 
+#define XT_MAX_BUCKETS 64  // length buckets served by one launch
+
+// One length bucket as seen by a launch that serves several buckets at once: the blocks [blk_end[i-1], blk_end[i]) of the
+// grid work on bucket i (XtKernelArgs::blk_end), striding over its track batches.
+struct XtBucketDesc {
+    const double* tracks;  // [N][L][D]
+    const double* sigma;   // [N][L][KS] or nullptr
+    double* ll_out;        // [N] or nullptr
+    double* preds_out;     // [N][L][S] or nullptr
+    int64_t N;
+    int32_t L, isBL;
+    double ll_const;       // -(L-1)*D/2*log(2*pi)
+};
+
 struct XtKernelArgs {
+    const XtBucketDesc* desc; // device array [ndesc], or nullptr: single bucket described by the fields below
+    int32_t ndesc;
+    int32_t blk_end[XT_MAX_BUCKETS];  // exclusive prefix of blocks per bucket
     const double* tracks;     // [N][L][D] device
     const double* sigma;      // [N][L][KS] per-peak localisation error (std) or nullptr
     const double* blob;       // model blob, XT_BLOB_HDR + XT_NTAB*S*G doubles
@@ -58,16 +75,47 @@ XT_HD int xt_pred_doubles(int S, int F) { return 2 * (S + 1) + (F + 1) * S + 2; 
 #define XT_STAGE 32  // positions of a track staged in LDS per refill (coalesced loads instead of a dependent global load per step)
 XT_HD int xt_stage_doubles(int D) { return XT_STAGE * (D + XT_MAX_DIMS); }
 
-template <int K, int D>
-struct XtL2 {
-    double v[K];
-};
+// Resolves which bucket this block serves: returns its descriptor by value (registers), the block's index inside the
+// bucket (lb) and the number of blocks serving the bucket (nb).  The kernel arguments stay in the constant kernarg segment.
+XT_HD XtBucketDesc xt_bind_bucket(const XtKernelArgs& a, int block, int nblocks, int& lb, int& nb)
+{
+    XtBucketDesc d;
+    if (a.desc == nullptr) {
+        d.tracks = a.tracks;
+        d.sigma = a.sigma;
+        d.ll_out = a.ll_out;
+        d.preds_out = a.preds_out;
+        d.N = a.N;
+        d.L = a.L;
+        d.isBL = a.isBL;
+        d.ll_const = a.ll_const;
+        lb = block;
+        nb = nblocks;
+        return d;
+    }
+    int i = 0, lo = 0, hi = a.blk_end[0];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int j = 0; j < XT_MAX_BUCKETS - 1; ++j) {
+        const bool past = j < a.ndesc - 1 && block >= a.blk_end[j];
+        i = past ? j + 1 : i;
+        lo = past ? a.blk_end[j] : lo;
+        hi = past ? a.blk_end[j + 1] : hi;
+    }
+    d = a.desc[i];
+    lb = block - lo;
+    nb = hi - lo;
+    return d;
+}
 
 template <int G_, int D, int K, bool PREDS, class Ctx>
 XT_HD void xt_track_body(const XtKernelArgs& a, Ctx& cx)
 {
+    int lb, nb;
+    const XtBucketDesc b = xt_bind_bucket(a, cx.block(), cx.nblocks(), lb, nb);
     const int G = G_ ? G_ : a.G;
-    const int S = a.S, E = a.E, NG = a.NG, L = a.L, F = a.F;
+    const int S = a.S, E = a.E, NG = a.NG, L = b.L, F = a.F;
     const int tid = cx.tid();
     double* smem = cx.smem();
 
@@ -103,7 +151,7 @@ XT_HD void xt_track_body(const XtKernelArgs& a, Ctx& cx)
     const int stay_from = a.min_len > 2 ? a.min_len : 2;
 
     double block_ll = 0.0;  // meaningful in thread g == 0 of each slot
-    const int64_t nbatch = (a.N + a.TPB - 1) / a.TPB;
+    const int64_t nbatch = (b.N + a.TPB - 1) / a.TPB;
     if (tvalid && g == 0) red_e[1] = 0;
     cx.sync();
     // compile-time group size: the table rows of this thread's (constant) newest old digit live in registers
@@ -115,11 +163,11 @@ XT_HD void xt_track_body(const XtKernelArgs& a, Ctx& cx)
             D2r[q] = TD2[q];
         }
 
-    for (int64_t batch = cx.block(); batch < nbatch; batch += cx.nblocks()) {
+    for (int64_t batch = lb; batch < nbatch; batch += nb) {
         const int64_t trk = batch * a.TPB + slot;
-        const bool act = tvalid && trk < a.N;
-        const double* c = a.tracks + (act ? trk : 0) * (int64_t)L * D;
-        const double* sg = a.sigma ? a.sigma + (act ? trk : 0) * (int64_t)L * a.KS : nullptr;
+        const bool act = tvalid && trk < b.N;
+        const double* c = b.tracks + (act ? trk : 0) * (int64_t)L * D;
+        const double* sg = b.sigma ? b.sigma + (act ? trk : 0) * (int64_t)L * a.KS : nullptr;
 
         // positions [p0, p0 + XT_STAGE) of this track -> LDS, by the track's own threads (coalesced along the track)
         auto stage = [&](int p0) {
@@ -315,7 +363,7 @@ XT_HD void xt_track_body(const XtKernelArgs& a, Ctx& cx)
                 if (act && g < S) {
                     double tot = 0.0;
                     for (int s = 0; s < S; ++s) tot += pacc[par * S + s];
-                    a.preds_out[(trk * L + (t - F)) * S + g] = pacc[par * S + g] / tot;
+                    b.preds_out[(trk * L + (t - F)) * S + g] = pacc[par * S + g] / tot;
                 }
             }
         }
@@ -330,7 +378,7 @@ XT_HD void xt_track_body(const XtKernelArgs& a, Ctx& cx)
             const int ph = (tl - 1) % a.P;
             const int base = a.base_tab[ph * NG + g];
             const int32_t* off = a.off_tab + ph * G;
-            const int vfin = (a.isBL ? 2 : 0) + (tl >= stay_from ? 1 : 0);
+            const int vfin = (b.isBL ? 2 : 0) + (tl >= stay_from ? 1 : 0);
             const double* TF = TAB + (vfin * S + prev) * G;
             double cl[D], l2l[K];
             for (int d = 0; d < D; ++d) cl[d] = spos[(tl & (XT_STAGE - 1)) * D + d];
@@ -405,8 +453,8 @@ XT_HD void xt_track_body(const XtKernelArgs& a, Ctx& cx)
         if (act && g == 0) {
             double sum = 0.0;
             for (int i = 0; i < NG; ++i) sum += zm[i];
-            const double ll = poisoned ? NAN : log(sum) + (double)fe * XT_LN2 + a.ll_const;
-            if (a.ll_out) a.ll_out[trk] = ll;
+            const double ll = poisoned ? NAN : log(sum) + (double)fe * XT_LN2 + b.ll_const;
+            if (b.ll_out) b.ll_out[trk] = ll;
             block_ll += ll;
         }
         if (PREDS && act) {
@@ -415,10 +463,10 @@ XT_HD void xt_track_body(const XtKernelArgs& a, Ctx& cx)
                 const int j = i / S;
                 double tots = 0.0;
                 for (int s = 0; s < S; ++s) tots += facc[j * S + s];
-                a.preds_out[(trk * L + (L - 1 - j)) * S + (i - j * S)] = facc[i] / tots;
+                b.preds_out[(trk * L + (L - 1 - j)) * S + (i - j * S)] = facc[i] / tots;
             }
             if (poisoned)
-                for (int i = g; i < L * S; i += NG) a.preds_out[trk * L * S + i] = NAN;
+                for (int i = g; i < L * S; i += NG) b.preds_out[trk * L * S + i] = NAN;
         }
         cx.sync();  // scratch (zm) and accumulators are re-initialised by the next batch
         if (act && g == 0) red_e[1] = 0;

@@ -211,3 +211,68 @@ extern "C" int xt_emul_run(const double* tracks, const double* sigma, long long 
     if (total) *total = s;
     return 0;
 }
+
+
+// Several length buckets served by ONE emulated launch through the bucket-descriptor table (the product's launch mode).
+extern "C" int xt_emul_run_multi(int nbuckets, const double** tracks, const long long* Ns, const int* Ls, int D, int S, int NS, int F,
+                                 int max_len, int min_len, int locerr_dims, const double* locerr, double pBL, const double* ds,
+                                 const double* Fs, const double* TrMat, const double* p_stay, const int* blocks_per_bucket,
+                                 double** ll_out, double* total)
+{
+    if (nbuckets < 1 || nbuckets > XT_MAX_BUCKETS) return -4;
+    XtConfig cfg;
+    if (!xt_build_config(S, NS, F, cfg).empty()) return -1;
+    XtModelHost m{S, NS, locerr_dims, {0, 0, 0}, 0.0, 0.0, pBL, ds, Fs, TrMat, p_stay};
+    for (int k = 0; k < 3; ++k) m.locerr[k] = locerr[k < locerr_dims ? k : 0];
+    std::vector<double> blob;
+    xt_build_blob(m, cfg, blob);
+    const int K = locerr_dims;
+    EmulLauncher l;
+    memset(&l.a, 0, sizeof(l.a));
+    xt_fill_args_from_config(cfg, l.a);
+    std::vector<XtBucketDesc> descs(nbuckets);
+    int acc = 0;
+    for (int i = 0; i < nbuckets; ++i) {
+        descs[i] = XtBucketDesc{tracks[i], nullptr, ll_out ? ll_out[i] : nullptr, nullptr, Ns[i], Ls[i], Ls[i] != max_len ? 1 : 0,
+                                -(double)(Ls[i] - 1) * D * 0.5 * XT_LOG2PI};
+        acc += blocks_per_bucket[i];
+        l.a.blk_end[i] = acc;
+    }
+    l.a.desc = descs.data();
+    l.a.ndesc = nbuckets;
+    l.nblocks = acc;
+    std::vector<double> partials(acc, 0.0);
+    l.a.blob = blob.data();
+    l.a.base_tab = cfg.base_tab.data();
+    l.a.off_tab = cfg.off_tab.data();
+    l.a.partials = partials.data();
+    l.a.min_len = min_len;
+    l.a.locerr_mode = 0;
+    l.a.KS = 1;
+    bool ok;
+    if (xt_use_fast2(S, NS, F, false)) {
+        l.threads = 64 * XT_F2_WAVES;
+        l.lds_bytes = (size_t)xt_f2_block_bytes(D, K, 0, 64 >> (F - 1));
+        ok = xt_dispatch_f2(F, D, K, l);
+    } else if (xt_use_entry(NS, cfg.G, cfg.NG, false)) {
+        int tpb2, thr2;
+        size_t lds2;
+        xt_entry_geometry(S, cfg.G, cfg.E, cfg.NG, D, K, tpb2, thr2, lds2);
+        l.threads = thr2;
+        l.a.TPB = tpb2;
+        l.lds_bytes = lds2;
+        ok = xt_dispatch_entry(xt_entry_gp(cfg.G), D, K, l);
+    } else {
+        int tpb, threads;
+        xt_geometry(cfg, D, K, tpb, threads);
+        l.threads = threads;
+        l.a.TPB = tpb;
+        l.lds_bytes = xt_lds_bytes(cfg, D, K, tpb);
+        ok = xt_dispatch(cfg.G, D, K, false, l);
+    }
+    if (!ok) return -3;
+    double s = 0.0;
+    for (double p : partials) s += p;
+    if (total) *total = s;
+    return 0;
+}

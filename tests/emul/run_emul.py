@@ -49,3 +49,28 @@ def run(Cs, LE, ds, Fs, T, pBL, isBL, p_stay, ns, F, min_len, preds=False, nbloc
     if rc != 0:
         raise RuntimeError("emul rc=%d" % rc)
     return ll, pr, tot.value, list(info)
+
+
+def run_multi(buckets, locerr, ds, Fs, T, pBL, p_stay, ns, F, min_len, max_len, blocks_per_bucket):
+    """buckets: list of arrays [N, L, D]; one emulated launch over all of them.  Returns (per-track lists, total)."""
+    nb = len(buckets)
+    bk = [np.ascontiguousarray(b, float) for b in buckets]
+    D = bk[0].shape[2]
+    S = len(ds)
+    le = np.zeros(3)
+    locerr = np.atleast_1d(np.asarray(locerr, float)).ravel()
+    le[:len(locerr)] = locerr
+    outs = [np.zeros(len(b)) for b in bk]
+    PD = C.POINTER(C.c_double)
+    tr = (PD * nb)(*[dp(b) for b in bk])
+    lo = (PD * nb)(*[dp(o) for o in outs])
+    Ns = (C.c_longlong * nb)(*[len(b) for b in bk])
+    Ls = (C.c_int * nb)(*[b.shape[1] for b in bk])
+    bp = (C.c_int * nb)(*blocks_per_bucket)
+    tot = C.c_double(0)
+    ds, Fs, T, p_stay = [np.ascontiguousarray(x, float) for x in (ds, Fs, T, p_stay)]
+    rc = lib().xt_emul_run_multi(nb, tr, Ns, Ls, D, S, ns, F, int(max_len), int(min_len), len(locerr), dp(le), C.c_double(pBL), dp(ds),
+                                 dp(Fs), dp(T), dp(p_stay), bp, lo, C.byref(tot))
+    if rc != 0:
+        raise RuntimeError("emul multi rc=%d" % rc)
+    return outs, tot.value

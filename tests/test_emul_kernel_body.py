@@ -115,3 +115,27 @@ def test_entry_parallel_body_on_multi_substep_cases(kernel_cases, monkeypatch):
         assert abs(tot - ll.sum()) < 1e-9
         n += 1
     assert n > 60 and worst < 1e-10, (n, worst)
+
+
+@pytest.mark.parametrize("S,ns,F", [(2, 1, 6), (3, 1, 3), (2, 2, 3)])
+def test_multi_bucket_single_launch(S, ns, F, monkeypatch):
+    """Several length buckets served by ONE launch through the bucket-descriptor table (all three kernel bodies): every
+    block must pick its own bucket's length, isBL flag and track range."""
+    monkeypatch.delenv("XT_EMUL_GENERIC", raising=False)
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "emul"))
+    import run_emul as E
+    rng = np.random.default_rng(S * 10 + F)
+    ds = np.sort(rng.uniform(0.01, 0.15, S))
+    Fs = np.full(S, 1 / S)
+    T = np.full((S, S), 0.08)
+    T[np.arange(S), np.arange(S)] = 1 - 0.08 * (S - 1)
+    lens = {2: 3, 5: 11, 9: 7, 12: 5}
+    buckets = [np.cumsum(rng.normal(0, 0.05, (n, L, 2)), 1) for L, n in lens.items()]
+    ps = O.p_stay_table(ds, S, ns, [1.0])
+    LE = np.array([[[0.02]]])
+    ref = [O.proba_cs(b, LE, ds, Fs, T, 0.1, 0 if b.shape[1] == 12 else 1, [1.0], ns, F, 2) for b in buckets]
+    outs, tot = E.run_multi(buckets, [0.02], ds, Fs, T, 0.1, ps, ns, F, 2, 12, [1, 3, 2, 2])
+    for o, r in zip(outs, ref):
+        assert np.abs(o - r).max() < 1e-10
+    assert abs(tot - sum(r.sum() for r in ref)) < 1e-9
