@@ -33,6 +33,7 @@ XT_HD void xt_entry_body(const XtKernelArgs& a, Ctx& cx)
     for (int i = tid; i < ntab; i += cx.nthreads()) smem[i] = a.blob[i];
     const double* hdr = smem;
     const double* TAB = smem + XT_BLOB_HDR;
+    const double* T64 = TAB + XT_NTAB * S * G;
 
     const int TPT = NG * GP;               // threads that own a (group, member) pair
     const int TPTP = xt_entry_tptp(NG, GP);  // threads reserved per track: TPT padded so tracks never straddle a reduction
@@ -169,16 +170,11 @@ XT_HD void xt_entry_body(const XtKernelArgs& a, Ctx& cx)
                     gf = sqrt(gf);
                 }
                 double p;
-                int n;
-                xt_exp_split(-quad, p, n);
-                double zn = Wm * (t >= stay_from ? t1q : t0q) * gf * p;
-                int en = We + n;
-                if (zn == 0.0 || en <= XT_EMIN) {
-                    zn = 0.0;
-                    en = XT_EMIN;
-                }
-                zm[idx] = zn;
-                ze[idx] = en;
+                int j, n;
+                xt_exp_tab(-quad, p, j, n);
+                const int en = We + n;
+                zm[idx] = (Wm * (t >= stay_from ? t1q : t0q)) * (gf * T64[j]) * p;
+                ze[idx] = en > XT_EMIN ? en : XT_EMIN;
                 for (int d = 0; d < D; ++d) mm[d * E + idx] = xt_fma(dm[d], tt[K == 1 ? 0 : d], M[d]);
                 for (int k = 0; k < K; ++k) uu[k * E + idx] = l2t[k] * tt[k];
             }
@@ -228,9 +224,9 @@ XT_HD void xt_entry_body(const XtKernelArgs& a, Ctx& cx)
                         gf = sqrt(gf);
                     }
                     double p;
-                    int n;
-                    xt_exp_split(-quad, p, n);
-                    tot.add(zq * TF[j] * gf * p, eq + n);
+                    int jj, n;
+                    xt_exp_tab(-quad, p, jj, n);
+                    tot.add(zq * TF[j] * (gf * T64[jj]) * p, eq + n);
                 }
             }
         }

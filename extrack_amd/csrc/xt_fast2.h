@@ -92,8 +92,8 @@ struct XtF2State {
 
 // Fixed LDS map of the fast path (bytes).  One array per field over all waves of the block, so that a field is reached
 // from the zm address by a compile-time offset and ze (4-byte elements) by (a >> 1) + constant.
-#define XT_F2_TAB_BYTES 1024                                   /* model tables (288 B) + T64 exp table (512 B) */
-#define XT_F2_T64_OFF 320
+#define XT_F2_TAB_BYTES 1024                                   /* model blob: tables (288 B) + T64 exp table (512 B) */
+#define XT_F2_T64_OFF ((XT_BLOB_HDR + XT_NTAB * 4) * 8)   /* the blob's T64 table (xt_tables.h) */
 #define XT_F2_NAN_OFF 832                                      /* int[XT_F2_WAVES][8]: track has a NaN position / sigma */
 #define XT_F2_ARR (XT_F2_WAVES * 128 * 8)                      /* bytes of one double field for all waves */
 #define XT_F2_ZM0 XT_F2_TAB_BYTES
@@ -222,7 +222,6 @@ XT_HD void xt_ll_s2_body(const XtKernelArgs& a, Ctx& cx)
     // block-shared model tables + the 2^(j/64) table of the exponential
     const int ntab = xt_tab_doubles(2, 2);
     for (int i = cx.tid(); i < ntab; i += cx.nthreads()) smem[i] = a.blob[i];
-    if (cx.tid() < 64) xt_at<double>(lds, XT_F2_T64_OFF + cx.tid() * 8) = exp2((double)cx.tid() * (1.0 / 64.0));
     cx.sync();
     const double* hdr = smem;
     const double* TAB = smem + XT_BLOB_HDR;

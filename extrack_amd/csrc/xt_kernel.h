@@ -69,7 +69,7 @@ struct XtKernelArgs {
 };
 
 // LDS footprint in doubles.  Layout: [tables][per-track regions x TPB][pred accumulators x TPB]
-XT_HD int xt_tab_doubles(int S, int G) { return XT_BLOB_HDR + XT_NTAB * S * G; }
+XT_HD int xt_tab_doubles(int S, int G) { return XT_BLOB_HDR + XT_NTAB * S * G + 64; }  // + T64[j] = 2^(j/64)
 XT_HD int xt_region_doubles(int E, int D, int K) { return E * (1 + D + K) + (E + 1) / 2 + 2; }
 XT_HD int xt_pred_doubles(int S, int F) { return 2 * (S + 1) + (F + 1) * S + 2; }
 #define XT_STAGE 32  // positions of a track staged in LDS per refill (coalesced loads instead of a dependent global load per step)
@@ -124,7 +124,7 @@ XT_HD void xt_track_body(const XtKernelArgs& a, Ctx& cx)
     for (int i = tid; i < ntab; i += cx.nthreads()) smem[i] = a.blob[i];
     const double* hdr = smem;
     const double* TAB = smem + XT_BLOB_HDR;
-    const int SG = S * G;
+    const double* T64 = TAB + XT_NTAB * S * G;
 
     const int slot = tid / NG;
     const int g = tid - slot * NG;
@@ -292,9 +292,9 @@ XT_HD void xt_track_body(const XtKernelArgs& a, Ctx& cx)
                                     }
                                 }
                                 double p;
-                                int n;
-                                xt_exp_split(-quad, p, n);
-                                pq[Q].add(zq * TT(q) * gf * p, ze[idx] + n);
+                                int j, n;
+                                xt_exp_tab(-quad, p, j, n);
+                                pq[Q].add(zq * TT(q) * (gf * T64[j]) * p, ze[idx] + n);
                             }
                         }
                         pemax = pq[Q].e > pemax ? pq[Q].e : pemax;
@@ -336,16 +336,11 @@ XT_HD void xt_track_body(const XtKernelArgs& a, Ctx& cx)
                         gf = sqrt(gf);
                     }
                     double p;
-                    int n;
-                    xt_exp_split(-quad, p, n);
-                    double zn = Wm * TT(q) * gf * p;
-                    int en = We + n;
-                    if (zn == 0.0 || en <= XT_EMIN) {
-                        zn = 0.0;
-                        en = XT_EMIN;
-                    }
-                    zm[idx] = zn;
-                    ze[idx] = en;
+                    int j, n;
+                    xt_exp_tab(-quad, p, j, n);
+                    const int en = We + n;
+                    zm[idx] = (Wm * TT(q)) * (gf * T64[j]) * p;  // Wm == 0 for an all-zero group, whose We is XT_EMIN
+                    ze[idx] = en > XT_EMIN ? en : XT_EMIN;
                     for (int d = 0; d < D; ++d) mm[d * E + idx] = xt_fma(dm[d], tt[K == 1 ? 0 : d], mb[d]);
                     for (int k = 0; k < K; ++k) uu[k * E + idx] = l2t[k] * tt[k];
                 }
@@ -416,9 +411,9 @@ XT_HD void xt_track_body(const XtKernelArgs& a, Ctx& cx)
                         gf = sqrt(gf);
                     }
                     double p;
-                    int n;
-                    xt_exp_split(-quad, p, n);
-                    const double wm = zq * TF[q] * gf * p;
+                    int j, n;
+                    xt_exp_tab(-quad, p, j, n);
+                    const double wm = zq * TF[q] * (gf * T64[j]) * p;
                     const int we = eq + n;
                     tot.add(wm, we);
                     if (PREDS) {

@@ -4,8 +4,8 @@
 //     value = m * 2^e        (m: double mantissa, not necessarily normalised; e: int32)
 // instead of the reference's log domain (extrack/tracking.py:109-318 keeps log-probabilities and
 // pays one exp per sequence and one log per fused sequence per step).  The only transcendental
-// left per (sequence, step) is the exponential of the Gaussian quadratic form, whose power-of-two
-// part goes straight into the integer exponent, so nothing under- or overflows.
+// left per (sequence, step) is the exponential of the Gaussian quadratic form (xt_exp_tab), whose
+// power-of-two part goes straight into the integer exponent, so nothing under- or overflows.
 //
 // Every function is usable from host code too: tests/emul runs the very same kernel body on CPU
 // threads (test infrastructure only; the product never does).
@@ -20,7 +20,6 @@
 #endif
 
 #define XT_EMIN (-(1 << 30))          // exponent of an exactly-zero weight
-#define XT_XCLAMP (-1.0e8)            // exp argument clamp: keeps e within int32 for >10 such steps
 #define XT_LN2 0.693147180559945309417232121458
 #define XT_LOG2PI 1.83787706640934548356065947281
 
@@ -59,29 +58,24 @@ XT_HD double xt_rint(double x) { return nearbyint(x); }
 
 XT_HD double xt_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 
-// exp(x) for x <= 0, returned as p * 2^n with p in [0.70, 1.42].  |rel err| < 3e-16.
-XT_HD void xt_exp_split(double x, double& p, int& n)
+// exp(x), x <= 0, table-driven: x = (64 e + j) ln2/64 + r, |r| <= ln2/128, exp(x) = 2^e * T64[j] * p with p = P5(r).
+// T64[j] = 2^(j/64) is part of the model blob (xt_tables.h).  |rel err| < 3e-16.  A NaN argument stays NaN.
+#define XT_TCLAMP (-3.0e7)  // keeps 64 x / ln2 inside int32
+XT_HD void xt_exp_tab(double x, double& p, int& j, int& e)
 {
-    x = x < XT_XCLAMP ? XT_XCLAMP : x;
-    const double kf = xt_rint(x * 1.44269504088896338700e+00);
-    double r = xt_fma(kf, -6.93147180369123816490e-01, x);  // ln2 hi (low 21 bits zero: kf*hi exact)
-    r = xt_fma(kf, -1.90821492927058770002e-10, r);         // ln2 lo
-    // Taylor/Horner degree 13 on |r| <= 0.3466 (truncation 4e-18)
-    double q = 1.6059043836821613e-10;            // 1/13!
-    q = xt_fma(q, r, 2.08767569878680989792e-09);  // 1/12!
-    q = xt_fma(q, r, 2.50521083854417187751e-08);  // 1/11!
-    q = xt_fma(q, r, 2.75573192239858906526e-07);  // 1/10!
-    q = xt_fma(q, r, 2.75573192239858906526e-06);  // 1/9!
-    q = xt_fma(q, r, 2.48015873015873015873e-05);  // 1/8!
-    q = xt_fma(q, r, 1.98412698412698412698e-04);  // 1/7!
-    q = xt_fma(q, r, 1.38888888888888888889e-03);  // 1/6!
-    q = xt_fma(q, r, 8.33333333333333333333e-03);  // 1/5!
-    q = xt_fma(q, r, 4.16666666666666666667e-02);  // 1/4!
-    q = xt_fma(q, r, 1.66666666666666666667e-01);  // 1/3!
+    x = x < XT_TCLAMP ? XT_TCLAMP : x;
+    const double kf = xt_rint(x * 92.33248261689366);
+    double r = xt_fma(kf, -0.010830424493178725, x);
+    r = xt_fma(kf, -2.030704202170295e-10, r);
+    double q = 8.33333333333333333333e-03;
+    q = xt_fma(q, r, 4.16666666666666666667e-02);
+    q = xt_fma(q, r, 1.66666666666666666667e-01);
     q = xt_fma(q, r, 0.5);
     q = xt_fma(q, r, 1.0);
     p = xt_fma(q, r, 1.0);
-    n = (int)kf;
+    const int n = (int)kf;
+    j = n & 63;
+    e = n >> 6;
 }
 
 // den^(-D/2) for a scalar variance (K == 1) given r = 1/den.

@@ -83,7 +83,8 @@ struct XtModelHost {
 static inline void xt_build_blob(const XtModelHost& m, const XtConfig& c, std::vector<double>& blob)
 {
     const int S = c.S, NS = c.NS, G = c.G;
-    blob.assign((size_t)XT_BLOB_HDR + (size_t)XT_NTAB * S * G, 0.0);
+    blob.assign((size_t)xt_tab_doubles(S, G), 0.0);
+    for (int j = 0; j < 64; ++j) blob[(size_t)XT_BLOB_HDR + (size_t)XT_NTAB * S * G + j] = exp2((double)j / 64.0);
     for (int k = 0; k < 3; ++k) {
         const double s = m.locerr[k < m.locerr_dims ? k : 0];
         blob[k] = s * s;

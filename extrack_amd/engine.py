@@ -10,7 +10,22 @@ from scipy.special import ndtr
 from . import _lib
 
 
+_P_STAY_CACHE = {}
+
+
 def p_stay_table(ds, nb_states, nb_substeps, cell_dims):
+    """Cached front of ``_p_stay_table``: during a fit most evaluations (finite-difference steps on the non-diffusion
+    parameters) repeat the same diffusion lengths."""
+    key = (tuple(np.asarray(ds, float).tolist()), int(nb_states), int(nb_substeps), tuple(float(c) for c in cell_dims))
+    hit = _P_STAY_CACHE.get(key)
+    if hit is None:
+        if len(_P_STAY_CACHE) > 256:
+            _P_STAY_CACHE.clear()
+        hit = _P_STAY_CACHE[key] = _p_stay_table(ds, nb_states, nb_substeps, cell_dims)
+    return hit
+
+
+def _p_stay_table(ds, nb_states, nb_substeps, cell_dims):
     """Probability of staying in the field of view for each of the S**ns newest sub-sequences.
 
     Same quadrature as the reference (extrack/tracking.py:182-191): mean over a 1000-point grid of
