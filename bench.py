@@ -105,6 +105,7 @@ def main():
         os.environ.setdefault("RANK", str(rank))
         os.environ.setdefault("WORLD_SIZE", str(world))
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")  # one node: the bootstrap never needs an external interface
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         from extrack_amd.distributed import Comm
         comm = Comm()
@@ -158,8 +159,9 @@ def main():
         except Exception:
             traffic = None
     # secondary (honest) bound: fp64 vector issue.  Flop count per track-step from the kernel's ISA:
-    # 48 FMA + 49 other fp64 ops per wave-step of 2 tracks -> 145 flop x 64 lanes / 2 tracks.
-    flop_per_eval = a.tracks * (LEN - 1) * 4640.0
+    # 34 FMA + 50 other fp64 instructions per wave-step of 2 tracks -> 118 flop x 64 lanes / 2 tracks = 3776 flop.
+    flop_per_eval = a.tracks * (LEN - 1) * 3776.0
+    valu_issue_cycles = a.tracks / 2 * (LEN - 1) * (84 * 4 + 37 * 2)   # fp64 ops issue in 4 cycles/wave, 32-bit ops in >= 2
     tflops = flop_per_eval / (k_ms * 1e-3) / 1e12
     out = {
         "metric": "log-likelihood evals/sec (1e6 tracks, 2-state, len=30)", "value": evals_per_s, "unit": "1e6-track LL evals/s",
@@ -172,7 +174,8 @@ def main():
                      "traffic": traffic, "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes,
                      "note": "the recursion is FP64-VALU bound, not HBM bound (arithmetic intensity ~300 flop/B, DESIGN.md)",
                      "fp64_valu": {"achieved": tflops, "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s", "frac": tflops / FP64_VALU_PEAK_TF,
-                                   "flop_per_launch": flop_per_eval}},
+                                   "flop_per_launch": flop_per_eval,
+                                   "valu_issue_floor_ms": valu_issue_cycles / (256 * 4) / 2.4e9 * 1e3}},
         "neg_loglik": -val,
     }
     if not a.no_cpu_baseline and world == 1:

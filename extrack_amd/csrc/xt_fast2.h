@@ -59,8 +59,10 @@ XT_HD void xt_exp_tab_x2(double x0, double x1, double& p0, double& p1, int& j0, 
 {
     x0 = x0 > XT_F2_XCLAMP ? x0 : XT_F2_XCLAMP;
     x1 = x1 > XT_F2_XCLAMP ? x1 : XT_F2_XCLAMP;
-    const double k0 = xt_rint(x0 * 92.33248261689366);
-    const double k1 = xt_rint(x1 * 92.33248261689366);
+    const double t0 = xt_fma(x0, 92.33248261689366, XT_MAGIC);  // integer part in the low 32 bits (xt_math.h)
+    const double t1 = xt_fma(x1, 92.33248261689366, XT_MAGIC);
+    const double k0 = t0 - XT_MAGIC;
+    const double k1 = t1 - XT_MAGIC;
     double r0 = xt_fma(k0, -0.010830424493178725, x0);
     double r1 = xt_fma(k1, -0.010830424493178725, x1);
     r0 = xt_fma(k0, -2.030704202170295e-10, r0);
@@ -77,7 +79,7 @@ XT_HD void xt_exp_tab_x2(double x0, double x1, double& p0, double& p1, int& j0, 
 #undef XT_H2
     p0 = q0;
     p1 = q1;
-    const int n0 = (int)k0, n1 = (int)k1;
+    const int n0 = xt_lo32(t0), n1 = xt_lo32(t1);
     j0 = n0 & 63;
     j1 = n1 & 63;
     e0 = n0 >> 6;

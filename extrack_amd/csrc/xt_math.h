@@ -58,13 +58,27 @@ XT_HD double xt_rint(double x) { return nearbyint(x); }
 
 XT_HD double xt_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 
+// Round-to-nearest-integer of |v| < 2^31 by the magic-number add: the integer lands in the low 32 bits of the double,
+// so the int conversion is free and the fp64 rounding instruction is saved (v_rndne_f64 + v_cvt_i32_f64 -> one add).
+#define XT_MAGIC 6755399441055744.0  // 1.5 * 2^52
+XT_HD int xt_lo32(double t)
+{
+    union {
+        double d;
+        long long i;
+    } u;
+    u.d = t;
+    return (int)u.i;
+}
+
 // exp(x), x <= 0, table-driven: x = (64 e + j) ln2/64 + r, |r| <= ln2/128, exp(x) = 2^e * T64[j] * p with p = P5(r).
 // T64[j] = 2^(j/64) is part of the model blob (xt_tables.h).  |rel err| < 3e-16.  A NaN argument stays NaN.
 #define XT_TCLAMP (-3.0e7)  // keeps 64 x / ln2 inside int32
 XT_HD void xt_exp_tab(double x, double& p, int& j, int& e)
 {
     x = x < XT_TCLAMP ? XT_TCLAMP : x;
-    const double kf = xt_rint(x * 92.33248261689366);
+    const double tk = xt_fma(x, 92.33248261689366, XT_MAGIC);
+    const double kf = tk - XT_MAGIC;
     double r = xt_fma(kf, -0.010830424493178725, x);
     r = xt_fma(kf, -2.030704202170295e-10, r);
     double q = 8.33333333333333333333e-03;
@@ -73,7 +87,7 @@ XT_HD void xt_exp_tab(double x, double& p, int& j, int& e)
     q = xt_fma(q, r, 0.5);
     q = xt_fma(q, r, 1.0);
     p = xt_fma(q, r, 1.0);
-    const int n = (int)kf;
+    const int n = xt_lo32(tk);
     j = n & 63;
     e = n >> 6;
 }
