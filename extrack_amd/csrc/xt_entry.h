@@ -26,7 +26,7 @@ XT_HD void xt_entry_body(const XtKernelArgs& a, Ctx& cx)
 {
     int lb, nb;
     const XtBucketDesc b = xt_bind_bucket(a, cx.block(), cx.nblocks(), lb, nb);
-    const int G = a.G, S = a.S, E = a.E, NG = a.NG, L = b.L;
+    const int G = a.G, S = a.S, E = a.E, EP = a.EP, NG = a.NG, L = b.L;
     const int tid = cx.tid();
     double* smem = cx.smem();
     const int ntab = xt_tab_doubles(S, G);
@@ -44,13 +44,13 @@ XT_HD void xt_entry_body(const XtKernelArgs& a, Ctx& cx)
     const int q = r - g * GP;
     const bool tvalid = slot < a.TPB;
     const bool qvalid = q < G && r < TPT;
-    const int rdoubles = xt_region_doubles(E, D, K);
+    const int rdoubles = xt_region_doubles(EP, D, K);
     double* reg = smem + ((ntab + 1) & ~1) + (tvalid ? slot : 0) * rdoubles;
     double* zm = reg;
-    double* mm = zm + E;
-    double* uu = mm + D * E;
-    int* ze = (int*)(uu + K * E);
-    int* red_e = ze + ((E + 1) & ~1);
+    double* mm = zm + EP;
+    double* uu = mm + D * EP;
+    int* ze = (int*)(uu + K * EP);
+    int* red_e = ze + ((EP + 1) & ~1);
     double* wsum = smem + ((ntab + 1) & ~1) + a.TPB * rdoubles + (tvalid ? slot : 0) * 16;  // per-wave partials of the final sum
 
     const int prev = (r < TPT ? g : 0) / a.prev_div;
@@ -86,12 +86,13 @@ XT_HD void xt_entry_body(const XtKernelArgs& a, Ctx& cx)
             double l20[K], c0[D];
             load_l2(0, l20);
             for (int d = 0; d < D; ++d) c0[d] = c[d];
-            for (int i = r; i < E; i += TPTP) {
-                const bool live = i < S;
-                zm[i] = live ? hdr[8 + i] : 0.0;
+            for (int il = r; il < E; il += TPTP) {
+                const bool live = il < S;
+                const int i = xt_skew(il, a.skew);
+                zm[i] = live ? hdr[8 + il] : 0.0;
                 ze[i] = live ? 0 : XT_EMIN;
-                for (int d = 0; d < D; ++d) mm[d * E + i] = c0[d];
-                for (int k = 0; k < K; ++k) uu[k * E + i] = l20[k];
+                for (int d = 0; d < D; ++d) mm[d * EP + i] = c0[d];
+                for (int k = 0; k < K; ++k) uu[k * EP + i] = l20[k];
             }
             if (r == 0) red_e[0] = XT_EMIN;
         }
@@ -117,11 +118,11 @@ XT_HD void xt_entry_body(const XtKernelArgs& a, Ctx& cx)
                 load_l2(t, l2t);
                 for (int k = 0; k < K; ++k) bad = bad || l2t[k] != l2t[k];
                 if (qvalid) {
-                    idx = a.base_tab[ph * NG + g] + a.off_tab[ph * G + q];
+                    idx = xt_skew(a.base_tab[ph * NG + g] + a.off_tab[ph * G + q], a.skew);
                     z = zm[idx];
                     e = ze[idx];
-                    for (int d = 0; d < D; ++d) mq[d] = mm[d * E + idx];
-                    for (int k = 0; k < K; ++k) uq[k] = uu[k * E + idx];
+                    for (int d = 0; d < D; ++d) mq[d] = mm[d * EP + idx];
+                    for (int k = 0; k < K; ++k) uq[k] = uu[k * EP + idx];
                 }
             }
             // group merge: butterfly over the GP lanes of the group (every lane of the wave takes part)
@@ -175,8 +176,8 @@ XT_HD void xt_entry_body(const XtKernelArgs& a, Ctx& cx)
                 const int en = We + n;
                 zm[idx] = (Wm * (t >= stay_from ? t1q : t0q)) * (gf * T64[j]) * p;
                 ze[idx] = en > XT_EMIN ? en : XT_EMIN;
-                for (int d = 0; d < D; ++d) mm[d * E + idx] = xt_fma(dm[d], tt[K == 1 ? 0 : d], M[d]);
-                for (int k = 0; k < K; ++k) uu[k * E + idx] = l2t[k] * tt[k];
+                for (int d = 0; d < D; ++d) mm[d * EP + idx] = xt_fma(dm[d], tt[K == 1 ? 0 : d], M[d]);
+                for (int k = 0; k < K; ++k) uu[k * EP + idx] = l2t[k] * tt[k];
             }
             cx.sync();
         }
@@ -187,7 +188,7 @@ XT_HD void xt_entry_body(const XtKernelArgs& a, Ctx& cx)
         if (act && qvalid) {
             const int tl = L - 1;
             const int ph = (tl - 1) % a.P;
-            const int idx = a.base_tab[ph * NG + g] + a.off_tab[ph * G + q];
+            const int idx = xt_skew(a.base_tab[ph * NG + g] + a.off_tab[ph * G + q], a.skew);
             const int vfin = (b.isBL ? 2 : 0) + (tl >= stay_from ? 1 : 0);
             const double* TF = TAB + (vfin * S + prev) * G;
             const double* TD2 = TAB + (4 * S + prev) * G;
@@ -203,10 +204,10 @@ XT_HD void xt_entry_body(const XtKernelArgs& a, Ctx& cx)
                 const int eq = ze[idx];
                 double dq[D], uq[K], dsq = 0.0;
                 for (int d = 0; d < D; ++d) {
-                    dq[d] = cl[d] - mm[d * E + idx];
+                    dq[d] = cl[d] - mm[d * EP + idx];
                     dsq = xt_fma(dq[d], dq[d], dsq);
                 }
-                for (int k = 0; k < K; ++k) uq[k] = uu[k * E + idx];
+                for (int k = 0; k < K; ++k) uq[k] = uu[k * EP + idx];
                 for (int j = 0; j < G; ++j) {
                     double quad, gf;
                     if (K == 1) {
@@ -280,7 +281,7 @@ static inline void xt_entry_geometry(int S, int G, int E, int NG, int D, int K, 
 {
     const int tptp = xt_entry_tptp(NG, xt_entry_gp(G));
     const size_t fixed = (size_t)((xt_tab_doubles(S, G) + 1) & ~1) * 8;
-    const size_t per_track = (size_t)(xt_region_doubles(E, D, K) + 16) * 8;
+    const size_t per_track = (size_t)(xt_region_doubles(xt_padded_entries(E, (S & (S - 1)) == 0), D, K) + 16) * 8;
     int by_threads = tptp >= 256 ? 1 : 256 / tptp;
     int by_lds = 64 * 1024 > fixed + per_track ? (int)((64 * 1024 - fixed) / per_track) : 1;
     tpb = by_threads < by_lds ? by_threads : by_lds;

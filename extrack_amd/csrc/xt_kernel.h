@@ -59,6 +59,8 @@ struct XtKernelArgs {
     double* preds_out;        // [N][L][S] (PREDS kernels)
     int64_t N;
     int32_t L, S, NS, F, G, E, NG, P;
+    int32_t EP;               // padded sequence-array length (E, or E + E/32 + E/1024 + 1 with the bank-conflict skew)
+    int32_t skew;             // 1: storage index = i + (i >> 5) + (i >> 10)  (power-of-two S: kills the 4^h / 2^h stride conflicts)
     int32_t TPB;              // tracks processed concurrently by one block
     int32_t isBL, min_len;
     int32_t locerr_mode;      // 0 global (blob[0..2]), 1 per-peak sigma, 2 per-peak affine clip(s*slope+offset,1e-6)
@@ -74,6 +76,10 @@ XT_HD int xt_region_doubles(int E, int D, int K) { return E * (1 + D + K) + (E +
 XT_HD int xt_pred_doubles(int S, int F) { return 2 * (S + 1) + (F + 1) * S + 2; }
 #define XT_STAGE 32  // positions of a track staged in LDS per refill (coalesced loads instead of a dependent global load per step)
 XT_HD int xt_stage_doubles(int D) { return XT_STAGE * (D + XT_MAX_DIMS); }
+// Storage index of logical sequence i.  For power-of-two S consecutive groups are 2^k / 4^k sequences apart, an up to
+// 12-way LDS bank conflict on the 8-byte arrays; the additive skew brings it to <= 2-way (tools/lds_conflicts_general.py).
+XT_HD int xt_skew(int i, int skew) { return skew ? i + (i >> 5) + (i >> 10) : i; }
+XT_HD int xt_padded_entries(int E, int skew) { return skew ? E + (E >> 5) + (E >> 10) + 1 : E; }
 
 // Resolves which bucket this block serves: returns its descriptor by value (registers), the block's index inside the
 // bucket (lb) and the number of blocks serving the bucket (nb).  The kernel arguments stay in the constant kernarg segment.
@@ -115,7 +121,7 @@ XT_HD void xt_track_body(const XtKernelArgs& a, Ctx& cx)
     int lb, nb;
     const XtBucketDesc b = xt_bind_bucket(a, cx.block(), cx.nblocks(), lb, nb);
     const int G = G_ ? G_ : a.G;
-    const int S = a.S, E = a.E, NG = a.NG, L = b.L, F = a.F;
+    const int S = a.S, E = a.E, EP = a.EP, NG = a.NG, L = b.L, F = a.F;
     const int tid = cx.tid();
     double* smem = cx.smem();
 
@@ -129,13 +135,13 @@ XT_HD void xt_track_body(const XtKernelArgs& a, Ctx& cx)
     const int slot = tid / NG;
     const int g = tid - slot * NG;
     const bool tvalid = slot < a.TPB;
-    const int rdoubles = xt_region_doubles(E, D, K);
+    const int rdoubles = xt_region_doubles(EP, D, K);
     double* reg = smem + ((ntab + 1) & ~1) + (tvalid ? slot : 0) * rdoubles;
     double* zm = reg;
-    double* mm = zm + E;
-    double* uu = mm + D * E;
-    int* ze = (int*)(uu + K * E);
-    int* red_e = ze + ((E + 1) & ~1);  // [2] ints: final-reduce exponent, spare
+    double* mm = zm + EP;
+    double* uu = mm + D * EP;
+    int* ze = (int*)(uu + K * EP);
+    int* red_e = ze + ((EP + 1) & ~1);  // [2] ints: final-reduce exponent, spare
     double* pbase = smem + ((ntab + 1) & ~1) + a.TPB * rdoubles + (tvalid ? slot : 0) * xt_pred_doubles(S, F);
     // PREDS accumulators: pe[2] (ints, in one double), pacc[2][S], facc[F+1][S]
     int* pe = (int*)pbase;
@@ -209,12 +215,13 @@ XT_HD void xt_track_body(const XtKernelArgs& a, Ctx& cx)
             double l20[K], c0[D];
             load_l2(0, l20);
             for (int d = 0; d < D; ++d) c0[d] = spos[d];
-            for (int i = g; i < E; i += NG) {
-                const bool live = i < S;
-                zm[i] = live ? hdr[8 + i] : 0.0;
+            for (int il = g; il < E; il += NG) {
+                const bool live = il < S;
+                const int i = xt_skew(il, a.skew);
+                zm[i] = live ? hdr[8 + il] : 0.0;
                 ze[i] = live ? 0 : XT_EMIN;
-                for (int d = 0; d < D; ++d) mm[d * E + i] = c0[d];
-                for (int k = 0; k < K; ++k) uu[k * E + i] = l20[k];
+                for (int d = 0; d < D; ++d) mm[d * EP + i] = c0[d];
+                for (int k = 0; k < K; ++k) uu[k * EP + i] = l20[k];
             }
             if (g == 0) {
                 red_e[0] = XT_EMIN;
@@ -246,18 +253,18 @@ XT_HD void xt_track_body(const XtKernelArgs& a, Ctx& cx)
 
                 int emax = XT_EMIN;
                 for (int q = 0; q < G; ++q) {
-                    const int e = ze[base + off[q]];
+                    const int e = ze[xt_skew(base + off[q], a.skew)];
                     emax = e > emax ? e : emax;
                 }
                 double W = 0.0, mb[D], ub[K];
                 for (int d = 0; d < D; ++d) mb[d] = 0.0;
                 for (int k = 0; k < K; ++k) ub[k] = 0.0;
                 for (int q = 0; q < G; ++q) {
-                    const int idx = base + off[q];
+                    const int idx = xt_skew(base + off[q], a.skew);
                     const double aq = xt_ldexp(zm[idx], ze[idx] - emax);
                     W += aq;
-                    for (int d = 0; d < D; ++d) mb[d] = xt_fma(aq, mm[d * E + idx], mb[d]);
-                    for (int k = 0; k < K; ++k) ub[k] = xt_fma(aq, uu[k * E + idx], ub[k]);
+                    for (int d = 0; d < D; ++d) mb[d] = xt_fma(aq, mm[d * EP + idx], mb[d]);
+                    for (int k = 0; k < K; ++k) ub[k] = xt_fma(aq, uu[k * EP + idx], ub[k]);
                 }
 
                 if (do_pred) {
@@ -265,16 +272,16 @@ XT_HD void xt_track_body(const XtKernelArgs& a, Ctx& cx)
                     // position t (tracking.py:255-271; note the reference's missing 1/2 on the log term)
                     int pemax = XT_EMIN;
                     for (int Q = 0; Q < G; ++Q) {
-                        const int idx = base + off[Q];
+                        const int idx = xt_skew(base + off[Q], a.skew);
                         pq[Q].clear();
                         const double zq = zm[idx];
                         if (zq != 0.0) {
                             double dq[D], uq[K], dsq = 0.0;
                             for (int d = 0; d < D; ++d) {
-                                dq[d] = ct[d] - mm[d * E + idx];
+                                dq[d] = ct[d] - mm[d * EP + idx];
                                 dsq = xt_fma(dq[d], dq[d], dsq);
                             }
-                            for (int k = 0; k < K; ++k) uq[k] = uu[k * E + idx];
+                            for (int k = 0; k < K; ++k) uq[k] = uu[k * EP + idx];
                             for (int q = 0; q < G; ++q) {
                                 double quad, gf;
                                 if (K == 1) {
@@ -314,7 +321,7 @@ XT_HD void xt_track_body(const XtKernelArgs& a, Ctx& cx)
                     dsq = xt_fma(dm[d], dm[d], dsq);
                 }
                 for (int q = 0; q < G; ++q) {
-                    const int idx = base + off[q];
+                    const int idx = xt_skew(base + off[q], a.skew);
                     const double d2 = TDD(q);
                     double quad, gf, tt[K];
                     if (K == 1) {
@@ -341,8 +348,8 @@ XT_HD void xt_track_body(const XtKernelArgs& a, Ctx& cx)
                     const int en = We + n;
                     zm[idx] = (Wm * TT(q)) * (gf * T64[j]) * p;  // Wm == 0 for an all-zero group, whose We is XT_EMIN
                     ze[idx] = en > XT_EMIN ? en : XT_EMIN;
-                    for (int d = 0; d < D; ++d) mm[d * E + idx] = xt_fma(dm[d], tt[K == 1 ? 0 : d], mb[d]);
-                    for (int k = 0; k < K; ++k) uu[k * E + idx] = l2t[k] * tt[k];
+                    for (int d = 0; d < D; ++d) mm[d * EP + idx] = xt_fma(dm[d], tt[K == 1 ? 0 : d], mb[d]);
+                    for (int k = 0; k < K; ++k) uu[k * EP + idx] = l2t[k] * tt[k];
                 }
             }
             cx.sync();
@@ -384,16 +391,16 @@ XT_HD void xt_track_body(const XtKernelArgs& a, Ctx& cx)
                     accq[q].clear();
                 }
             for (int Q = 0; Q < G; ++Q) {
-                const int idx = base + off[Q];
+                const int idx = xt_skew(base + off[Q], a.skew);
                 const double zq = zm[idx];
                 if (zq == 0.0) continue;
                 const int eq = ze[idx];
                 double dq[D], uq[K], dsq = 0.0;
                 for (int d = 0; d < D; ++d) {
-                    dq[d] = cl[d] - mm[d * E + idx];
+                    dq[d] = cl[d] - mm[d * EP + idx];
                     dsq = xt_fma(dq[d], dq[d], dsq);
                 }
-                for (int k = 0; k < K; ++k) uq[k] = uu[k * E + idx];
+                for (int k = 0; k < K; ++k) uq[k] = uu[k * EP + idx];
                 for (int q = 0; q < G; ++q) {
                     double quad, gf;
                     if (K == 1) {

@@ -16,7 +16,7 @@
 #include "xt_kernel.h"
 
 struct XtConfig {
-    int S = 0, NS = 0, F = 0, G = 0, E = 0, NG = 0, P = 0, prev_div = 1;
+    int S = 0, NS = 0, F = 0, G = 0, E = 0, NG = 0, P = 0, prev_div = 1, EP = 0, skew = 0;
     int pw[16] = {0};
     std::vector<int32_t> base_tab;  // [P][NG]
     std::vector<int32_t> off_tab;   // [P][G]
@@ -41,6 +41,8 @@ static inline std::string xt_build_config(int S, int NS, int F, XtConfig& c)
     c.G = c.pw[NS];
     c.E = c.pw[F];
     c.NG = c.E / c.G;
+    c.skew = (S & (S - 1)) == 0 ? 1 : 0;  // power-of-two S: skewed storage (xt_kernel.h)
+    c.EP = xt_padded_entries(c.E, c.skew);
     c.P = F / xt_gcd(F, NS);
     c.prev_div = c.pw[F - NS - 1];
     c.base_tab.assign((size_t)c.P * c.NG, 0);
@@ -150,6 +152,8 @@ static inline void xt_fill_args_from_config(const XtConfig& c, XtKernelArgs& a)
     a.G = c.G;
     a.E = c.E;
     a.NG = c.NG;
+    a.EP = c.EP;
+    a.skew = c.skew;
     a.P = c.P;
     a.prev_div = c.prev_div;
     for (int i = 0; i < 16; ++i) a.pw[i] = c.pw[i];
@@ -157,7 +161,7 @@ static inline void xt_fill_args_from_config(const XtConfig& c, XtKernelArgs& a)
 
 static inline size_t xt_lds_bytes(const XtConfig& c, int D, int K, int tpb)
 {
-    size_t d = (size_t)((xt_tab_doubles(c.S, c.G) + 1) & ~1) + (size_t)tpb * xt_region_doubles(c.E, D, K);
+    size_t d = (size_t)((xt_tab_doubles(c.S, c.G) + 1) & ~1) + (size_t)tpb * xt_region_doubles(c.EP, D, K);
     d += (size_t)tpb * (xt_pred_doubles(c.S, c.F) + xt_stage_doubles(D));  // posterior accumulators + staged positions
     return d * sizeof(double);
 }
