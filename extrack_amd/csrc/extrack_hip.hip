@@ -62,7 +62,7 @@ __global__ void __launch_bounds__(MAXT) xt_track_kernel(XtKernelArgs a)
 }
 
 template <int F, int D, int K>
-__global__ void __launch_bounds__(64 * XT_F2_WAVES, (K == 1 ? 4 : 3)) xt_ll_s2_kernel(XtKernelArgs a)
+__global__ void __launch_bounds__(64 * XT_F2_WAVES) xt_ll_s2_kernel(XtKernelArgs a)
 {
     DevCtx cx;
     xt_ll_s2_body<F, D, K>(a, cx);

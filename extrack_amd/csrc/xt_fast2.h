@@ -101,7 +101,8 @@ struct XtF2State {
 #define XT_F2_ZM0 XT_F2_TAB_BYTES
 XT_HD int xt_f2_ze0(int D, int K) { return XT_F2_ZM0 + (1 + D + K) * XT_F2_ARR; }
 XT_HD int xt_f2_pos0(int D, int K) { return xt_f2_ze0(D, K) + XT_F2_WAVES * 128 * 4; }
-XT_HD int xt_f2_block_bytes(int D, int K, int KS, int tpw) { return xt_f2_pos0(D, K) + XT_F2_WAVES * tpw * XT_F2_CHUNK * (D + KS) * 8; }
+XT_HD int xt_f2_acc0(int D, int K, int KS, int tpw) { return xt_f2_pos0(D, K) + XT_F2_WAVES * tpw * XT_F2_CHUNK * (D + KS) * 8; }
+XT_HD int xt_f2_block_bytes(int D, int K, int KS, int tpw) { return xt_f2_acc0(D, K, KS, tpw) + XT_F2_WAVES * 8 * 3 * 8; }
 
 // Keeps the compiler from hoisting the (loop-invariant) unpacked addresses of all F phases out of the
 // step loop, which costs ~50 VGPRs and halves the occupancy.
@@ -231,7 +232,7 @@ XT_HD void xt_ll_s2_body(const XtKernelArgs& a, Ctx& cx)
     const int ts = lane / NG;        // track slot inside the wave
     const int g = lane - ts * NG;    // group of that track
     const int prev = g >> (F - 2 >= 0 ? F - 2 : 0);  // top digit of g (F >= 2)
-    double T0[2], T1[2], TD2[2], TFIN[2];
+    double T0[2], T1[2], TD2[2];
     const int tlast = L - 1;
     const int stay_from = a.min_len > 2 ? a.min_len : 2;
     const int vfin = (b.isBL ? 2 : 0) + (tlast >= stay_from ? 1 : 0);
@@ -239,12 +240,9 @@ XT_HD void xt_ll_s2_body(const XtKernelArgs& a, Ctx& cx)
         T0[q] = TAB[(0 * 2 + prev) * 2 + q];
         T1[q] = TAB[(1 * 2 + prev) * 2 + q];
         TD2[q] = TAB[(4 * 2 + prev) * 2 + q];
-        TFIN[q] = TAB[(vfin * 2 + prev) * 2 + q];
     }
     double l2g[K];
     for (int k = 0; k < K; ++k) l2g[k] = hdr[k];
-    const double slope = hdr[3], offset = hdr[4];
-    const double F0 = hdr[8], F1 = hdr[9];
 
     // LDS map (bytes): [tables 1 KiB][zm][m x D][u x K] (each XT_F2_WAVES x 128 doubles) [ze: XT_F2_WAVES x 128 ints][pos][sig]
     constexpr int ZEO = XT_F2_ZM0 + (1 + D + K) * XT_F2_ARR - XT_F2_ZM0 / 2;
@@ -259,8 +257,14 @@ XT_HD void xt_ll_s2_body(const XtKernelArgs& a, Ctx& cx)
         st.s01[h] = b0 | (b1 << 16);
     }
 
-    // running product of the tracks' likelihoods for this lane's track slot (identical in its NG lanes)
-    double accm = 1.0, acce = 0.0, ntr = 0.0;
+    // running product of the tracks' likelihoods per track slot {mantissa, exponent, count}: kept in LDS (owned by the
+    // slot's lane g == 0) rather than in six VGPRs that would be live across the whole kernel
+    double* accp = (double*)(lds + xt_f2_acc0(D, K, KS, TPW)) + (wib * 8 + ts) * 3;
+    if (g == 0) {
+        accp[0] = 1.0;
+        accp[1] = 0.0;
+        accp[2] = 0.0;
+    }
 
     const int64_t nbatch = (b.N + TPW - 1) / TPW;
     const int64_t W0 = (int64_t)lb * nwb + wib, NW = (int64_t)nb * nwb;
@@ -303,7 +307,7 @@ XT_HD void xt_ll_s2_body(const XtKernelArgs& a, Ctx& cx)
                 for (int k = 0; k < K; ++k) {
                     double s = sig[(ts * XT_F2_CHUNK + r) * KS + (KS == 1 ? 0 : k)];
                     if (a.locerr_mode == 2) {
-                        s = xt_fma(s, slope, offset);
+                        s = xt_fma(s, hdr[3], hdr[4]);
                         s = s < 1e-6 ? 1e-6 : s;
                     }
                     l2[k] = s * s;
@@ -348,7 +352,7 @@ XT_HD void xt_ll_s2_body(const XtKernelArgs& a, Ctx& cx)
                     const int w = ts * E + g * 2 + q;  // any bijection lanes x {0,1} -> the track's E sequences
                     const int idx = w - ts * E;
                     const int aq = wave0 + xt_f2_swz<F>(w) * 8;
-                    xt_at<double>(lds, aq) = idx == 0 ? F0 : (idx == 1 ? F1 : 0.0);
+                    xt_at<double>(lds, aq) = idx < 2 ? hdr[8 + idx] : 0.0;  // initial fractions F0, F1
                     xt_at<int>(lds, (aq >> 1) + ZEO) = idx < 2 ? 0 : XT_EMIN;
                     for (int d = 0; d < D; ++d) xt_at<double>(lds, aq + (1 + d) * XT_F2_ARR) = c0[d];
                     for (int k = 0; k < K; ++k) xt_at<double>(lds, aq + (1 + D + k) * XT_F2_ARR) = l20[k];
@@ -368,6 +372,9 @@ XT_HD void xt_ll_s2_body(const XtKernelArgs& a, Ctx& cx)
             int pk = st.s01[0];
             for (int hh = 1; hh < F; ++hh) pk = h == hh ? st.s01[hh] : pk;
             const int a0 = pk & 0xffff, a1 = (int)((unsigned)pk >> 16);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1  // cold code: keep its register footprint below the step loop's so that it does not set the kernel's VGPR count
+#endif
             for (int Q = 0; Q < 2; ++Q) {
                 const int aq = Q ? a1 : a0;
                 const double zq = xt_at<double>(lds, aq);
@@ -398,7 +405,7 @@ XT_HD void xt_ll_s2_body(const XtKernelArgs& a, Ctx& cx)
                 int j[2], n[2];
                 xt_exp_tab_x2(x[0], x[1], p[0], p[1], j[0], j[1], n[0], n[1]);
                 for (int q = 0; q < 2; ++q)
-                    tot.add(zq * TFIN[q] * gf[q] * xt_at<double>(lds, XT_F2_T64_OFF + j[q] * 8) * p[q], eq + n[q]);
+                    tot.add(zq * TAB[(vfin * 2 + prev) * 2 + q] * gf[q] * xt_at<double>(lds, XT_F2_T64_OFF + j[q] * 8) * p[q], eq + n[q]);
             }
         }
         // reduce over the track's NG lanes (all lanes end with the same values)
@@ -410,20 +417,21 @@ XT_HD void xt_ll_s2_body(const XtKernelArgs& a, Ctx& cx)
         double sum = tot.m != 0.0 ? xt_ldexp(tot.m, tot.e - fe) : 0.0;
         for (int m = 1; m < NG; m <<= 1) sum += cx.shfl_xor_f64(sum, m);
         if (xt_at<int>(lds, XT_F2_NAN_OFF + (wib * 8 + ts) * 4)) sum = NAN;  // NaN input -> NaN likelihood, as in the reference
-        if (act) {
-            if (b.ll_out && g == 0) b.ll_out[trk] = log(sum) + (double)fe * XT_LN2 + b.ll_const;
-            const double pm = accm * xt_frexp_mant(sum);
-            acce += (double)(fe + xt_frexp_exp(sum) + xt_frexp_exp(pm));
-            accm = xt_frexp_mant(pm);
-            ntr += 1.0;
+        if (act && g == 0) {
+            if (b.ll_out) b.ll_out[trk] = log(sum) + (double)fe * XT_LN2 + b.ll_const;
+            const double pm = accp[0] * xt_frexp_mant(sum);
+            double acce = accp[1] + (double)(fe + xt_frexp_exp(sum) + xt_frexp_exp(pm));
             if (sum == 0.0) acce = -INFINITY;  // zero likelihood: log = -inf, as the reference would produce
+            accp[0] = xt_frexp_mant(pm);
+            accp[1] = acce;
+            accp[2] += 1.0;
         }
         cx.wave_sync();
     }
 
     // ---- per-slot log-likelihood sums -> block partial (fixed order)
     cx.sync();
-    if (g == 0) smem[wib * TPW + ts] = ntr > 0.0 ? log(accm) + acce * XT_LN2 + ntr * b.ll_const : 0.0;
+    if (g == 0) smem[wib * TPW + ts] = accp[2] > 0.0 ? log(accp[0]) + accp[1] * XT_LN2 + accp[2] * b.ll_const : 0.0;
     cx.sync();
     if (cx.tid() == 0) {
         double s = 0.0;
