@@ -328,3 +328,23 @@ def test_tiny_and_ragged_datasets():
     assert sorted(pr.keys(), key=int) == ["2", "3", "7", "31"] and pr["3"].shape == (0, 3, 2)
     for k in ("2", "7", "31"):
         np.testing.assert_allclose(pr[k], pro[k], atol=TOL_PRED, rtol=0)
+
+
+@pytest.mark.parametrize("S,F,L", [(2, 6, 1000), (2, 4, 257), (3, 4, 400), (4, 3, 300)])
+def test_long_tracks_error_accumulation(S, F, L):
+    """Rounding errors accumulate along the track: parity on tracks of hundreds of positions (many 32-position staging chunks)."""
+    from extrack_amd import synth, tracking as T
+    from oracle import oracle_np as O
+    Ds = [0.0, 0.05, 0.25, 0.8][:S]
+    Tm = np.full((S, S), 0.06)
+    Tm[np.arange(S), np.arange(S)] = 1 - 0.06 * (S - 1)
+    Fs = np.full(S, 1.0 / S)
+    Cs = synth.brownian_tracks(24, L, Ds, Tm, Fs, seed=L)
+    ds = np.sqrt(2 * np.array(Ds) * 0.02) + 1e-4
+    LE = np.array([[[0.02]]])
+    ref = O.proba_cs(Cs, LE, ds, Fs, Tm, 0.1, 0, [1.0], 1, F, 3)
+    got = T.Proba_Cs(Cs, LE, ds, Fs, Tm, 0.1, 0, [1.0], 1, F, 3)
+    assert np.abs(got - ref).max() < TOL_LL, np.abs(got - ref).max()
+    _, _, preds = T.P_Cs_inter_bound_stats(Cs[:6], LE, ds, Fs, Tm, 0.1, 1, [1.0], 1, F, 1, 3)
+    _, pref = O.p_cs_inter_bound_stats(Cs[:6], LE, ds, Fs, Tm, 0.1, 1, [1.0], 1, F, 1, 3)
+    assert np.abs(preds - pref).max() < TOL_PRED
