@@ -77,6 +77,23 @@ def cpu_baseline(sample_tracks_per_core=8000):
             "tracks_per_s": tps}
 
 
+def cpu_baseline_compiled(cores, n=400000):
+    """Secondary CPU number: the plain-C restatement (oracle/extrack_oracle.c, gcc -O2 -fopenmp, log domain like the reference)
+    on the same socket.  Reported next to the numpy baseline so that the GPU/CPU ratio can also be read against compiled code."""
+    from extrack_amd import synth
+    from oracle import oracle_c, oracle_np as O
+    Cs = synth.brownian_tracks(n, LEN, DS_COEF, TRMAT, FS, LOCERR, DT, DIMS, seed=321)
+    ds = np.sqrt(2 * np.array(DS_COEF) * DT)
+    T = 1 - np.exp(-np.array(TRMAT)); T[np.arange(S), np.arange(S)] = 0; T[np.arange(S), np.arange(S)] = 1 - T.sum(1)
+    ps = O.p_stay_table(ds, S, NS, CELL)
+    oracle_c.run(Cs[:2000], np.array([[[LOCERR]]]), ds, FS, T, PBL, 0, ps, NS, FRAME, LEN, nthreads=cores)
+    t0 = time.perf_counter()
+    oracle_c.run(Cs, np.array([[[LOCERR]]]), ds, FS, T, PBL, 0, ps, NS, FRAME, LEN, nthreads=cores)
+    wall = time.perf_counter() - t0
+    return {"value": n / wall / N_TRACKS, "unit": "1e6-track LL evals/s", "cores": cores, "kind": "port (C, OpenMP)",
+            "sample": "%d tracks, %.0f tracks/s" % (n, n / wall)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -181,6 +198,10 @@ def main():
     if not a.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline()
         out["speedup_vs_cpu_baseline"] = evals_per_s / out["cpu_baseline"]["value"]
+        try:
+            out["cpu_baseline_compiled"] = cpu_baseline_compiled(out["cpu_baseline"]["cores"])
+        except Exception as e:  # gcc missing on the box: the numpy baseline stands alone
+            out["cpu_baseline_compiled"] = {"error": str(e)}
     try:  # RCCL's version banner (NCCL_DEBUG=VERSION) sits in the C stdio buffer: flush it so the JSON line comes last
         import ctypes
         ctypes.CDLL(None).fflush(None)

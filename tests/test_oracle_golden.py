@@ -115,3 +115,44 @@ def test_errors():
         O.p_cs_inter_bound_stats(np.zeros((1, 1, 2)), np.array([[[0.02]]]), [0.01, 0.1], [0.5, 0.5], [[.9, .1], [.1, .9]])
     with pytest.raises(ValueError):
         O.p_cs_inter_bound_stats(np.zeros((1, 5, 2)), np.full((1, 3, 2), 0.02), [0.01, 0.1], [0.5, 0.5], [[.9, .1], [.1, .9]])
+
+
+def test_c_oracle_kernel_cases(kernel_cases):
+    """The plain-C restatement (oracle/extrack_oracle.c) against the same reference-generated vectors, including the cases too
+    large for the vectorised numpy oracle (4 states, 3 substeps: 4^10 sequences per track)."""
+    import shutil
+    if shutil.which("gcc") is None:
+        pytest.skip("needs gcc")
+    from oracle import oracle_c
+    meta, data = kernel_cases
+    worst_lp = worst_pr = 0.0
+    n = 0
+    for row in meta:
+        if row["id"] % 2 and row["nB"] < 300000:
+            continue
+        x = case_inputs(row, data)
+        ps = O.p_stay_table(x["ds"], row["S"], row["ns"], row["cell_dims"])
+        do_preds = row["ns"] == 1
+        ll, pr = oracle_c.run(x["Cs"], x["LE"], x["ds"], x["Fs"], x["T"], row["pBL"], row["isBL"], ps, row["ns"], row["F"], row["min_len"],
+                              do_preds=do_preds, nthreads=4)
+        worst_lp = max(worst_lp, np.abs(ll - x["LPC"]).max())
+        if do_preds:
+            worst_pr = max(worst_pr, np.abs(pr - x["preds"]).max())
+        n += 1
+    assert n > 450 and worst_lp < TOL_LP and worst_pr < TOL_PRED, (n, worst_lp, worst_pr)
+
+
+def test_c_oracle_matches_numpy_oracle_on_affine_per_peak_locerr():
+    import shutil
+    if shutil.which("gcc") is None:
+        pytest.skip("needs gcc")
+    from oracle import oracle_c
+    rng = np.random.default_rng(11)
+    Cs = np.cumsum(rng.normal(0, 0.05, (7, 13, 2)), 1)
+    sig = rng.uniform(0.01, 0.03, (7, 13, 2))
+    ds, Fs, T = np.array([0.01, 0.08, 0.2]), np.array([.3, .3, .4]), np.array([[.8, .1, .1], [.1, .8, .1], [.1, .1, .8]])
+    ps = O.p_stay_table(ds, 3, 1, [1.0])
+    aff = np.clip(sig * 1.2 + 0.001, 1e-6, np.inf)
+    ref = O.proba_cs(Cs, aff, ds, Fs, T, 0.05, 1, [1.0], 1, 4, 3)
+    ll, _ = oracle_c.run(Cs, sig, ds, Fs, T, 0.05, 1, ps, 1, 4, 3, slope=1.2, offset=0.001)
+    assert np.abs(ll - ref).max() < TOL_LP
