@@ -5,6 +5,7 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -31,6 +32,25 @@ try:
     b = T.cum_Proba_Cs(p, ts, 0.02, [1], None, 2, 1, 6, verbose=0)
     ts.close()
     assert a == b, (a, b)
+    # the same communicator through the public fitting entry point (sharding + per-evaluation all-reduce inside the optimiser loop)
+    import contextlib, io
+    p0 = T.generate_params(nb_states=2, LocErr_type=1, LocErr_bounds=[0.005, 0.1], D_max=3, estimated_Ds=[0.0001, 0.1], estimated_Fs=[0.5],
+                           estimated_transition_rates=0.05)
+    with contextlib.redirect_stdout(io.StringIO()):
+        fit_c = T.param_fitting(tr, 0.02, params=p0, nb_states=2, frame_len=4, verbose=0, method="bfgs", cell_dims=[1], comm=comm)
+        fit_s = T.param_fitting(tr, 0.02, params=p0, nb_states=2, frame_len=4, verbose=0, method="bfgs", cell_dims=[1])
+    assert fit_c.nfev == fit_s.nfev and fit_c.residual[0] == fit_s.residual[0], (fit_c.nfev, fit_s.nfev, fit_c.residual, fit_s.residual)
+    # zero-copy attach of torch tensors (device pointers) gives the same objective as the host-upload path
+    from extrack_amd import _lib
+    ctx = _lib.Context(0)
+    tens = [torch.from_numpy(np.ascontiguousarray(x)).cuda() for x in lst]
+    for t_ in tens:
+        ctx.attach_bucket(t_)
+    torch.cuda.synchronize()
+    ts2 = T.TrackSet(lst)
+    model = T._objective_model(p, ts2, 0.02, [1], None, 2, 1, 6, 1)
+    assert ctx.loglik(model) == ts2.loglik(model)
+    ts2.close(); ctx.close()
     print("RCCL_PATH_OK", a)
 finally:
     dist.destroy_process_group()
