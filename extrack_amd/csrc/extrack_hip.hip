@@ -55,7 +55,7 @@ struct DevCtx {
 // MAXT: 256 for the common one-wave-set-per-few-tracks geometry (lets the allocator use up to 256
 // VGPRs at 2 waves/SIMD if it needs them), 1024 when one track's groups need more than 256 threads.
 template <int G_, int D, int K, bool PREDS, int MAXT>
-__global__ void __launch_bounds__(MAXT) xt_track_kernel(XtKernelArgs a)
+__global__ void __launch_bounds__(MAXT, (MAXT == 256 && !PREDS && G_ != 4 ? 4 : 1)) xt_track_kernel(XtKernelArgs a)
 {
     DevCtx cx;
     xt_track_body<G_, D, K, PREDS>(a, cx);
