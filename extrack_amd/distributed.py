@@ -64,6 +64,16 @@ class Comm:
             raise ValueError("rank %d received no tracks: fewer tracks than ranks" % self.rank)
         return TrackSet(t_loc, s_loc, device=device, min_len=lo, max_len=hi)
 
+    # ---- posteriors: no collective in the data path, only an ordered gather of the per-rank row blocks ------------
+    def gather_rows(self, local, dst=0):
+        """``local``: {key: ndarray[rows_of_this_rank, ...]} with the same keys on every rank (rows follow ``shard_range``).
+        Returns the row-concatenated dict on rank ``dst`` (rank order == original row order), None elsewhere."""
+        parts = [None] * self.world if self.rank == dst else None
+        self.dist.gather_object(local, parts, dst=dst, group=self.group)
+        if self.rank != dst:
+            return None
+        return {k: np.concatenate([p[k] for p in parts], axis=0) for k in local}
+
     # ---- the per-evaluation collective ----------------------------------------------------------------------
     def allreduce_loglik(self, ts, model):
         """Local sum of log-likelihoods on this rank's GPU -> all-reduce(sum) -> python float."""

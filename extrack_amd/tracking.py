@@ -322,12 +322,22 @@ def param_fitting(all_tracks, dt, params=None, nb_states=2, nb_substeps=1, frame
 
 
 def predict_Bs(all_tracks, dt, params, cell_dims=[1], nb_states=4, frame_len=5, max_nb_states=200, threshold=0.1, workers=1,
-               input_LocErr=None, verbose=0, nb_max=1, device=0):
+               input_LocErr=None, verbose=0, nb_max=1, device=0, comm=None):
     """Probability of each localisation to be in each state (extrack/tracking.py:792-906).
 
     Returns {str(len): ndarray[n_tracks, len, nb_states]} keyed by every input key (empty arrays for empty
     buckets), rows in input order.  ``nb_substeps`` is forced to 1 like the reference (:839); min/max length
-    come from ALL keys (:853-854)."""
+    come from ALL keys (:853-854).  With ``comm`` (extrack_amd.distributed.Comm) every rank annotates its row range of
+    every bucket on its own GPU and rank 0 gets the row-ordered result (other ranks get None); no collective is needed in
+    the data path."""
+    if comm is not None:
+        from .distributed import shard_range
+        loc_tracks = {k: np.asarray(v)[slice(*shard_range(len(v), comm.rank, comm.world))] for k, v in all_tracks.items()}
+        loc_sig = None if input_LocErr is None else {k: np.asarray(v)[slice(*shard_range(len(v), comm.rank, comm.world))]
+                                                     for k, v in input_LocErr.items()}
+        local = predict_Bs(loc_tracks, dt, params, cell_dims, nb_states, frame_len, max_nb_states, threshold, workers, loc_sig, verbose,
+                           nb_max, device, None)
+        return comm.gather_rows(local)
     keys, tracks, sigmas = engine.sort_buckets(all_tracks, input_LocErr)
     if not is_parameters(params):
         raise TypeError("params must be either of the class 'lmfit.parameter.Parameters' or a dictionary of the relevant parameters")

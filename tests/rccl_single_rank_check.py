@@ -40,6 +40,9 @@ try:
         fit_c = T.param_fitting(tr, 0.02, params=p0, nb_states=2, frame_len=4, verbose=0, method="bfgs", cell_dims=[1], comm=comm)
         fit_s = T.param_fitting(tr, 0.02, params=p0, nb_states=2, frame_len=4, verbose=0, method="bfgs", cell_dims=[1])
     assert fit_c.nfev == fit_s.nfev and fit_c.residual[0] == fit_s.residual[0], (fit_c.nfev, fit_s.nfev, fit_c.residual, fit_s.residual)
+    pa = T.predict_Bs(tr, 0.02, p, cell_dims=[1], nb_states=2, frame_len=5, comm=comm)
+    pb = T.predict_Bs(tr, 0.02, p, cell_dims=[1], nb_states=2, frame_len=5)
+    assert all(np.array_equal(pa[k], pb[k]) for k in pb)
     # zero-copy attach of torch tensors (device pointers) gives the same objective as the host-upload path
     from extrack_amd import _lib
     ctx = _lib.Context(0)

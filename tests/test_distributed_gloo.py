@@ -46,6 +46,13 @@ def _worker(rank, world, port, q):
         total = comm.allreduce_scalar(local, "sum")
         ref = -O.cum_proba_cs(vals, tracks, 0.02, [1], None, 1, 6)
         covered = comm.allreduce_scalar(sum(len(b) for b in t_loc), "sum")
+        # ordered gather of per-rank row blocks (what predict_Bs(comm=...) uses): rank 0 must get the rows in input order
+        local = {k: v[slice(*shard_range(len(v), rank, world))] for k, v in tracks.items()}
+        full = comm.gather_rows(local)
+        if rank == 0:
+            assert all(np.array_equal(full[k], tracks[k]) for k in tracks)
+        else:
+            assert full is None
         q.put((rank, total, ref, covered, [shard_range(41, r, world) for r in range(world)]))
     finally:
         dist.destroy_process_group()
