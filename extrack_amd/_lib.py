@@ -15,7 +15,7 @@ EXPORTS = [
     "extrack_abi_version", "extrack_create", "extrack_destroy", "extrack_last_error", "extrack_set_stream",
     "extrack_upload_bucket", "extrack_attach_bucket", "extrack_clear_buckets", "extrack_bucket_count",
     "extrack_loglik", "extrack_loglik_async", "extrack_predict", "extrack_last_kernel_ms",
-    "extrack_last_launch_info", "extrack_p_stay_table",
+    "extrack_last_launch_info", "extrack_p_stay_table", "extrack_loglik_th", "extrack_th_plan_step",
 ]
 
 _dp = C.POINTER(C.c_double)
@@ -88,7 +88,9 @@ def load():
     lib.extrack_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.extrack_last_launch_info.argtypes = [vp, C.POINTER(i32 * 6)]
     lib.extrack_p_stay_table.argtypes = [vp, i32, i32, vp, i32, vp]
-    if lib.extrack_abi_version() != 1:
+    lib.extrack_loglik_th.argtypes = [vp, C.POINTER(ExtrackModel), C.c_double, i32, i32, _dp, vp]
+    lib.extrack_th_plan_step.argtypes = [vp, i32, i64, i32, C.POINTER(i32), C.POINTER(i32), vp, vp, i32]
+    if lib.extrack_abi_version() != 2:
         raise ImportError("libextrack_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -202,6 +204,26 @@ class Context:
         out = np.empty(self.n_tracks()) if per_track else None
         self._check(self._lib.extrack_loglik(self._h, C.byref(model.c), C.byref(tot), out.ctypes.data_as(C.c_void_p) if per_track else None))
         return (tot.value, out) if per_track else tot.value
+
+    def loglik_th(self, model, threshold=0.2, max_nb_states=120, chunk=2000, per_track=False):
+        """Threshold-fusion log-likelihood (extrack/tracking.py:427-743 semantics, see include/extrack_hip.h)."""
+        tot = C.c_double(0.0)
+        out = np.empty(self.n_tracks()) if per_track else None
+        self._check(self._lib.extrack_loglik_th(self._h, C.byref(model.c), C.c_double(threshold), int(max_nb_states), int(chunk),
+                                                C.byref(tot), out.ctypes.data_as(C.c_void_p) if per_track else None))
+        return (tot.value, out) if per_track else tot.value
+
+    def th_plan_step(self, bucket_id, chunk_index, t):
+        """Merge groups (list of index arrays) decided at step t for one chunk by the last loglik_th call."""
+        nE, nG = C.c_int32(0), C.c_int32(0)
+        self._check(self._lib.extrack_th_plan_step(self._h, int(bucket_id), int(chunk_index), int(t), C.byref(nE), C.byref(nG), None, None, 0))
+        if nG.value == 0:
+            return nE.value, []
+        mem = np.zeros(nE.value, np.uint16)
+        gst = np.zeros(nG.value + 1, np.uint16)
+        self._check(self._lib.extrack_th_plan_step(self._h, int(bucket_id), int(chunk_index), int(t), C.byref(nE), C.byref(nG),
+                                                   mem.ctypes.data_as(C.c_void_p), gst.ctypes.data_as(C.c_void_p), max(len(mem), len(gst))))
+        return nE.value, [mem[gst[g]:gst[g + 1]].astype(int) for g in range(nG.value)]
 
     def loglik_async(self, model, d_total_ptr=None):
         self._check(self._lib.extrack_loglik_async(self._h, C.byref(model.c), C.c_void_p(d_total_ptr) if d_total_ptr else None))

@@ -16,6 +16,7 @@
 #include "xt_entry.h"
 #include "xt_fast2.h"
 #include "xt_tables.h"
+#include "xt_th.h"
 
 // ------------------------------------------------------------------------------------------------
 // device side
@@ -39,6 +40,13 @@ struct DevCtx {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    // number of lanes below this one with flag set; total = lanes of the wave with flag set
+    __device__ __forceinline__ int wave_rank(bool flag, int& total)
+    {
+        const unsigned long long b = __ballot(flag);
+        total = __popcll(b);
+        return __popcll(b & ((1ull << (threadIdx.x & 63)) - 1ull));
     }
     __device__ __forceinline__ int shfl_xor_i32(int v, int m) { return __shfl_xor(v, m, 64); }
     __device__ __forceinline__ double shfl_xor_f64(double v, int m) { return __shfl_xor(v, m, 64); }
@@ -75,6 +83,20 @@ __global__ void __launch_bounds__(MAXT) xt_entry_kernel(XtKernelArgs a)
     xt_entry_body<GP, D, K>(a, cx);
 }
 
+template <int D, int K>
+__global__ void __launch_bounds__(256) xt_th_plan_kernel(XtThArgs a)
+{
+    DevCtx cx;
+    xt_th_plan_body<D, K>(a, cx);
+}
+
+template <int D, int K>
+__global__ void __launch_bounds__(256) xt_th_apply_kernel(XtThArgs a)
+{
+    DevCtx cx;
+    xt_th_apply_body<D, K>(a, cx);
+}
+
 // Fixed-order reduction of the per-block partial sums (deterministic for a given launch geometry).
 __global__ void __launch_bounds__(256) xt_reduce_partials(const double* __restrict__ partials, int n, double* __restrict__ out)
 {
@@ -100,6 +122,13 @@ struct XtBucket {
     int64_t N = 0;
     int L = 0, D = 0, KS = 0;
     double* d_ll = nullptr;  // per-track output, allocated on first request
+    // threshold-fusion plan of the last extrack_loglik_th call (xt_th.h)
+    uint16_t* th_members = nullptr;
+    uint16_t* th_gstart = nullptr;
+    int32_t* th_hdr = nullptr;
+    int32_t* th_status = nullptr;
+    int th_capE = 0, th_chunk = 0;
+    int64_t th_nchunks = 0;
 };
 
 struct extrack_ctx {
@@ -125,6 +154,11 @@ struct extrack_ctx {
     bool timed = false;
     int32_t launch_info[6] = {0, 0, 0, 0, 0, 0};
     std::map<std::pair<const void*, std::pair<int, size_t>>, int> occ_cache;
+    double* d_th_ws = nullptr;  // plan-kernel workspace
+    size_t th_ws_cap = 0;
+    int th_capE = 128;          // plan capacity (expanded sequences per step); grows on overflow
+    std::vector<int32_t> th_status_host;
+    float th_plan_ms = 0.f;
     std::string err;
 };
 
@@ -208,6 +242,10 @@ static void xt_free_bucket(XtBucket& b)
         if (b.d_sigma) (void)hipFree((void*)b.d_sigma);
     }
     if (b.d_ll) (void)hipFree(b.d_ll);
+    if (b.th_members) (void)hipFree(b.th_members);
+    if (b.th_gstart) (void)hipFree(b.th_gstart);
+    if (b.th_hdr) (void)hipFree(b.th_hdr);
+    if (b.th_status) (void)hipFree(b.th_status);
     b = XtBucket();
 }
 
@@ -227,6 +265,7 @@ extern "C" void extrack_destroy(extrack_ctx* ctx)
     extrack_clear_buckets(ctx);
     if (ctx->d_base_tab) (void)hipFree(ctx->d_base_tab);
     if (ctx->d_off_tab) (void)hipFree(ctx->d_off_tab);
+    if (ctx->d_th_ws) (void)hipFree(ctx->d_th_ws);
     if (ctx->d_blob) (void)hipFree(ctx->d_blob);
     if (ctx->h_blob) (void)hipHostFree(ctx->h_blob);
     if (ctx->d_partials) (void)hipFree(ctx->d_partials);
@@ -323,6 +362,43 @@ static int xt_validate_model(extrack_ctx* ctx, const extrack_model* m)
     return EXTRACK_OK;
 }
 
+static void xt_model_host(const extrack_model* m, XtModelHost& mh)
+{
+    mh.S = m->n_states;
+    mh.NS = m->nb_substeps;
+    mh.locerr_dims = m->locerr_mode == 0 ? m->locerr_dims : 1;
+    for (int k = 0; k < 3; ++k) mh.locerr[k] = m->locerr[k];
+    mh.slope = m->slope;
+    mh.offset = m->offset;
+    mh.pBL = m->pBL;
+    mh.ds = m->ds;
+    mh.Fs = m->Fs;
+    mh.TrMat = m->TrMat;
+    mh.p_stay = m->p_stay;
+}
+
+// Ships a model blob through the pinned staging buffer to ctx->d_blob (stream-ordered).
+static int xt_upload_blob(extrack_ctx* ctx, const std::vector<double>& blob)
+{
+    if (blob.size() > ctx->blob_cap) {
+        XT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->d_blob) (void)hipFree(ctx->d_blob);
+        if (ctx->h_blob) (void)hipHostFree(ctx->h_blob);
+        ctx->d_blob = nullptr;
+        ctx->h_blob = nullptr;
+        ctx->blob_cap = 0;
+        XT_HIP(ctx, hipMalloc(&ctx->d_blob, blob.size() * sizeof(double)));
+        XT_HIP(ctx, hipHostMalloc(&ctx->h_blob, blob.size() * sizeof(double), hipHostMallocDefault));
+        ctx->blob_cap = blob.size();
+    } else {
+        // the pinned staging buffer may still be in flight from the previous evaluation
+        XT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    memcpy(ctx->h_blob, blob.data(), blob.size() * sizeof(double));
+    XT_HIP(ctx, hipMemcpyAsync(ctx->d_blob, ctx->h_blob, blob.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    return EXTRACK_OK;
+}
+
 // (Re)builds the digit-slot tables when (S, ns, F) changes and uploads the model blob.
 static int xt_prepare(extrack_ctx* ctx, const extrack_model* m)
 {
@@ -341,36 +417,10 @@ static int xt_prepare(extrack_ctx* ctx, const extrack_model* m)
         ctx->cfg = c;
     }
     XtModelHost mh;
-    mh.S = m->n_states;
-    mh.NS = m->nb_substeps;
-    mh.locerr_dims = m->locerr_mode == 0 ? m->locerr_dims : 1;
-    for (int k = 0; k < 3; ++k) mh.locerr[k] = m->locerr[k];
-    mh.slope = m->slope;
-    mh.offset = m->offset;
-    mh.pBL = m->pBL;
-    mh.ds = m->ds;
-    mh.Fs = m->Fs;
-    mh.TrMat = m->TrMat;
-    mh.p_stay = m->p_stay;
+    xt_model_host(m, mh);
     std::vector<double> blob;
     xt_build_blob(mh, ctx->cfg, blob);
-    if (blob.size() > ctx->blob_cap) {
-        XT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (ctx->d_blob) (void)hipFree(ctx->d_blob);
-        if (ctx->h_blob) (void)hipHostFree(ctx->h_blob);
-        ctx->d_blob = nullptr;
-        ctx->h_blob = nullptr;
-        ctx->blob_cap = 0;
-        XT_HIP(ctx, hipMalloc(&ctx->d_blob, blob.size() * sizeof(double)));
-        XT_HIP(ctx, hipHostMalloc(&ctx->h_blob, blob.size() * sizeof(double), hipHostMallocDefault));
-        ctx->blob_cap = blob.size();
-    } else {
-        // the pinned staging buffer may still be in flight from the previous evaluation
-        XT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    }
-    memcpy(ctx->h_blob, blob.data(), blob.size() * sizeof(double));
-    XT_HIP(ctx, hipMemcpyAsync(ctx->d_blob, ctx->h_blob, blob.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    return EXTRACK_OK;
+    return xt_upload_blob(ctx, blob);
 }
 
 struct DevLauncher {
@@ -633,6 +683,240 @@ extern "C" int extrack_predict(extrack_ctx* ctx, const extrack_model* m, int32_t
     }
     (void)hipFree(d_preds);
     return rc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// threshold-fusion variant (xt_th.h): plan kernel + apply kernel per bucket
+// ------------------------------------------------------------------------------------------------
+template <class KernT>
+static hipError_t xt_th_set_lds(extrack_ctx* ctx, KernT kern, size_t lds)
+{
+    if (lds <= 64 * 1024) return hipSuccess;
+    return hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+}
+
+template <int D, int K>
+static hipError_t xt_th_launch_plan(extrack_ctx* ctx, const XtThArgs& a, int grid, size_t lds)
+{
+    hipError_t e = xt_th_set_lds(ctx, xt_th_plan_kernel<D, K>, lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((xt_th_plan_kernel<D, K>), dim3(grid), dim3(256), lds, ctx->stream, a);
+    return hipGetLastError();
+}
+
+template <int D, int K>
+static hipError_t xt_th_launch_apply(extrack_ctx* ctx, const XtThArgs& a, int grid, int threads, size_t lds)
+{
+    hipError_t e = xt_th_set_lds(ctx, xt_th_apply_kernel<D, K>, lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((xt_th_apply_kernel<D, K>), dim3(grid), dim3(threads), lds, ctx->stream, a);
+    return hipGetLastError();
+}
+
+static int xt_th_reserve_plan(extrack_ctx* ctx, XtBucket& b, int chunk, int capE)
+{
+    const int64_t nchunks = (b.N + chunk - 1) / chunk;
+    if (b.th_members && b.th_capE == capE && b.th_chunk == chunk && b.th_nchunks == nchunks) return EXTRACK_OK;
+    XT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (b.th_members) (void)hipFree(b.th_members);
+    if (b.th_gstart) (void)hipFree(b.th_gstart);
+    if (b.th_hdr) (void)hipFree(b.th_hdr);
+    if (b.th_status) (void)hipFree(b.th_status);
+    b.th_members = b.th_gstart = nullptr;
+    b.th_hdr = b.th_status = nullptr;
+    XT_HIP(ctx, hipMalloc(&b.th_members, (size_t)nchunks * b.L * capE * sizeof(uint16_t)));
+    XT_HIP(ctx, hipMalloc(&b.th_gstart, (size_t)nchunks * b.L * (capE + 1) * sizeof(uint16_t)));
+    XT_HIP(ctx, hipMalloc(&b.th_hdr, (size_t)nchunks * b.L * 2 * sizeof(int32_t)));
+    XT_HIP(ctx, hipMalloc(&b.th_status, (size_t)nchunks * 4 * sizeof(int32_t)));
+    b.th_capE = capE;
+    b.th_chunk = chunk;
+    b.th_nchunks = nchunks;
+    return EXTRACK_OK;
+}
+
+extern "C" int extrack_loglik_th(extrack_ctx* ctx, const extrack_model* m, double threshold, int32_t max_nb_states, int32_t chunk,
+                                 double* total_ll, double* per_track)
+{
+    if (!ctx || !total_ll) return xt_fail(ctx, EXTRACK_E_INVALID, "null argument");
+    int rc = xt_validate_model(ctx, m);
+    if (rc) return rc;
+    if (ctx->buckets.empty()) return xt_fail(ctx, EXTRACK_E_INVALID, "no bucket uploaded");
+    if (chunk < 1) return xt_fail(ctx, EXTRACK_E_INVALID, "chunk must be >= 1");
+    if (!(threshold >= 0.0)) return xt_fail(ctx, EXTRACK_E_INVALID, "threshold must be >= 0");
+    if (m->frame_len <= m->nb_substeps || m->frame_len > 15) return xt_fail(ctx, EXTRACK_E_INVALID, "frame_len must be in (nb_substeps, 15]");
+    XT_HIP(ctx, hipSetDevice(ctx->device));
+    XtModelHost mh;
+    xt_model_host(m, mh);
+    std::vector<double> blob;
+    int G = 0;
+    std::string err = xt_th_build_blob(mh, blob, G);
+    if (!err.empty()) return xt_fail(ctx, EXTRACK_E_INVALID, err);
+    if ((rc = xt_upload_blob(ctx, blob))) return rc;
+    const int S = m->n_states, NS = m->nb_substeps, F = m->frame_len;
+    if (S * G > XT_TH_MAXCAP) return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "n_states^(nb_substeps+1) exceeds the plan capacity");
+    if ((rc = xt_reserve_partials(ctx, ctx->buckets.size() * xt_max_grid(ctx)))) return rc;
+    if (per_track)
+        for (auto& b : ctx->buckets)
+            if (!b.d_ll) XT_HIP(ctx, hipMalloc(&b.d_ll, (size_t)b.N * sizeof(double)));
+    size_t poff = 0;
+    float plan_ms = 0.f;
+    XT_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    for (auto& b : ctx->buckets) {
+        const int D = b.D;
+        int K;
+        if (m->locerr_mode == 0) {
+            K = m->locerr_dims;
+        } else {
+            if (!b.d_sigma) return xt_fail(ctx, EXTRACK_E_INVALID, "per-peak localisation error mode but the bucket has no sigma");
+            K = b.KS;
+        }
+        XtThArgs a;
+        memset(&a, 0, sizeof(a));
+        a.tracks = b.d_tracks;
+        a.sigma = m->locerr_mode ? b.d_sigma : nullptr;
+        a.blob = ctx->d_blob;
+        a.ll_out = per_track ? b.d_ll : nullptr;
+        a.N = b.N;
+        a.L = b.L;
+        a.S = S;
+        a.NS = NS;
+        a.G = G;
+        a.F = F;
+        a.isBL = (b.L != m->max_len) ? 1 : 0;  // tracking.py:1037-1040
+        a.min_len = m->min_len;
+        a.locerr_mode = m->locerr_mode;
+        a.KS = b.KS ? b.KS : 1;
+        a.chunk = chunk;
+        a.nchunks = (int32_t)((b.N + chunk - 1) / chunk);
+        a.max_nb = max_nb_states;
+        a.threshold = threshold;
+        a.ll_const = -(double)(b.L - 1) * D * 0.5 * XT_LOG2PI;
+        hipError_t e = hipSuccess;
+        int maxG = 0;
+        for (;;) {  // plan, growing the capacity on overflow
+            int capE = ctx->th_capE;
+            while (capE < S * G) capE *= 2;
+            ctx->th_capE = capE;
+            if ((rc = xt_th_reserve_plan(ctx, b, chunk, capE))) return rc;
+            a.capE = capE;
+            a.members = b.th_members;
+            a.gstart = b.th_gstart;
+            a.hdr = b.th_hdr;
+            a.status = b.th_status;
+            const int grid = std::min<int64_t>(a.nchunks, (int64_t)ctx->n_cu * 2);
+            a.ws_stride = xt_th_ws_doubles(capE, D, K, F, NS, S);
+            const size_t need = (size_t)a.ws_stride * grid * sizeof(double);
+            if (need > ctx->th_ws_cap) {
+                XT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                if (ctx->d_th_ws) (void)hipFree(ctx->d_th_ws);
+                ctx->d_th_ws = nullptr;
+                ctx->th_ws_cap = 0;
+                XT_HIP(ctx, hipMalloc(&ctx->d_th_ws, need));
+                ctx->th_ws_cap = need;
+            }
+            a.ws = ctx->d_th_ws;
+            const size_t lds = (size_t)xt_th_plan_lds_doubles(S, G, capE, D, K) * sizeof(double);
+            if (lds > 160 * 1024) return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "plan tables do not fit the 160 KiB LDS of a CU");
+#define XT_TH_PLAN_CALL(...) xt_th_launch_plan<__VA_ARGS__>(ctx, a, grid, lds)
+            if (D == 1 && K == 1) e = XT_TH_PLAN_CALL(1, 1);
+            else if (D == 2 && K == 1) e = XT_TH_PLAN_CALL(2, 1);
+            else if (D == 2 && K == 2) e = XT_TH_PLAN_CALL(2, 2);
+            else if (D == 3 && K == 1) e = XT_TH_PLAN_CALL(3, 1);
+            else if (D == 3 && K == 3) e = XT_TH_PLAN_CALL(3, 3);
+            else return xt_fail(ctx, EXTRACK_E_INVALID, "locerr_dims must be 1 or the track dimensionality");
+#undef XT_TH_PLAN_CALL
+            if (e != hipSuccess) return xt_fail(ctx, EXTRACK_E_HIP, std::string("plan kernel launch: ") + hipGetErrorString(e));
+            ctx->th_status_host.resize((size_t)a.nchunks * 4);
+            XT_HIP(ctx, hipMemcpyAsync(ctx->th_status_host.data(), b.th_status, (size_t)a.nchunks * 4 * sizeof(int32_t), hipMemcpyDeviceToHost,
+                                       ctx->stream));
+            XT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            int over = 0, maxE = 0;
+            maxG = 0;
+            for (int c = 0; c < a.nchunks; ++c) {
+                over |= ctx->th_status_host[(size_t)c * 4];
+                maxE = std::max(maxE, ctx->th_status_host[(size_t)c * 4 + 1]);
+                maxG = std::max(maxG, ctx->th_status_host[(size_t)c * 4 + 2]);
+            }
+            if (!over) break;
+            int ncap = capE;
+            while (ncap < maxE) ncap *= 2;
+            if (ncap == capE) ncap *= 2;
+            if (ncap > XT_TH_MAXCAP)
+                return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "more than 8192 live state sequences per step: raise threshold or lower max_nb_states");
+            ctx->th_capE = ncap;
+        }
+        // apply geometry: as many tracks of a chunk per workgroup as keep the tile within ~48 KiB of LDS
+        a.capG = maxG;
+        int TT = 64;
+        while (TT > 1 && (TT > chunk * 2 || (size_t)xt_th_apply_lds_doubles(S, G, maxG, TT, D, K, a.KS) * 8 > 48 * 1024)) TT >>= 1;
+        size_t lds = (size_t)xt_th_apply_lds_doubles(S, G, maxG, TT, D, K, a.KS) * 8;
+        if (lds > 160 * 1024) return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "live state sequences do not fit the 160 KiB LDS of a CU");
+        a.TT = TT;
+        int threads = (maxG * TT + 63) / 64 * 64;
+        threads = threads > 256 ? 256 : threads;
+        threads = threads < TT ? TT : threads;
+        const int64_t tpc = (chunk + TT - 1) / TT;
+        const int64_t ntiles = (int64_t)a.nchunks * tpc;
+        int blocks_per_cu = (int)std::min<size_t>(8, (160 * 1024) / lds);
+        blocks_per_cu = std::max(1, std::min(blocks_per_cu, 2048 / threads));
+        const int grid = (int)std::min<int64_t>(ntiles, (int64_t)ctx->n_cu * blocks_per_cu * ctx->oversub);
+        if ((size_t)grid > xt_max_grid(ctx)) return xt_fail(ctx, EXTRACK_E_HIP, "internal: grid exceeds the partial-sum reservation");
+        a.partials = ctx->d_partials + poff;
+#define XT_TH_APPLY_CALL(...) xt_th_launch_apply<__VA_ARGS__>(ctx, a, grid, threads, lds)
+        if (D == 1 && K == 1) e = XT_TH_APPLY_CALL(1, 1);
+        else if (D == 2 && K == 1) e = XT_TH_APPLY_CALL(2, 1);
+        else if (D == 2 && K == 2) e = XT_TH_APPLY_CALL(2, 2);
+        else if (D == 3 && K == 1) e = XT_TH_APPLY_CALL(3, 1);
+        else e = XT_TH_APPLY_CALL(3, 3);
+#undef XT_TH_APPLY_CALL
+        if (e != hipSuccess) return xt_fail(ctx, EXTRACK_E_HIP, std::string("apply kernel launch: ") + hipGetErrorString(e));
+        poff += (size_t)grid;
+        ctx->launch_info[0] = grid;
+        ctx->launch_info[1] = threads;
+        ctx->launch_info[2] = (int32_t)lds;
+        ctx->launch_info[3] = TT;
+        ctx->launch_info[4] = blocks_per_cu;
+        ctx->launch_info[5] = ctx->n_cu;
+    }
+    (void)plan_ms;
+    XT_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    ctx->timed = true;
+    hipLaunchKernelGGL(xt_reduce_partials, dim3(1), dim3(256), 0, ctx->stream, ctx->d_partials, (int)poff, ctx->d_total);
+    XT_HIP(ctx, hipGetLastError());
+    XT_HIP(ctx, hipMemcpyAsync(ctx->h_total, ctx->d_total, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (per_track) {
+        size_t o = 0;
+        for (auto& b : ctx->buckets) {
+            XT_HIP(ctx, hipMemcpyAsync(per_track + o, b.d_ll, (size_t)b.N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+            o += (size_t)b.N;
+        }
+    }
+    XT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *total_ll = *ctx->h_total;
+    return EXTRACK_OK;
+}
+
+extern "C" int extrack_th_plan_step(extrack_ctx* ctx, int32_t bucket_id, int64_t chunk_index, int32_t t, int32_t* n_expanded,
+                                    int32_t* n_groups, uint16_t* members, uint16_t* gstart, int32_t cap)
+{
+    if (!ctx || !n_expanded || !n_groups) return xt_fail(ctx, EXTRACK_E_INVALID, "null argument");
+    if (bucket_id < 0 || bucket_id >= (int)ctx->buckets.size()) return xt_fail(ctx, EXTRACK_E_INVALID, "bucket id out of range");
+    XtBucket& b = ctx->buckets[bucket_id];
+    if (!b.th_members) return xt_fail(ctx, EXTRACK_E_INVALID, "no threshold-fusion evaluation has run on this bucket");
+    if (chunk_index < 0 || chunk_index >= b.th_nchunks || t < 1 || t > b.L - 1) return xt_fail(ctx, EXTRACK_E_INVALID, "chunk or step out of range");
+    XT_HIP(ctx, hipSetDevice(ctx->device));
+    XT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    int32_t h[2];
+    XT_HIP(ctx, hipMemcpy(h, b.th_hdr + ((size_t)chunk_index * b.L + t) * 2, sizeof(h), hipMemcpyDeviceToHost));
+    *n_expanded = h[0];
+    *n_groups = h[1];
+    if (members && gstart && h[1] > 0) {
+        if (cap < h[0] || cap < h[1] + 1) return xt_fail(ctx, EXTRACK_E_INVALID, "output capacity too small");
+        XT_HIP(ctx, hipMemcpy(members, b.th_members + ((size_t)chunk_index * b.L + t) * b.th_capE, (size_t)h[0] * sizeof(uint16_t), hipMemcpyDeviceToHost));
+        XT_HIP(ctx, hipMemcpy(gstart, b.th_gstart + ((size_t)chunk_index * b.L + t) * (b.th_capE + 1), (size_t)(h[1] + 1) * sizeof(uint16_t),
+                              hipMemcpyDeviceToHost));
+    }
+    return EXTRACK_OK;
 }
 
 extern "C" int extrack_last_kernel_ms(extrack_ctx* ctx, float* ms)

@@ -144,6 +144,67 @@ static inline void xt_build_blob(const XtModelHost& m, const XtConfig& c, std::v
     }
 }
 
+// Model tables of the threshold-fusion kernels (xt_th.h): same five [prev][.] tables and header as xt_build_blob, but the
+// second index is r in the REFERENCE's digit order (digit c of r = c-th newest sub-state, tracking.py:548-551), which is
+// how the expanded sequence index j = parent * S^ns + r of P_Cs_inter_bound_stats_th is laid out.
+static inline std::string xt_th_build_blob(const XtModelHost& m, std::vector<double>& blob, int& G_out)
+{
+    const int S = m.S, NS = m.NS;
+    if (S < 2 || S > XT_MAX_STATES) return "n_states must be in [2, 8]";
+    if (NS < 1 || NS > 4) return "nb_substeps must be in [1, 4]";
+    int G = 1;
+    for (int i = 0; i < NS; ++i) G *= S;
+    G_out = G;
+    blob.assign((size_t)xt_tab_doubles(S, G), 0.0);
+    for (int j = 0; j < 64; ++j) blob[(size_t)XT_BLOB_HDR + (size_t)XT_NTAB * S * G + j] = exp2((double)j / 64.0);
+    for (int k = 0; k < 3; ++k) {
+        const double s = m.locerr[k < m.locerr_dims ? k : 0];
+        blob[k] = s * s;
+    }
+    blob[3] = m.slope;
+    blob[4] = m.offset;
+    for (int s = 0; s < S; ++s) blob[8 + s] = m.Fs[s];
+    std::vector<double> v(S), w(S);
+    for (int s = 0; s < S; ++s) {
+        const double ps = m.p_stay[s];  // raw newest state as index (reference quirk, tracking.py:624)
+        v[s] = m.pBL + (1.0 - ps) - m.pBL * (1.0 - ps);
+    }
+    for (int it = 0; it < NS; ++it) {
+        for (int i = 0; i < S; ++i) {
+            double acc = 0.0;
+            for (int j = 0; j < S; ++j) acc += m.TrMat[i * S + j] * v[j];
+            w[i] = acc;
+        }
+        v = w;
+    }
+    double* TAB = blob.data() + XT_BLOB_HDR;
+    const size_t SG = (size_t)S * G;
+    for (int prev = 0; prev < S; ++prev)
+        for (int r = 0; r < G; ++r) {
+            int dig[8], rr = r;
+            for (int c = 0; c < NS; ++c) {
+                dig[c] = rr % S;  // c-th newest
+                rr /= S;
+            }
+            dig[NS] = prev;
+            double tp = 1.0, d2 = 0.0;
+            for (int c = 0; c < NS; ++c) {
+                tp *= m.TrMat[dig[c + 1] * S + dig[c]];
+                d2 += (m.ds[dig[c]] * m.ds[dig[c]] + m.ds[dig[c + 1]] * m.ds[dig[c + 1]]) / 2.0;
+            }
+            d2 /= NS;
+            const double stay = m.p_stay[r] * (1.0 - m.pBL);
+            const double ee = v[dig[0]];
+            const size_t o = (size_t)prev * G + r;
+            TAB[0 * SG + o] = tp;
+            TAB[1 * SG + o] = tp * stay;
+            TAB[2 * SG + o] = tp * ee;
+            TAB[3 * SG + o] = tp * stay * ee;
+            TAB[4 * SG + o] = d2;
+        }
+    return "";
+}
+
 static inline void xt_fill_args_from_config(const XtConfig& c, XtKernelArgs& a)
 {
     a.S = c.S;

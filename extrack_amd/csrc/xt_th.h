@@ -1,0 +1,674 @@
+// Threshold-fusion track likelihood: the kernel bodies shared by the HIP kernels (extrack_hip.hip) and by the
+// CPU-thread emulator used in tests (tests/emul).
+//
+// What it computes (reference, relative to /root/reference/):
+//   extrack/tracking.py:427-650  P_Cs_inter_bound_stats_th   (the variant param_fitting / predict_Bs call in v1.6.3)
+//   extrack/tracking.py:652-743  fuse_tracks_th              (greedy, data-dependent grouping of state sequences)
+//   extrack/tracking.py:769-787  Proba_Cs                    (per-track log-sum)
+// The reference decides WHICH sequences to merge at a step from the first 30 tracks of a chunk ("pilot" tracks,
+// tracking.py:678-679) and applies that decision to every track of the chunk (2000 tracks in cum_Proba_Cs,
+// tracking.py:1043).  The result is therefore a function of (track, chunk), not of the track alone.
+//
+// How it is organised for CDNA4 (NOT the reference's data flow):
+//   * PLAN kernel (xt_th_plan_body): one workgroup per chunk walks the recursion for the <= 30 pilot tracks and runs the
+//     greedy grouping on the device; output = the "plan" of the chunk: for every step the member lists of the merge
+//     groups (CSR: members[] sorted by group, gstart[]).  The state-history bookkeeping the reference uses for its
+//     "same last frame_len states" rule (the `cat` array, averaged with np.mean at every merge, tracking.py:729) is
+//     carried in fp64 with numpy's summation order, so that argmax ties resolve as they do in the reference.
+//   * APPLY kernel (xt_th_apply_body): every track of the chunk follows the plan.  Sequence weights are linear-domain
+//     extended-range numbers (zm * 2^ze) as in xt_kernel.h.  The Gaussian integration of a position depends only on the
+//     PARENT sequence (mean, variance), not on the new state digits, so it is done once per parent (one exp, one rcp)
+//     and the expansion by the S^ns new digits is folded into the merge: a group's new weight/mean/variance is a
+//     gather over its members (parent, new digits) of table lookups and FMAs.  The expanded S^ns-fold array of the
+//     reference never exists.  State lives in LDS as [sequence][field][track] with TT tracks of ONE chunk per workgroup
+//     (same plan -> uniform control flow, conflict-free LDS rows, the plan is staged once per step per workgroup).
+#pragma once
+#include "xt_kernel.h"
+
+#define XT_TH_PILOT 30  // tracking.py:678-679
+#define XT_TH_STAGE 8   // positions staged in LDS per refill (apply kernel)
+#define XT_TH_MAXCAP 8192
+
+struct XtThArgs {
+    const double* tracks;  // [N][L][D]
+    const double* sigma;   // [N][L][KS] or nullptr
+    const double* blob;    // model tables, [prev][r] with r in the reference's digit order (digit 0 = newest sub-state)
+    double* ll_out;        // [N] or nullptr
+    double* partials;      // [grid] per-block LL sums (apply kernel)
+    int64_t N;
+    int32_t L, S, NS, G, F;
+    int32_t isBL, min_len, locerr_mode, KS;
+    int32_t chunk, nchunks;
+    int32_t capE;          // plan capacity: expanded sequences per step
+    int32_t max_nb;        // max_nb_states (tracking.py:601-602: threshold *= 1.2 while exceeded)
+    double threshold;
+    double ll_const;       // -(L-1)*D/2*log(2*pi)
+    uint16_t* members;     // [nchunks][L][capE]
+    uint16_t* gstart;      // [nchunks][L][capE + 1]
+    int32_t* hdr;          // [nchunks][L][2]: nE (expanded sequences at step t), nG (groups after the merge, 0 if none)
+    int32_t* status;       // [nchunks][4]: overflow flag, max nE, max nG, -
+    double* ws;            // plan-kernel workspace, ws_stride doubles per workgroup
+    int64_t ws_stride;
+    int32_t TT;            // apply kernel: tracks per workgroup tile (power of two)
+    int32_t capG;          // apply kernel: parent-sequence capacity of the LDS buffers
+};
+
+// View of a parent-sequence state buffer: entry (g, x) of track/pilot x lives at index g * gs + x * xs of every plane.
+struct XtThBuf {
+    double* zm;
+    double* m;  // [D] planes
+    double* u;  // [K] planes: variance (after a merge: s2 incl. the diffusion term; after an integration: l2*s2/(l2+s2))
+    int* ze;
+    int plane;
+};
+
+XT_HD int xt_th_hm(int F, int NS) { return F + NS; }
+XT_HD int64_t xt_th_buf_doubles(int plane, int D, int K) { return (int64_t)plane * (1 + D + K) + (plane + 1) / 2; }
+XT_HD int64_t xt_th_ws_doubles(int capE, int D, int K, int F, int NS, int S)
+{
+    const int plane = XT_TH_PILOT * capE;
+    return 2 * xt_th_buf_doubles(plane, D, K) + (int64_t)K * plane + 2 * (int64_t)capE * xt_th_hm(F, NS) * S + 2 * (int64_t)capE + 8;
+}
+XT_HD int xt_th_plan_lds_doubles(int S, int G, int capE, int D, int K)
+{
+    // tables | pivot m, s | wave counts | bytes: newest[2][capE], grouped[capE], mem u16[capE], gst u16[capE + 1]
+    const int bytes = 3 * capE + 2 * capE + 2 * (capE + 1);
+    return ((xt_tab_doubles(S, G) + 1) & ~1) + XT_TH_PILOT * (D + K) + 8 + (bytes + 7) / 8 + 2;
+}
+XT_HD int xt_th_apply_lds_doubles(int S, int G, int capG, int TT, int D, int K, int KS)
+{
+    const int plane = capG * TT;
+    const int capEl = capG * G;
+    const int bytes = 2 * capG + 2 * capEl + 2 * (capEl + 1) + 4 * TT;
+    return ((xt_tab_doubles(S, G) + 1) & ~1) + 2 * (int)xt_th_buf_doubles(plane, D, K) + XT_TH_STAGE * (D + KS) * (TT + 1) + TT + (bytes + 7) / 8 + 2;
+}
+
+XT_HD void xt_th_carve(double*& w, XtThBuf& b, int plane, int D, int K)
+{
+    b.zm = w;
+    b.m = b.zm + plane;
+    b.u = b.m + (int64_t)D * plane;
+    b.ze = (int*)(b.u + (int64_t)K * plane);
+    b.plane = plane;
+    w += xt_th_buf_doubles(plane, D, K);
+}
+
+// Gaussian integration of one position into one parent sequence, in place (tracking.py:76-98 log_integrale_dif without
+// the diffusion term, which depends on the new digits and is added in the gather).
+template <int D, int K>
+XT_HD void xt_th_integrate(const XtThBuf& b, int idx, const double* c, const double* l2, const double* T64)
+{
+    const double z = b.zm[idx];
+    double dm[D], dsq = 0.0;
+    for (int d = 0; d < D; ++d) {
+        dm[d] = c[d] - b.m[d * b.plane + idx];
+        dsq = xt_fma(dm[d], dm[d], dsq);
+    }
+    double quad, gf, tt[K];
+    if (K == 1) {
+        const double s2 = b.u[idx];
+        const double r = xt_rcp(l2[0] + s2);
+        tt[0] = s2 * r;
+        quad = 0.5 * dsq * r;
+        gf = xt_pow_half<D>(r);
+    } else {
+        quad = 0.0;
+        gf = 1.0;
+        for (int d = 0; d < D; ++d) {
+            const double s2 = b.u[d * b.plane + idx];
+            const double r = xt_rcp(l2[d] + s2);
+            tt[d] = s2 * r;
+            quad = xt_fma(0.5 * dm[d] * dm[d], r, quad);
+            gf *= r;
+        }
+        gf = sqrt(gf);
+    }
+    double p;
+    int j, n;
+    xt_exp_tab(-quad, p, j, n);
+    b.zm[idx] = z * (gf * T64[j]) * p;
+    const int en = b.ze[idx] + n;
+    b.ze[idx] = (z != 0.0 && en > XT_EMIN) ? en : XT_EMIN;
+    for (int d = 0; d < D; ++d) b.m[d * b.plane + idx] = xt_fma(dm[d], tt[K == 1 ? 0 : d], b.m[d * b.plane + idx]);
+    for (int k = 0; k < K; ++k) b.u[k * b.plane + idx] = l2[k] * tt[k];
+}
+
+// One merge group of one track: gather over the members (parent g = j / G, new digits r = j % G) of the integrated
+// parents in `src`; weight = parent weight * T[newest(parent)][r], variance = parent variance + d2[newest(parent)][r]
+// (tracking.py:548-600 expansion + tracking.py:703-741 softmax-weighted merge, in the linear domain).
+template <int D, int K, class MemT, class NewT>
+XT_HD void xt_th_gather(const XtThBuf& src, int gs, int xoff, const MemT* members, int k0, int k1, int G, const NewT* newest,
+                        const double* TT, const double* TD2, const XtThBuf& dst, int didx)
+{
+    double W = 0.0, M[D], U[K];
+    int E = XT_EMIN;
+    for (int d = 0; d < D; ++d) M[d] = 0.0;
+    for (int k = 0; k < K; ++k) U[k] = 0.0;
+    if (k1 - k0 == 1) {
+        const int j = members[k0];
+        const int g = j / G, r = j - g * G, o = (int)newest[g] * G + r, idx = g * gs + xoff;
+        W = src.zm[idx] * TT[o];
+        E = src.ze[idx];
+        for (int d = 0; d < D; ++d) M[d] = src.m[d * src.plane + idx];
+        for (int k = 0; k < K; ++k) U[k] = src.u[k * src.plane + idx] + TD2[o];
+    } else {
+        for (int kk = k0; kk < k1; ++kk) {
+            const int j = members[kk];
+            const int g = j / G, r = j - g * G, o = (int)newest[g] * G + r, idx = g * gs + xoff;
+            const double wm = src.zm[idx] * TT[o];
+            if (wm == 0.0) continue;
+            const int we = src.ze[idx];
+            double av;
+            if (we > E) {
+                const double sc = xt_ldexp(1.0, E - we);  // E - we may be hugely negative: saturates to 0
+                W *= sc;
+                for (int d = 0; d < D; ++d) M[d] *= sc;
+                for (int k = 0; k < K; ++k) U[k] *= sc;
+                E = we;
+                av = wm;
+            } else {
+                av = xt_ldexp(wm, we - E);
+            }
+            W += av;
+            for (int d = 0; d < D; ++d) M[d] = xt_fma(av, src.m[d * src.plane + idx], M[d]);
+            for (int k = 0; k < K; ++k) U[k] = xt_fma(av, src.u[k * src.plane + idx] + TD2[o], U[k]);
+        }
+        const double rW = (W == 0.0) ? 0.0 : xt_rcp(W);
+        for (int d = 0; d < D; ++d) M[d] *= rW;
+        for (int k = 0; k < K; ++k) U[k] *= rW;
+    }
+    const bool live = W != 0.0;
+    dst.zm[didx] = xt_frexp_mant(W);
+    dst.ze[didx] = live ? E + xt_frexp_exp(W) : XT_EMIN;
+    for (int d = 0; d < D; ++d) dst.m[d * dst.plane + didx] = M[d];
+    for (int k = 0; k < K; ++k) dst.u[k * dst.plane + didx] = U[k];
+}
+
+XT_HD double xt_th_l2_from_sigma(double s, int mode, const double* hdr)
+{
+    if (mode == 2) {
+        s = xt_fma(s, hdr[3], hdr[4]);  // tracking.py:928-930
+        s = s < 1e-6 ? 1e-6 : s;
+    }
+    return s * s;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// PLAN kernel body: one workgroup per chunk.
+// ------------------------------------------------------------------------------------------------------------------
+template <int D, int K, class Ctx>
+XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
+{
+    const int S = a.S, G = a.G, NS = a.NS, F = a.F, L = a.L, capE = a.capE;
+    const int tid = cx.tid(), nt = cx.nthreads();
+    const int HM = xt_th_hm(F, NS);
+    double* smem = cx.smem();
+    const int ntab = xt_tab_doubles(S, G);
+    for (int i = tid; i < ntab; i += nt) smem[i] = a.blob[i];
+    const double* hdr = smem;
+    const double* TAB = smem + XT_BLOB_HDR;
+    const double* T64 = TAB + XT_NTAB * S * G;
+    const double* TD2 = TAB + 4 * S * G;
+    double* pm = smem + ((ntab + 1) & ~1);
+    double* ps = pm + XT_TH_PILOT * D;
+    int* wcnt = (int*)(ps + XT_TH_PILOT * K);
+    uint8_t* newA = (uint8_t*)(wcnt + 16);
+    uint8_t* newB = newA + capE;
+    uint8_t* grouped = newB + capE;
+    uint16_t* mem = (uint16_t*)(grouped + capE + (capE & 1));
+    uint16_t* gst = mem + capE;
+
+    double* w = a.ws + (int64_t)cx.block() * a.ws_stride;
+    const int plane = XT_TH_PILOT * capE;
+    XtThBuf A, B;
+    xt_th_carve(w, A, plane, D, K);
+    xt_th_carve(w, B, plane, D, K);
+    double* sE = w;
+    w += (int64_t)K * plane;
+    double* catA = w;
+    w += (int64_t)capE * HM * S;
+    double* catB = w;
+    w += (int64_t)capE * HM * S;
+    unsigned long long* keyA = (unsigned long long*)w;
+    w += capE;
+    unsigned long long* keyB = (unsigned long long*)w;
+    const int Fk = F - NS;  // parent history entries inside the frame_len window of an expanded sequence
+    int pwS[8];
+    pwS[0] = 1;
+    for (int i = 1; i < 8; ++i) pwS[i] = pwS[i - 1] * S;
+
+    for (int ch = cx.block(); ch < a.nchunks; ch += cx.nblocks()) {
+        const int64_t c0 = (int64_t)ch * a.chunk;
+        const int n = (int)((a.N - c0) < a.chunk ? (a.N - c0) : a.chunk);
+        const int P = n < XT_TH_PILOT ? n : XT_TH_PILOT;
+        uint16_t* mem_g = a.members + (int64_t)ch * L * capE;
+        uint16_t* gst_g = a.gstart + (int64_t)ch * L * (capE + 1);
+        int32_t* hdr_g = a.hdr + (int64_t)ch * L * 2;
+        cx.sync();  // tables loaded / previous chunk done
+
+        auto load_l2 = [&](int x, int pos, double* l2) {
+            if (a.locerr_mode == 0) {
+                for (int k = 0; k < K; ++k) l2[k] = hdr[k];
+            } else {
+                for (int k = 0; k < K; ++k)
+                    l2[k] = xt_th_l2_from_sigma(a.sigma[((c0 + x) * L + pos) * a.KS + (a.KS == 1 ? 0 : k)], a.locerr_mode, hdr);
+            }
+        };
+
+        // ---- position 0: S parents (the oldest state a), history = [a]
+        for (int i = tid; i < P * S; i += nt) {
+            const int x = i / S, s = i - x * S, idx = x * capE + s;
+            double l2[K];
+            load_l2(x, 0, l2);
+            A.zm[idx] = hdr[8 + s];
+            A.ze[idx] = 0;
+            for (int d = 0; d < D; ++d) A.m[d * plane + idx] = a.tracks[((c0 + x) * L + 0) * D + d];
+            for (int k = 0; k < K; ++k) A.u[k * plane + idx] = l2[k];
+        }
+        for (int i = tid; i < S * S; i += nt) catA[(i / S) * HM * S + (i % S)] = (i / S == i % S) ? 1.0 : 0.0;
+        for (int i = tid; i < S; i += nt) newA[i] = (uint8_t)i;
+        int nPar = S, Hc = 1, maxE = 0, maxG = S, overflow = 0, nfuse = 0;
+        double thr = a.threshold;
+        uint8_t *nwA = newA, *nwB = newB;
+        double *ctA = catA, *ctB = catB;
+        unsigned long long *kyA = keyA, *kyB = keyB;
+        XtThBuf bA = A, bB = B;
+        cx.sync();
+
+        for (int t = 1; t <= L - 1; ++t) {
+            if (t >= 2) {
+                const int pos = t - 1;
+                for (int i = tid; i < P * nPar; i += nt) {
+                    const int x = i / nPar, g = i - x * nPar;
+                    double c[D], l2[K];
+                    for (int d = 0; d < D; ++d) c[d] = a.tracks[((c0 + x) * L + pos) * D + d];
+                    load_l2(x, pos, l2);
+                    xt_th_integrate<D, K>(bA, x * capE + g, c, l2, T64);
+                }
+                cx.sync();
+            }
+            const int nE = nPar * G;
+            if (nE > capE) {
+                overflow = 1;
+                maxE = nE;
+                break;
+            }
+            if (t >= 2 && nE > a.max_nb) thr = thr * 1.2;  // tracking.py:601-602
+            maxE = nE > maxE ? nE : maxE;
+            int nG = 0;
+            if (t < L - 1) {
+                const int He = Hc + NS;
+                if (t == 1) {
+                    // the initial S^(ns+1) sequences are not merged (tracking.py:479-534): identity plan
+                    for (int i = tid; i < nE; i += nt) mem[i] = (uint16_t)i;
+                    for (int i = tid; i <= nE; i += nt) gst[i] = (uint16_t)i;
+                    nG = nE;
+                } else {
+                    // ---- greedy grouping on the pilot tracks (tracking.py:652-701)
+                    const bool useA = He > F;
+                    for (int i = tid; i < P * nE; i += nt) {
+                        const int x = i / nE, j = i - x * nE, g = j / G, r = j - g * G;
+                        for (int k = 0; k < K; ++k)
+                            sE[k * plane + x * capE + j] = sqrt(bA.u[k * plane + x * capE + g] + TD2[(int)nwA[g] * G + r]);
+                    }
+                    for (int i = tid; i < nE; i += nt) grouped[i] = 0;
+                    cx.sync();
+                    int mpos = 0;
+                    const double cntn = (double)(P * K);
+                    for (int b = 0; b < nE; ++b) {
+                        if (grouped[b]) continue;
+                        const int gb = b / G, rb = b - gb * G;
+                        for (int i = tid; i < P * (D + K); i += nt) {
+                            const int x = i / (D + K), f = i - x * (D + K);
+                            if (f < D)
+                                pm[x * D + f] = bA.m[f * plane + x * capE + gb];
+                            else
+                                ps[x * K + (f - D)] = sE[(f - D) * plane + x * capE + b];
+                        }
+                        if (tid == 0) gst[nG] = (uint16_t)mpos;
+                        cx.sync();
+                        for (int base = b; base < nE; base += nt) {
+                            const int j = base + tid;
+                            bool flag = false;
+                            if (j < nE && !grouped[j]) {
+                                const int gj = j / G, rj = j - gj * G;
+                                if (j == b) {
+                                    flag = true;
+                                } else if (useA && rj == rb && kyA[gj] == kyA[gb]) {
+                                    flag = true;  // same last frame_len states
+                                } else if (rj % S == rb % S) {
+                                    int cm = 0, cs = 0;
+                                    for (int x = 0; x < P; ++x) {
+                                        double dmn = 0.0, dsd = 0.0, sj[K];
+                                        for (int d = 0; d < D; ++d) dmn += fabs(bA.m[d * plane + x * capE + gj] - pm[x * D + d]);
+                                        dmn = dmn / (double)D;
+                                        for (int k = 0; k < K; ++k) {
+                                            sj[k] = sE[k * plane + x * capE + j];
+                                            dsd += fabs(sj[k] - ps[x * K + k]);
+                                        }
+                                        dsd = dsd / (double)K;
+                                        for (int k = 0; k < K; ++k) {
+                                            cm += (dmn / sj[k] < thr) ? 1 : 0;
+                                            cs += (dsd / sj[k] < thr) ? 1 : 0;
+                                        }
+                                    }
+                                    flag = ((double)cm / cntn > 0.8) && ((double)cs / cntn > 0.8);
+                                }
+                            }
+                            // ordered compaction of the selected candidates (ascending j, as np.where gives them)
+                            int wtot;
+                            const int rank = cx.wave_rank(flag, wtot);
+                            if (cx.lane() == 0) wcnt[cx.wave_in_block()] = wtot;
+                            cx.sync();
+                            int off = 0, tot = 0;
+                            for (int wv = 0; wv < cx.waves_per_block(); ++wv) {
+                                const int cnt = wcnt[wv];
+                                off += wv < cx.wave_in_block() ? cnt : 0;
+                                tot += cnt;
+                            }
+                            if (flag) {
+                                mem[mpos + off + rank] = (uint16_t)j;
+                                grouped[j] = 1;
+                            }
+                            mpos += tot;
+                            cx.sync();
+                        }
+                        ++nG;
+                    }
+                    if (tid == 0) gst[nG] = (uint16_t)mpos;
+                }
+                cx.sync();
+                // ---- merge: pilots' states, the shared state history, newest state of each group; publish the plan
+                const bool stay = t >= 2 && t >= a.min_len;
+                const double* TTl = TAB + (stay ? 1 : 0) * S * G;
+                for (int i = tid; i < P * nG; i += nt) {
+                    const int x = i / nG, g2 = i - x * nG;
+                    xt_th_gather<D, K>(bA, 1, x * capE, mem, (int)gst[g2], (int)gst[g2 + 1], G, nwA, TTl, TD2, bB, x * capE + g2);
+                }
+                const int Hn = (t == 1) ? He : (He < F ? He : F);  // fit mode keeps frame_len entries (tracking.py:699-701)
+                const int Pc = nfuse == 0 ? 1 : P;                 // rows of the reference's cat array (tracking.py:726-729)
+                for (int i = tid; i < nG * Hn * S; i += nt) {
+                    const int g2 = i / (Hn * S), hs = i - g2 * (Hn * S), h = hs / S, s = hs - h * S;
+                    const int k0 = gst[g2], k1 = gst[g2 + 1];
+                    auto val = [&](int j) -> double {
+                        const int g = j / G, r = j - g * G;
+                        if (h < NS) return ((r / pwS[h]) % S == s) ? 1.0 : 0.0;
+                        return ctA[(g * HM + (h - NS)) * S + s];
+                    };
+                    double o;
+                    if (k1 - k0 == 1) {
+                        o = val(mem[k0]);
+                    } else {
+                        // np.mean over (pilot rows x members) of identical rows: sequential, member-major (see tests)
+                        double acc = 0.0;
+                        for (int kk = k0; kk < k1; ++kk) {
+                            const double v = val(mem[kk]);
+                            for (int rep = 0; rep < Pc; ++rep) acc = acc + v;
+                        }
+                        o = acc / (double)(Pc * (k1 - k0));
+                    }
+                    ctB[(g2 * HM + h) * S + s] = o;
+                }
+                for (int i = tid; i < nG; i += nt) nwB[i] = (uint8_t)((int)mem[gst[i]] % S);
+                for (int i = tid; i < nE; i += nt) mem_g[(int64_t)t * capE + i] = mem[i];
+                for (int i = tid; i <= nG; i += nt) gst_g[(int64_t)t * (capE + 1) + i] = gst[i];
+                cx.sync();
+                // history keys of the new parents: argmax over states of the first Fk entries
+                for (int i = tid; i < nG; i += nt) {
+                    unsigned long long key = 0;
+                    for (int h = 0; h < Fk && h < Hn; ++h) {
+                        int best = 0;
+                        double bv = ctB[(i * HM + h) * S];
+                        for (int s = 1; s < S; ++s) {
+                            const double v = ctB[(i * HM + h) * S + s];
+                            if (v > bv) {
+                                bv = v;
+                                best = s;
+                            }
+                        }
+                        key |= (unsigned long long)best << (3 * h);
+                    }
+                    kyB[i] = key;
+                }
+                if (t >= 2) ++nfuse;
+                {
+                    XtThBuf tb = bA;
+                    bA = bB;
+                    bB = tb;
+                    uint8_t* tn = nwA;
+                    nwA = nwB;
+                    nwB = tn;
+                    double* tc = ctA;
+                    ctA = ctB;
+                    ctB = tc;
+                    unsigned long long* tk = kyA;
+                    kyA = kyB;
+                    kyB = tk;
+                }
+                nPar = nG;
+                Hc = Hn;
+                maxG = nG > maxG ? nG : maxG;
+                cx.sync();
+            }
+            if (tid == 0) {
+                hdr_g[t * 2] = nE;
+                hdr_g[t * 2 + 1] = nG;
+            }
+        }
+        if (tid == 0) {
+            a.status[ch * 4 + 0] = overflow;
+            a.status[ch * 4 + 1] = maxE;
+            a.status[ch * 4 + 2] = maxG;
+            a.status[ch * 4 + 3] = 0;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// APPLY kernel body: tiles of TT tracks of one chunk per workgroup.
+// ------------------------------------------------------------------------------------------------------------------
+template <int D, int K, class Ctx>
+XT_HD void xt_th_apply_body(const XtThArgs& a, Ctx& cx)
+{
+    const int S = a.S, G = a.G, L = a.L, capE = a.capE, TT = a.TT, capG = a.capG, KS = a.KS;
+    const int tid = cx.tid(), nt = cx.nthreads();
+    const int TP = TT + 1;  // padded row of the position stage
+    double* smem = cx.smem();
+    const int ntab = xt_tab_doubles(S, G);
+    for (int i = tid; i < ntab; i += nt) smem[i] = a.blob[i];
+    const double* hdr = smem;
+    const double* TAB = smem + XT_BLOB_HDR;
+    const double* T64 = TAB + XT_NTAB * S * G;
+    const double* TD2 = TAB + 4 * S * G;
+    double* w = smem + ((ntab + 1) & ~1);
+    const int plane = capG * TT;
+    const int capEl = capG * G;
+    XtThBuf bA, bB;
+    xt_th_carve(w, bA, plane, D, K);
+    xt_th_carve(w, bB, plane, D, K);
+    double* spos = w;
+    w += XT_TH_STAGE * D * TP;
+    double* ssig = w;
+    w += XT_TH_STAGE * KS * TP;
+    double* red = w;
+    w += TT;
+    int* nanflag = (int*)w;
+    uint8_t* nwA = (uint8_t*)(nanflag + TT);
+    uint8_t* nwB = nwA + capG;
+    uint16_t* mem = (uint16_t*)(nwB + capG);
+    uint16_t* gst = mem + capEl;
+
+    const int tpc = (a.chunk + TT - 1) / TT;
+    const int64_t ntiles = (int64_t)a.nchunks * tpc;
+    const int x = tid & (TT - 1);  // TT is a power of two <= nthreads
+    const int g0 = tid / TT, gstep = nt / TT;
+    double my_ll = 0.0;  // meaningful in threads with g0 == 0
+
+    for (int64_t tile = cx.block(); tile < ntiles; tile += cx.nblocks()) {
+        const int ch = (int)(tile / tpc);
+        const int64_t first = (int64_t)ch * a.chunk + (tile - (int64_t)ch * tpc) * TT;
+        int64_t cend = (int64_t)(ch + 1) * a.chunk;
+        cend = cend < a.N ? cend : a.N;
+        if (first >= cend) continue;
+        const int nx = (int)((cend - first) < TT ? (cend - first) : TT);
+        const uint16_t* mem_g = a.members + (int64_t)ch * L * capE;
+        const uint16_t* gst_g = a.gstart + (int64_t)ch * L * (capE + 1);
+        const int32_t* hdr_g = a.hdr + (int64_t)ch * L * 2;
+        const bool act = x < nx;
+        cx.sync();  // tables loaded / previous tile's reads done
+        if (tid < TT) nanflag[tid] = 0;
+        cx.sync();
+
+        auto stage = [&](int p0) {
+            for (int i = tid; i < TT * XT_TH_STAGE * D; i += nt) {
+                const int xx = i / (XT_TH_STAGE * D), o = i - xx * (XT_TH_STAGE * D);
+                if (xx < nx && p0 + o / D < L) {
+                    const double v = a.tracks[((first + xx) * L + p0) * D + o];
+                    spos[o * TP + xx] = v;
+                    if (v != v) nanflag[xx] = 1;  // NaN input: the track's result becomes NaN, as in the reference
+                }
+            }
+            if (a.locerr_mode != 0)
+                for (int i = tid; i < TT * XT_TH_STAGE * KS; i += nt) {
+                    const int xx = i / (XT_TH_STAGE * KS), o = i - xx * (XT_TH_STAGE * KS);
+                    if (xx < nx && p0 + o / KS < L) {
+                        const double v = a.sigma[((first + xx) * L + p0) * KS + o];
+                        ssig[o * TP + xx] = v;
+                        if (v != v) nanflag[xx] = 1;
+                    }
+                }
+            cx.sync();
+        };
+        auto load_l2 = [&](int pos, double* l2) {
+            if (a.locerr_mode == 0) {
+                for (int k = 0; k < K; ++k) l2[k] = hdr[k];
+            } else {
+                for (int k = 0; k < K; ++k)
+                    l2[k] = xt_th_l2_from_sigma(ssig[((pos & (XT_TH_STAGE - 1)) * KS + (KS == 1 ? 0 : k)) * TP + x], a.locerr_mode, hdr);
+            }
+        };
+
+        stage(0);
+        // ---- position 0: S parents
+        if (act) {
+            double l2[K];
+            load_l2(0, l2);
+            for (int g = g0; g < S; g += gstep) {
+                const int idx = g * TT + x;
+                bA.zm[idx] = hdr[8 + g];
+                bA.ze[idx] = 0;
+                for (int d = 0; d < D; ++d) bA.m[d * plane + idx] = spos[d * TP + x];
+                for (int k = 0; k < K; ++k) bA.u[k * plane + idx] = l2[k];
+            }
+        }
+        if (tid < S) nwA[tid] = (uint8_t)tid;
+        int nPar = S;
+        XtThBuf cur = bA, nxt = bB;
+        uint8_t *ncur = nwA, *nnxt = nwB;
+        cx.sync();
+
+        for (int t = 1; t <= L - 1; ++t) {
+            if (t >= 2) {
+                const int pos = t - 1;
+                if ((pos & (XT_TH_STAGE - 1)) == 0) stage(pos);
+                if (act) {
+                    double c[D], l2[K];
+                    for (int d = 0; d < D; ++d) c[d] = spos[((pos & (XT_TH_STAGE - 1)) * D + d) * TP + x];
+                    load_l2(pos, l2);
+                    for (int g = g0; g < nPar; g += gstep) xt_th_integrate<D, K>(cur, g * TT + x, c, l2, T64);
+                }
+            }
+            if (t < L - 1) {
+                const int nE = nPar * G;
+                const int nG = hdr_g[t * 2 + 1];
+                for (int i = tid; i < nE; i += nt) mem[i] = mem_g[(int64_t)t * capE + i];
+                for (int i = tid; i <= nG; i += nt) gst[i] = gst_g[(int64_t)t * (capE + 1) + i];
+                cx.sync();
+                const bool stay = t >= 2 && t >= a.min_len;
+                const double* TTl = TAB + (stay ? 1 : 0) * S * G;
+                if (act)
+                    for (int g2 = g0; g2 < nG; g2 += gstep)
+                        xt_th_gather<D, K>(cur, TT, x, mem, (int)gst[g2], (int)gst[g2 + 1], G, ncur, TTl, TD2, nxt, g2 * TT + x);
+                for (int i = tid; i < nG; i += nt) nnxt[i] = (uint8_t)((int)mem[gst[i]] % S);
+                cx.sync();
+                XtThBuf tb = cur;
+                cur = nxt;
+                nxt = tb;
+                uint8_t* tn = ncur;
+                ncur = nnxt;
+                nnxt = tn;
+                nPar = nG;
+            }
+        }
+        cx.sync();
+
+        // ---- last position (+ leaving/bleaching term, tracking.py:611-633): reduction over (parent, new digits)
+        const int tl = L - 1;
+        if ((tl & (XT_TH_STAGE - 1)) == 0 && tl != 0) stage(tl);
+        if (act) {
+            const bool stay = tl >= 2 && tl >= a.min_len;
+            const double* TF = TAB + ((a.isBL ? 2 : 0) + (stay ? 1 : 0)) * S * G;
+            double cl[D], l2l[K];
+            for (int d = 0; d < D; ++d) cl[d] = spos[((tl & (XT_TH_STAGE - 1)) * D + d) * TP + x];
+            load_l2(tl, l2l);
+            for (int g = g0; g < nPar; g += gstep) {
+                const int idx = g * TT + x;
+                XtAcc acc;
+                acc.clear();
+                const double zq = cur.zm[idx];
+                if (zq != 0.0) {
+                    const int eq = cur.ze[idx];
+                    const int o = (int)ncur[g] * G;
+                    double dq[D], uq[K], dsq = 0.0;
+                    for (int d = 0; d < D; ++d) {
+                        dq[d] = cl[d] - cur.m[d * plane + idx];
+                        dsq = xt_fma(dq[d], dq[d], dsq);
+                    }
+                    for (int k = 0; k < K; ++k) uq[k] = cur.u[k * plane + idx];
+                    for (int r = 0; r < G; ++r) {
+                        double quad, gf;
+                        if (K == 1) {
+                            const double rr = xt_rcp(TD2[o + r] + uq[0] + l2l[0]);
+                            quad = 0.5 * dsq * rr;
+                            gf = xt_pow_half<D>(rr);
+                        } else {
+                            quad = 0.0;
+                            gf = 1.0;
+                            for (int d = 0; d < D; ++d) {
+                                const double rr = xt_rcp(TD2[o + r] + uq[d] + l2l[d]);
+                                quad = xt_fma(0.5 * dq[d] * dq[d], rr, quad);
+                                gf *= rr;
+                            }
+                            gf = sqrt(gf);
+                        }
+                        double p;
+                        int j, n;
+                        xt_exp_tab(-quad, p, j, n);
+                        acc.add(zq * TF[o + r] * (gf * T64[j]) * p, eq + n);
+                    }
+                }
+                nxt.zm[idx] = acc.m;
+                nxt.ze[idx] = acc.e;
+            }
+        }
+        cx.sync();
+        if (act && g0 == 0) {
+            XtAcc tot;
+            tot.clear();
+            for (int g = 0; g < nPar; ++g) tot.add(nxt.zm[g * TT + x], nxt.ze[g * TT + x]);
+            const double ll = nanflag[x] ? NAN : log(tot.m) + (double)tot.e * XT_LN2 + a.ll_const;
+            if (a.ll_out) a.ll_out[first + x] = ll;
+            my_ll += ll;
+        }
+    }
+
+    // ---- block partial: fixed-order sum over the tile's track slots
+    cx.sync();
+    if (g0 == 0) red[x] = my_ll;
+    cx.sync();
+    if (tid == 0) {
+        double s = 0.0;
+        for (int i = 0; i < TT; ++i) s += red[i];
+        a.partials[cx.block()] = s;
+    }
+}

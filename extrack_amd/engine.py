@@ -119,6 +119,9 @@ class TrackSet:
     def loglik(self, model, per_track=False):
         return self.ctx.loglik(model, per_track=per_track)
 
+    def loglik_th(self, model, threshold=0.2, max_nb_states=120, chunk=2000, per_track=False):
+        return self.ctx.loglik_th(model, threshold, max_nb_states, chunk, per_track=per_track)
+
     def predict(self, model):
         """Posteriors for every uploaded bucket, in upload order: list of arrays [N_l, l, S]."""
         return [self.ctx.predict(model, i) for i in range(len(self.shapes))]

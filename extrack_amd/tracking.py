@@ -13,9 +13,14 @@ Same public names, argument meaning and error behaviour as the reference for THI
   get_params        extrack/tracking.py:1090-1212
 
 The recursion itself runs in hand-written HIP kernels for gfx950 through the C ABI in
-include/extrack_hip.h; nothing here computes likelihoods on the CPU.  The algorithm is the
-FIXED-WINDOW kernel (``P_Cs_inter_bound_stats``); ``threshold`` / ``max_nb_states`` / ``nb_max`` of the
-threshold-fusion variant are accepted for signature compatibility and ignored.
+include/extrack_hip.h; nothing here computes likelihoods on the CPU.  Two kernels exist, selected by the extra
+keyword ``fusion``:
+  ``fusion="window"`` (default)  the FIXED-WINDOW kernel ``P_Cs_inter_bound_stats`` (tracking.py:109-318, what
+                                 BASELINE.json names); ``threshold`` / ``max_nb_states`` are accepted and ignored.
+  ``fusion="threshold"``         the THRESHOLD-FUSION kernel ``P_Cs_inter_bound_stats_th`` (tracking.py:427-743) that
+                                 ``extrack.tracking.param_fitting`` calls in v1.6.3, chunked by 2000 tracks like
+                                 ``cum_Proba_Cs`` (tracking.py:1043); log-likelihood only (``predict_Bs`` stays on the
+                                 fixed window).
 ``workers`` is accepted and ignored: the tracks are sharded over GPUs instead (extrack_amd.distributed).
 """
 import numpy as np
@@ -171,6 +176,12 @@ def get_params(nb_states=2, steady_state=False, vary_params=_GP_VARY, estimated_
     return params
 
 
+def _check_fusion(fusion):
+    if fusion not in ("window", "threshold"):
+        raise ValueError("fusion must be 'window' or 'threshold'")
+    return fusion == "threshold"
+
+
 # ------------------------------------------------------------------------------------------------------------
 # kernel-level mirrors (one-off uploads; used by tests and for drop-in calls on small chunks)
 # ------------------------------------------------------------------------------------------------------------
@@ -194,11 +205,16 @@ def _one_bucket(Cs, LocErr, isBL, min_len, device):
 
 
 def Proba_Cs(Cs, LocErr, ds, Fs, TrMat, pBL, isBL, cell_dims, nb_substeps, frame_len, min_len, threshold=None, max_nb_states=None,
-             device=0):
-    """Per-track log-likelihood LP_C[N] of one chunk (extrack/tracking_0.py:440-458), computed on the GPU."""
+             device=0, fusion="window"):
+    """Per-track log-likelihood LP_C[N] of one chunk, computed on the GPU: extrack/tracking_0.py:440-458 (fixed window) or,
+    with ``fusion="threshold"``, extrack/tracking.py:769-787 (the whole of ``Cs`` is ONE chunk: its first 30 tracks decide
+    the merges, tracking.py:678-679)."""
     ts, le = _one_bucket(Cs, LocErr, isBL, min_len, device)
     try:
         model = ts.make_model(le, ds, Fs, TrMat, pBL, cell_dims, nb_substeps, frame_len)
+        if _check_fusion(fusion):
+            return ts.loglik_th(model, 0.2 if threshold is None else threshold, 120 if max_nb_states is None else max_nb_states,
+                                chunk=max(len(Cs), 1), per_track=True)[1]
         return ts.loglik(model, per_track=True)[1]
     finally:
         ts.close()
@@ -257,16 +273,23 @@ def _objective_model(params, ts, dt, cell_dims, input_LocErr, nb_states, nb_subs
 
 
 def cum_Proba_Cs(params, all_tracks, dt, cell_dims, input_LocErr, nb_states, nb_substeps, frame_len, verbose=1, workers=1,
-                 Matrix_type=1, threshold=0.2, max_nb_states=120, max_number_of_tracks_per_matrix=2000, comm=None):
+                 Matrix_type=1, threshold=0.2, max_nb_states=120, max_number_of_tracks_per_matrix=2000, comm=None, fusion="window"):
     """-sum of per-track log-likelihoods, or +inf for invalid parameters / NaN (extrack/tracking.py:991-1088).
 
     ``all_tracks``: list of bucket arrays sorted short->long (as the reference passes it) or a ``TrackSet``.
     ``comm``: optional extrack_amd.distributed.Comm; when given, ``all_tracks`` is this rank's shard and the
-    scalar is all-reduced over the ranks."""
+    scalar is all-reduced over the ranks.  ``fusion="threshold"``: the v1.6.3 kernel with ``threshold``, ``max_nb_states`` and
+    chunks of ``max_number_of_tracks_per_matrix`` tracks (single GPU: the chunking is part of the result)."""
+    th = _check_fusion(fusion)
+    if th and comm is not None:
+        raise NotImplementedError("fusion='threshold' depends on the chunking of the whole dataset and is evaluated on one GPU")
     ts = _as_trackset(all_tracks, input_LocErr)
     model = _objective_model(params, ts, dt, cell_dims, input_LocErr, nb_states, nb_substeps, frame_len, Matrix_type)
     if model is not None:
-        Cum_P = ts.loglik(model) if comm is None else comm.allreduce_loglik(ts, model)
+        if th:
+            Cum_P = ts.loglik_th(model, threshold, max_nb_states, max_number_of_tracks_per_matrix)
+        else:
+            Cum_P = ts.loglik(model) if comm is None else comm.allreduce_loglik(ts, model)
         if verbose == 1:
             q = [p + " = " + str(np.round(params[p].value, 6)) for p in params]
             print(Cum_P, q)
@@ -289,12 +312,13 @@ def cum_Proba_Cs(params, all_tracks, dt, cell_dims, input_LocErr, nb_states, nb_
 # ------------------------------------------------------------------------------------------------------------
 def param_fitting(all_tracks, dt, params=None, nb_states=2, nb_substeps=1, frame_len=6, verbose=1, workers=1, Matrix_type=1,
                   method="bfgs", steady_state=False, cell_dims=[1], input_LocErr=None, threshold=0.2, max_nb_states=120,
-                  device=0, comm=None):
+                  device=0, comm=None, fusion="window"):
     """Fit the model parameters to a length-bucketed track dict (extrack/tracking.py:1299-1386).
 
     all_tracks: {str(len): ndarray[n_tracks, len, dims]}.  Returns the lmfit (or lmfit_compat) MinimizerResult:
     ``.params[name].value``, ``.residual[0] == -log-likelihood``.  Extra keywords: ``device`` (GPU index) and
-    ``comm`` (distributed shard communicator)."""
+    ``comm`` (distributed shard communicator), ``fusion`` ("window" | "threshold", see the module docstring)."""
+    _check_fusion(fusion)
     if params is None:
         params = generate_params(nb_states=nb_states, LocErr_type=1, LocErr_bounds=[0.005, 0.1], D_max=3,
                                  Fractions_bounds=[0.001, 0.99], estimated_transition_rates=0.1)
@@ -312,7 +336,7 @@ def param_fitting(all_tracks, dt, params=None, nb_states=2, nb_substeps=1, frame
     try:
         fit = minimize(cum_Proba_Cs, params,
                        args=(ts, dt, cell_dims, sigmas, nb_states, nb_substeps, frame_len, verbose, workers, Matrix_type, threshold,
-                             max_nb_states, 2000, comm),
+                             max_nb_states, 2000, comm, fusion),
                        method=method, nan_policy="propagate")
     finally:
         ts.close()

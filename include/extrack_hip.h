@@ -15,6 +15,12 @@
  *   extrack_predict
  *       P_Cs_inter_bound_stats(..., do_preds=1)[2] for one bucket (Pool_star_P_inter,
  *       extrack/tracking_0.py:460-461, driven by predict_Bs :463-563).
+ *   extrack_loglik_th
+ *       the same sum for the THRESHOLD-FUSION kernel that extrack.tracking calls in v1.6.3: Proba_Cs
+ *       (extrack/tracking.py:769-787) -> P_Cs_inter_bound_stats_th (:427-650) + fuse_tracks_th (:652-743),
+ *       evaluated in chunks as cum_Proba_Cs does (tracking.py:1043-1069, 2000 tracks per chunk).
+ *   extrack_th_plan_step
+ *       the merge groups fuse_tracks_th decided for one chunk and step (tracking.py:681-701) - diagnostic.
  *   extrack_p_stay_table
  *       the field-of-view survival table, extrack/tracking.py:182-191.
  *
@@ -32,7 +38,7 @@
 extern "C" {
 #endif
 
-#define EXTRACK_ABI_VERSION 1
+#define EXTRACK_ABI_VERSION 2
 
 #define EXTRACK_OK 0
 #define EXTRACK_E_INVALID (-1)     /* bad argument / unsupported configuration */
@@ -99,6 +105,23 @@ int extrack_loglik_async(extrack_ctx* ctx, const extrack_model* model, double* d
 /* State posteriors of one bucket: preds host [n][len][S].  model->nb_substeps must be 1
  * (predict_Bs forces it, extrack/tracking.py:839). */
 int extrack_predict(extrack_ctx* ctx, const extrack_model* model, int32_t bucket_id, double* preds);
+
+/* Threshold-fusion log-likelihood (the kernel extrack.tracking.param_fitting / cum_Proba_Cs call in v1.6.3,
+ * extrack/tracking.py:427-743).  Which state sequences are merged at a step is decided from the first 30 tracks
+ * of every chunk of `chunk` consecutive tracks of a bucket (tracking.py:678-679; cum_Proba_Cs uses chunk = 2000,
+ * tracking.py:1043) and applied to the whole chunk, so the value depends on `chunk` and on the track order.
+ * model->frame_len is the number of most recent states whose equality forces a merge; threshold and
+ * max_nb_states as in tracking.py:427 (threshold is multiplied by 1.2 at every step with more than
+ * max_nb_states live sequences).  Fixed time step only (scalar dt).
+ * total_ll / per_track as in extrack_loglik. */
+int extrack_loglik_th(extrack_ctx* ctx, const extrack_model* model, double threshold, int32_t max_nb_states, int32_t chunk,
+                      double* total_ll, double* per_track);
+/* Diagnostic: merge groups of the last extrack_loglik_th call for chunk `chunk_index` of a bucket at step t
+ * (t = 1 .. len-1; merges happen for t < len-1).  n_expanded = sequences before the merge, n_groups = after
+ * (0 when the step has no merge).  members[0..n_expanded) are the expanded sequence indices sorted by group,
+ * gstart[0..n_groups] the group boundaries; both may be NULL; cap = capacity of both arrays in elements. */
+int extrack_th_plan_step(extrack_ctx* ctx, int32_t bucket_id, int64_t chunk_index, int32_t t, int32_t* n_expanded,
+                         int32_t* n_groups, uint16_t* members, uint16_t* gstart, int32_t cap);
 
 /* Device time (ms, HIP events on the context's stream) spent in the track kernels of the last
  * extrack_loglik / extrack_loglik_async / extrack_predict call (valid after the stream is idle). */

@@ -13,6 +13,7 @@
 #include "../../extrack_amd/csrc/xt_entry.h"
 #include "../../extrack_amd/csrc/xt_fast2.h"
 #include "../../extrack_amd/csrc/xt_tables.h"
+#include "../../extrack_amd/csrc/xt_th.h"
 
 struct HostCtx {
     int tid_, nthreads_, block_, nblocks_;
@@ -33,6 +34,20 @@ struct HostCtx {
         return o;
     }
     int shfl_xor_i32(int v, int m) { return (int)shfl_xor_f64((double)v, m); }
+    int wave_rank(bool flag, int& total)
+    {
+        wscr_[lane()] = flag ? 1.0 : 0.0;
+        pthread_barrier_wait(wbar_);
+        int r = 0, t = 0;
+        for (int i = 0; i < 64; ++i) {
+            const int f = wscr_[i] != 0.0;
+            t += f;
+            r += (i < lane()) ? f : 0;
+        }
+        pthread_barrier_wait(wbar_);
+        total = t;
+        return r;
+    }
     int tid() const { return tid_; }
     int nthreads() const { return nthreads_; }
     int block() const { return block_; }
@@ -271,6 +286,112 @@ extern "C" int xt_emul_run_multi(int nbuckets, const double** tracks, const long
         ok = xt_dispatch(cfg.G, D, K, false, l);
     }
     if (!ok) return -3;
+    double s = 0.0;
+    for (double p : partials) s += p;
+    if (total) *total = s;
+    return 0;
+}
+
+
+// ---- threshold-fusion kernels (xt_th.h): plan + apply for ONE bucket, emulated block by block.
+template <class Body>
+static void th_emul_blocks(int nblocks, int threads, size_t lds_doubles, Body body)
+{
+    const int nw = threads / 64;
+    for (int b = 0; b < nblocks; ++b) {
+        std::vector<double> smem(lds_doubles + 16, 0.0);
+        pthread_barrier_t bar;
+        pthread_barrier_init(&bar, nullptr, threads);
+        std::vector<pthread_barrier_t> wb(nw);
+        std::vector<std::vector<double>> ws(nw, std::vector<double>(64, 0.0));
+        for (auto& x : wb) pthread_barrier_init(&x, nullptr, 64);
+        std::vector<std::thread> th;
+        for (int t = 0; t < threads; ++t)
+            th.emplace_back([&, t]() {
+                HostCtx cx{t, threads, b, nblocks, smem.data(), &bar};
+                cx.wbar_ = &wb[t >> 6];
+                cx.wscr_ = ws[t >> 6].data();
+                body(cx);
+            });
+        for (auto& x : th) x.join();
+        pthread_barrier_destroy(&bar);
+        for (auto& x : wb) pthread_barrier_destroy(&x);
+    }
+}
+
+extern "C" int xt_emul_th_run(const double* tracks, const double* sigma, long long N, int L, int D, int KS, int S, int NS, int F, int isBL,
+                              int min_len, int locerr_mode, int locerr_dims, const double* locerr, double slope, double offset, double pBL,
+                              const double* ds, const double* Fs, const double* TrMat, const double* p_stay, double threshold, int max_nb,
+                              int chunk, int capE, int TT, int apply_threads, int nblocks, double* ll_out, double* total,
+                              int* hdr_out /* [nchunks][L][2] */, unsigned short* members_out /* [nchunks][L][capE] */,
+                              unsigned short* gstart_out /* [nchunks][L][capE+1] */, int* status_out /* [nchunks][4] */)
+{
+    XtModelHost m{S, NS, locerr_dims, {0, 0, 0}, slope, offset, pBL, ds, Fs, TrMat, p_stay};
+    for (int k = 0; k < 3; ++k) m.locerr[k] = locerr ? locerr[k < locerr_dims ? k : 0] : 0.0;
+    std::vector<double> blob;
+    int G = 0;
+    if (!xt_th_build_blob(m, blob, G).empty()) return -1;
+    const int K = locerr_mode == 0 ? locerr_dims : KS;
+    XtThArgs a;
+    memset(&a, 0, sizeof(a));
+    a.tracks = tracks;
+    a.sigma = locerr_mode ? sigma : nullptr;
+    a.blob = blob.data();
+    a.ll_out = ll_out;
+    a.N = N;
+    a.L = L;
+    a.S = S;
+    a.NS = NS;
+    a.G = G;
+    a.F = F;
+    a.isBL = isBL;
+    a.min_len = min_len;
+    a.locerr_mode = locerr_mode;
+    a.KS = KS ? KS : 1;
+    a.chunk = chunk;
+    a.nchunks = (int)((N + chunk - 1) / chunk);
+    a.capE = capE;
+    a.max_nb = max_nb;
+    a.threshold = threshold;
+    a.ll_const = -(double)(L - 1) * D * 0.5 * XT_LOG2PI;
+    std::vector<uint16_t> mem((size_t)a.nchunks * L * capE, 0), gst((size_t)a.nchunks * L * (capE + 1), 0);
+    std::vector<int32_t> hdr((size_t)a.nchunks * L * 2, 0), status((size_t)a.nchunks * 4, 0);
+    a.members = mem.data();
+    a.gstart = gst.data();
+    a.hdr = hdr.data();
+    a.status = status.data();
+    const int plan_blocks = nblocks < a.nchunks ? nblocks : a.nchunks;
+    a.ws_stride = xt_th_ws_doubles(capE, D, K, F, NS, S);
+    std::vector<double> ws((size_t)a.ws_stride * plan_blocks, 0.0);
+    a.ws = ws.data();
+    const size_t plan_lds = xt_th_plan_lds_doubles(S, G, capE, D, K);
+    const int plan_threads = apply_threads;  // same block size for both kernels in the emulation
+#define TH_RUN(BODY, NB, NT, LDS)                                                                             \
+    do {                                                                                                      \
+        if (D == 1 && K == 1) th_emul_blocks(NB, NT, LDS, [&](HostCtx& cx) { BODY<1, 1>(a, cx); });           \
+        else if (D == 2 && K == 1) th_emul_blocks(NB, NT, LDS, [&](HostCtx& cx) { BODY<2, 1>(a, cx); });      \
+        else if (D == 2 && K == 2) th_emul_blocks(NB, NT, LDS, [&](HostCtx& cx) { BODY<2, 2>(a, cx); });      \
+        else if (D == 3 && K == 1) th_emul_blocks(NB, NT, LDS, [&](HostCtx& cx) { BODY<3, 1>(a, cx); });      \
+        else if (D == 3 && K == 3) th_emul_blocks(NB, NT, LDS, [&](HostCtx& cx) { BODY<3, 3>(a, cx); });      \
+        else return -3;                                                                                       \
+    } while (0)
+    TH_RUN(xt_th_plan_body, plan_blocks, plan_threads, plan_lds);
+    if (hdr_out) memcpy(hdr_out, hdr.data(), hdr.size() * sizeof(int32_t));
+    if (members_out) memcpy(members_out, mem.data(), mem.size() * sizeof(uint16_t));
+    if (gstart_out) memcpy(gstart_out, gst.data(), gst.size() * sizeof(uint16_t));
+    if (status_out) memcpy(status_out, status.data(), status.size() * sizeof(int32_t));
+    int maxG = 0;
+    for (int c = 0; c < a.nchunks; ++c) {
+        if (status[(size_t)c * 4]) return -5;  // plan capacity overflow
+        maxG = status[(size_t)c * 4 + 2] > maxG ? status[(size_t)c * 4 + 2] : maxG;
+    }
+    a.capG = maxG;
+    a.TT = TT;
+    std::vector<double> partials(nblocks, 0.0);
+    a.partials = partials.data();
+    const size_t apply_lds = xt_th_apply_lds_doubles(S, G, maxG, TT, D, K, a.KS);
+    TH_RUN(xt_th_apply_body, nblocks, apply_threads, apply_lds);
+#undef TH_RUN
     double s = 0.0;
     for (double p : partials) s += p;
     if (total) *total = s;

@@ -13,7 +13,7 @@ def lib():
     if _lib is None:
         so = os.path.join(HERE, "libxt_emul.so")
         src = os.path.join(HERE, "emul.cpp")
-        hdrs = [os.path.join(HERE, "..", "..", "extrack_amd", "csrc", h) for h in ("xt_kernel.h", "xt_math.h", "xt_tables.h", "xt_dispatch.h")]
+        hdrs = [os.path.join(HERE, "..", "..", "extrack_amd", "csrc", h) for h in ("xt_kernel.h", "xt_math.h", "xt_tables.h", "xt_dispatch.h", "xt_th.h", "xt_entry.h", "xt_fast2.h")]
         if not os.path.exists(so) or any(os.path.getmtime(f) > os.path.getmtime(so) for f in [src] + hdrs):
             import subprocess
             subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-pthread", "-o", so, src])
@@ -74,3 +74,44 @@ def run_multi(buckets, locerr, ds, Fs, T, pBL, p_stay, ns, F, min_len, max_len, 
     if rc != 0:
         raise RuntimeError("emul multi rc=%d" % rc)
     return outs, tot.value
+
+
+def run_th(Cs, LE, ds, Fs, T, pBL, isBL, p_stay, ns, F, min_len, threshold, max_nb, chunk=2000, capE=256, TT=8, threads=64, nblocks=2,
+           slope=None, offset=None):
+    """Threshold-fusion plan + apply kernel bodies on CPU threads.  Returns (per-track LL, total, plan) with
+    plan[chunk][t] = list of member arrays (groups) for the fused steps."""
+    Cs = np.ascontiguousarray(Cs, float)
+    N, L, D = Cs.shape
+    S = len(ds)
+    LE = np.ascontiguousarray(LE, float)
+    if LE.shape[1] == 1 and L != 1:
+        mode, K, KS = 0, LE.shape[2], 0
+        locerr = np.zeros(3)
+        locerr[:K] = LE[0, 0]
+        sigma = None
+    else:
+        mode, KS = (2 if slope is not None else 1), LE.shape[2]
+        K, locerr, sigma = KS, np.zeros(3), LE
+    nch = (N + chunk - 1) // chunk
+    ll = np.zeros(N)
+    tot = C.c_double(0)
+    hdr = np.zeros((nch, L, 2), np.int32)
+    mem = np.zeros((nch, L, capE), np.uint16)
+    gst = np.zeros((nch, L, capE + 1), np.uint16)
+    status = np.zeros((nch, 4), np.int32)
+    ds, Fs, T, p_stay = [np.ascontiguousarray(x, float) for x in (ds, Fs, T, p_stay)]
+    vp = C.c_void_p
+    rc = lib().xt_emul_th_run(dp(Cs), dp(sigma), C.c_longlong(N), L, D, KS, S, ns, F, int(isBL), int(min_len), mode, K, dp(locerr),
+                              C.c_double(slope or 0.0), C.c_double(offset or 0.0), C.c_double(pBL), dp(ds), dp(Fs), dp(T), dp(p_stay),
+                              C.c_double(threshold), int(max_nb), int(chunk), int(capE), int(TT), int(threads), int(nblocks), dp(ll),
+                              C.byref(tot), hdr.ctypes.data_as(vp), mem.ctypes.data_as(vp), gst.ctypes.data_as(vp), status.ctypes.data_as(vp))
+    if rc != 0:
+        raise RuntimeError("emul th rc=%d status=%s" % (rc, status.tolist()))
+    plan = []
+    for c in range(nch):
+        steps = {}
+        for t in range(2, L - 1):
+            nE, nG = hdr[c, t]
+            steps[t] = [mem[c, t, gst[c, t, g]:gst[c, t, g + 1]].astype(int) for g in range(nG)]
+        plan.append(steps)
+    return ll, tot.value, plan, hdr, status
