@@ -31,6 +31,8 @@ struct DevCtx {
     __device__ __forceinline__ double* smem() const { return xt_smem; }
     __device__ __forceinline__ void sync() { __syncthreads(); }
     __device__ __forceinline__ int lane() const { return threadIdx.x & 63; }
+    // promise that v is the same in every lane of the wavefront (moves it to an SGPR: scalar loads, scalar address math)
+    __device__ __forceinline__ int uniform(int v) const { return __builtin_amdgcn_readfirstlane(v); }
     __device__ __forceinline__ int wave_in_block() const { return threadIdx.x >> 6; }
     __device__ __forceinline__ int waves_per_block() const { return blockDim.x >> 6; }
     // LDS operations of one wavefront execute in order; only the compiler must be kept from moving
@@ -90,11 +92,11 @@ __global__ void __launch_bounds__(256) xt_th_plan_kernel(XtThArgs a)
     xt_th_plan_body<D, K>(a, cx);
 }
 
-template <int D, int K>
-__global__ void __launch_bounds__(256) xt_th_apply_kernel(XtThArgs a)
+template <int D, int K, bool UNI>
+__global__ void __launch_bounds__(1024) xt_th_apply_kernel(XtThArgs a)
 {
     DevCtx cx;
-    xt_th_apply_body<D, K>(a, cx);
+    xt_th_apply_body<D, K, UNI>(a, cx);
 }
 
 // Fixed-order reduction of the per-block partial sums (deterministic for a given launch geometry).
@@ -124,6 +126,8 @@ struct XtBucket {
     double* d_ll = nullptr;  // per-track output, allocated on first request
     // threshold-fusion plan of the last extrack_loglik_th call (xt_th.h)
     uint16_t* th_members = nullptr;
+    uint32_t* th_mpack = nullptr;
+    uint8_t* th_gnew = nullptr;
     uint16_t* th_gstart = nullptr;
     int32_t* th_hdr = nullptr;
     int32_t* th_status = nullptr;
@@ -159,6 +163,7 @@ struct extrack_ctx {
     int th_capE = 128;          // plan capacity (expanded sequences per step); grows on overflow
     std::vector<int32_t> th_status_host;
     float th_plan_ms = 0.f;
+    int th_force_tt = 0, th_force_threads = 0, th_oversub = 2;  // tuning knobs (EXTRACK_TH_TT / _THREADS / _OVERSUB)
     std::string err;
 };
 
@@ -215,6 +220,18 @@ extern "C" int extrack_create(int device_id, extrack_ctx** out)
         int v = atoi(ev);
         if (v >= 1 && v <= 64) c->oversub = v;
     }
+    if (const char* ev = getenv("EXTRACK_TH_TT")) {
+        int v = atoi(ev);
+        if (v >= 1 && v <= 256 && (v & (v - 1)) == 0) c->th_force_tt = v;
+    }
+    if (const char* ev = getenv("EXTRACK_TH_THREADS")) {
+        int v = atoi(ev);
+        if (v >= 64 && v <= 1024 && v % 64 == 0) c->th_force_threads = v;
+    }
+    if (const char* ev = getenv("EXTRACK_TH_OVERSUB")) {
+        int v = atoi(ev);
+        if (v >= 1 && v <= 64) c->th_oversub = v;
+    }
 #define XT_CREATE(call)                                                             \
     if ((e = (call)) != hipSuccess) {                                               \
         g_create_err = std::string(#call) + ": " + hipGetErrorString(e);            \
@@ -243,6 +260,8 @@ static void xt_free_bucket(XtBucket& b)
     }
     if (b.d_ll) (void)hipFree(b.d_ll);
     if (b.th_members) (void)hipFree(b.th_members);
+    if (b.th_mpack) (void)hipFree(b.th_mpack);
+    if (b.th_gnew) (void)hipFree(b.th_gnew);
     if (b.th_gstart) (void)hipFree(b.th_gstart);
     if (b.th_hdr) (void)hipFree(b.th_hdr);
     if (b.th_status) (void)hipFree(b.th_status);
@@ -705,12 +724,35 @@ static hipError_t xt_th_launch_plan(extrack_ctx* ctx, const XtThArgs& a, int gri
 }
 
 template <int D, int K>
-static hipError_t xt_th_launch_apply(extrack_ctx* ctx, const XtThArgs& a, int grid, int threads, size_t lds)
+static hipError_t xt_th_launch_apply(extrack_ctx* ctx, const XtThArgs& a, int grid, int threads, size_t lds, bool uni)
 {
-    hipError_t e = xt_th_set_lds(ctx, xt_th_apply_kernel<D, K>, lds);
+    if (uni) {
+        hipError_t e = xt_th_set_lds(ctx, xt_th_apply_kernel<D, K, true>, lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((xt_th_apply_kernel<D, K, true>), dim3(grid), dim3(threads), lds, ctx->stream, a);
+        return hipGetLastError();
+    }
+    hipError_t e = xt_th_set_lds(ctx, xt_th_apply_kernel<D, K, false>, lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((xt_th_apply_kernel<D, K>), dim3(grid), dim3(threads), lds, ctx->stream, a);
+    hipLaunchKernelGGL((xt_th_apply_kernel<D, K, false>), dim3(grid), dim3(threads), lds, ctx->stream, a);
     return hipGetLastError();
+}
+
+// Grows the partial-sum array to n entries, keeping what earlier launches of this evaluation wrote.
+static int xt_grow_partials(extrack_ctx* ctx, size_t n)
+{
+    if (n <= ctx->partials_cap) return EXTRACK_OK;
+    const size_t cap = std::max(n, ctx->partials_cap * 2);
+    double* nw = nullptr;
+    XT_HIP(ctx, hipMalloc(&nw, cap * sizeof(double)));
+    if (ctx->d_partials) {
+        XT_HIP(ctx, hipMemcpyAsync(nw, ctx->d_partials, ctx->partials_cap * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+        XT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        (void)hipFree(ctx->d_partials);
+    }
+    ctx->d_partials = nw;
+    ctx->partials_cap = cap;
+    return EXTRACK_OK;
 }
 
 static int xt_th_reserve_plan(extrack_ctx* ctx, XtBucket& b, int chunk, int capE)
@@ -719,12 +761,18 @@ static int xt_th_reserve_plan(extrack_ctx* ctx, XtBucket& b, int chunk, int capE
     if (b.th_members && b.th_capE == capE && b.th_chunk == chunk && b.th_nchunks == nchunks) return EXTRACK_OK;
     XT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (b.th_members) (void)hipFree(b.th_members);
+    if (b.th_mpack) (void)hipFree(b.th_mpack);
+    if (b.th_gnew) (void)hipFree(b.th_gnew);
     if (b.th_gstart) (void)hipFree(b.th_gstart);
     if (b.th_hdr) (void)hipFree(b.th_hdr);
     if (b.th_status) (void)hipFree(b.th_status);
     b.th_members = b.th_gstart = nullptr;
+    b.th_mpack = nullptr;
+    b.th_gnew = nullptr;
     b.th_hdr = b.th_status = nullptr;
     XT_HIP(ctx, hipMalloc(&b.th_members, (size_t)nchunks * b.L * capE * sizeof(uint16_t)));
+    XT_HIP(ctx, hipMalloc(&b.th_mpack, (size_t)nchunks * b.L * capE * sizeof(uint32_t)));
+    XT_HIP(ctx, hipMalloc(&b.th_gnew, (size_t)nchunks * b.L * capE));
     XT_HIP(ctx, hipMalloc(&b.th_gstart, (size_t)nchunks * b.L * (capE + 1) * sizeof(uint16_t)));
     XT_HIP(ctx, hipMalloc(&b.th_hdr, (size_t)nchunks * b.L * 2 * sizeof(int32_t)));
     XT_HIP(ctx, hipMalloc(&b.th_status, (size_t)nchunks * 4 * sizeof(int32_t)));
@@ -754,7 +802,6 @@ extern "C" int extrack_loglik_th(extrack_ctx* ctx, const extrack_model* m, doubl
     if ((rc = xt_upload_blob(ctx, blob))) return rc;
     const int S = m->n_states, NS = m->nb_substeps, F = m->frame_len;
     if (S * G > XT_TH_MAXCAP) return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "n_states^(nb_substeps+1) exceeds the plan capacity");
-    if ((rc = xt_reserve_partials(ctx, ctx->buckets.size() * xt_max_grid(ctx)))) return rc;
     if (per_track)
         for (auto& b : ctx->buckets)
             if (!b.d_ll) XT_HIP(ctx, hipMalloc(&b.d_ll, (size_t)b.N * sizeof(double)));
@@ -792,7 +839,7 @@ extern "C" int extrack_loglik_th(extrack_ctx* ctx, const extrack_model* m, doubl
         a.threshold = threshold;
         a.ll_const = -(double)(b.L - 1) * D * 0.5 * XT_LOG2PI;
         hipError_t e = hipSuccess;
-        int maxG = 0;
+        int maxG = 0, sumE = 0;
         for (;;) {  // plan, growing the capacity on overflow
             int capE = ctx->th_capE;
             while (capE < S * G) capE *= 2;
@@ -800,6 +847,8 @@ extern "C" int extrack_loglik_th(extrack_ctx* ctx, const extrack_model* m, doubl
             if ((rc = xt_th_reserve_plan(ctx, b, chunk, capE))) return rc;
             a.capE = capE;
             a.members = b.th_members;
+            a.mpack = b.th_mpack;
+            a.gnew = b.th_gnew;
             a.gstart = b.th_gstart;
             a.hdr = b.th_hdr;
             a.status = b.th_status;
@@ -831,11 +880,12 @@ extern "C" int extrack_loglik_th(extrack_ctx* ctx, const extrack_model* m, doubl
                                        ctx->stream));
             XT_HIP(ctx, hipStreamSynchronize(ctx->stream));
             int over = 0, maxE = 0;
-            maxG = 0;
+            maxG = sumE = 0;
             for (int c = 0; c < a.nchunks; ++c) {
                 over |= ctx->th_status_host[(size_t)c * 4];
                 maxE = std::max(maxE, ctx->th_status_host[(size_t)c * 4 + 1]);
                 maxG = std::max(maxG, ctx->th_status_host[(size_t)c * 4 + 2]);
+                sumE = std::max(sumE, ctx->th_status_host[(size_t)c * 4 + 3]);
             }
             if (!over) break;
             int ncap = capE;
@@ -845,24 +895,41 @@ extern "C" int extrack_loglik_th(extrack_ctx* ctx, const extrack_model* m, doubl
                 return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "more than 8192 live state sequences per step: raise threshold or lower max_nb_states");
             ctx->th_capE = ncap;
         }
-        // apply geometry: as many tracks of a chunk per workgroup as keep the tile within ~48 KiB of LDS
+        // apply geometry: a workgroup serves tiles of TT tracks of one chunk and keeps that chunk's plan in LDS when it is
+        // small enough (always, for the usual 2-3 state models); TT = as many tracks as keep the tile within ~48 KiB of LDS
         a.capG = maxG;
+        a.plan_cap = (size_t)sumE * 6 + 2 * (size_t)b.L <= 24 * 1024 ? std::max(sumE, 1) : 0;
+        auto lds_of = [&](int tt) { return (size_t)xt_th_apply_lds_doubles(S, G, maxG, tt, D, K, a.KS, b.L, a.plan_cap, tt == 64) * 8; };
+        // 64 tracks per tile (wave-uniform scalar path) when two workgroups of that size fit a CU's LDS, else fewer tracks
         int TT = 64;
-        while (TT > 1 && (TT > chunk * 2 || (size_t)xt_th_apply_lds_doubles(S, G, maxG, TT, D, K, a.KS) * 8 > 48 * 1024)) TT >>= 1;
-        size_t lds = (size_t)xt_th_apply_lds_doubles(S, G, maxG, TT, D, K, a.KS) * 8;
+        if (ctx->th_force_tt > 0) TT = ctx->th_force_tt;
+        else if (chunk < 48 || lds_of(64) > 76 * 1024) {
+            TT = 32;
+            while (TT > 1 && (TT > chunk * 2 || lds_of(TT) > 48 * 1024)) TT >>= 1;
+        }
+        while (TT > 1 && lds_of(TT) > 160 * 1024) TT >>= 1;
+        const bool uni = TT == 64;
+        const size_t lds = lds_of(TT);
         if (lds > 160 * 1024) return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "live state sequences do not fit the 160 KiB LDS of a CU");
         a.TT = TT;
+        a.logTT = 0;
+        while ((1 << a.logTT) < TT) ++a.logTT;
         int threads = (maxG * TT + 63) / 64 * 64;
         threads = threads > 256 ? 256 : threads;
         threads = threads < TT ? TT : threads;
+        if (uni) threads = 64 * std::max(4, std::min(16, maxG));  // one wavefront per live parent sequence of the 64-track tile
+        if (ctx->th_force_threads > 0 && ctx->th_force_threads % TT == 0) threads = ctx->th_force_threads;
         const int64_t tpc = (chunk + TT - 1) / TT;
-        const int64_t ntiles = (int64_t)a.nchunks * tpc;
         int blocks_per_cu = (int)std::min<size_t>(8, (160 * 1024) / lds);
         blocks_per_cu = std::max(1, std::min(blocks_per_cu, 2048 / threads));
-        const int grid = (int)std::min<int64_t>(ntiles, (int64_t)ctx->n_cu * blocks_per_cu * ctx->oversub);
-        if ((size_t)grid > xt_max_grid(ctx)) return xt_fail(ctx, EXTRACK_E_HIP, "internal: grid exceeds the partial-sum reservation");
+        const int64_t target = (int64_t)ctx->n_cu * blocks_per_cu * ctx->th_oversub;
+        int64_t bpc = (target + a.nchunks - 1) / a.nchunks;
+        bpc = std::max<int64_t>(1, std::min<int64_t>(bpc, tpc));
+        a.bpc = (int32_t)bpc;
+        const int grid = (int)(a.nchunks * bpc);
+        if ((rc = xt_grow_partials(ctx, poff + (size_t)grid))) return rc;
         a.partials = ctx->d_partials + poff;
-#define XT_TH_APPLY_CALL(...) xt_th_launch_apply<__VA_ARGS__>(ctx, a, grid, threads, lds)
+#define XT_TH_APPLY_CALL(...) xt_th_launch_apply<__VA_ARGS__>(ctx, a, grid, threads, lds, uni)
         if (D == 1 && K == 1) e = XT_TH_APPLY_CALL(1, 1);
         else if (D == 2 && K == 1) e = XT_TH_APPLY_CALL(2, 1);
         else if (D == 2 && K == 2) e = XT_TH_APPLY_CALL(2, 2);

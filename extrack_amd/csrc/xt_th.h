@@ -21,7 +21,8 @@
 //     and the expansion by the S^ns new digits is folded into the merge: a group's new weight/mean/variance is a
 //     gather over its members (parent, new digits) of table lookups and FMAs.  The expanded S^ns-fold array of the
 //     reference never exists.  State lives in LDS as [sequence][field][track] with TT tracks of ONE chunk per workgroup
-//     (same plan -> uniform control flow, conflict-free LDS rows, the plan is staged once per step per workgroup).
+//     (same plan -> uniform control flow, conflict-free LDS rows); a workgroup is bound to one chunk and keeps the chunk's
+//     whole plan in LDS, members pre-resolved to (parent, table offset) words so the gather does no index arithmetic.
 #pragma once
 #include "xt_kernel.h"
 
@@ -43,27 +44,53 @@ struct XtThArgs {
     int32_t max_nb;        // max_nb_states (tracking.py:601-602: threshold *= 1.2 while exceeded)
     double threshold;
     double ll_const;       // -(L-1)*D/2*log(2*pi)
-    uint16_t* members;     // [nchunks][L][capE]
+    uint16_t* members;     // [nchunks][L][capE]  expanded index j of every member, sorted by group (diagnostics)
+    uint32_t* mpack;       // [nchunks][L][capE]  the same members as (parent << 16 | newest(parent) * G + r): what the apply kernel reads
     uint16_t* gstart;      // [nchunks][L][capE + 1]
+    uint8_t* gnew;         // [nchunks][L][capE]  newest state of every group after the merge
     int32_t* hdr;          // [nchunks][L][2]: nE (expanded sequences at step t), nG (groups after the merge, 0 if none)
-    int32_t* status;       // [nchunks][4]: overflow flag, max nE, max nG, -
+    int32_t* status;       // [nchunks][4]: overflow flag, max nE, max nG, sum over merged steps of nE
     double* ws;            // plan-kernel workspace, ws_stride doubles per workgroup
     int64_t ws_stride;
-    int32_t TT;            // apply kernel: tracks per workgroup tile (power of two)
+    int32_t TT, logTT;     // apply kernel: tracks per workgroup tile (power of two)
     int32_t capG;          // apply kernel: parent-sequence capacity of the LDS buffers
+    int32_t bpc;           // apply kernel: workgroups per chunk (a workgroup serves tiles of ONE chunk)
+    int32_t plan_cap;      // apply kernel: members of ALL merged steps kept in LDS (0: the plan is streamed step by step)
 };
 
-// View of a parent-sequence state buffer: entry (g, x) of track/pilot x lives at index g * gs + x * xs of every plane.
-struct XtThBuf {
-    double* zm;
-    double* m;  // [D] planes
-    double* u;  // [K] planes: variance (after a merge: s2 incl. the diffusion term; after an integration: l2*s2/(l2+s2))
-    int* ze;
+// Pointer to read-only data that is addressed with wave-uniform indices: on the device it lives in the constant address
+// space, which lets the compiler use scalar loads (s_load) instead of one vector load per lane.
+template <bool C, class T>
+struct XtCPtr {
+    typedef const T* type;
+    static XT_HD type make(const T* p) { return p; }
+};
+#if defined(__HIP_DEVICE_COMPILE__)
+template <class T>
+struct XtCPtr<true, T> {
+    typedef const __attribute__((address_space(4))) T* type;
+    static XT_HD type make(const T* p) { return (type)p; }
+};
+#endif
+
+// View of a parent-sequence state buffer {zm, m[D], u[K], ze} per entry.  u = variance: after a merge s2 incl. the diffusion
+// term, after an integration l2*s2/(l2+s2).
+//   AOS = false (plan kernel, global or LDS workspace): field planes of `plane` entries.
+//   AOS = true  (apply kernel, LDS): one (D+K+2)-double record per entry, so the fields sit at immediate offsets of ONE
+//   address computation; a record stride of 10 dwords (D=2, K=1) is bank-conflict free for 32 consecutive lanes.
+template <int D, int K, bool AOS>
+struct XtThView {
+    double* base;
     int plane;
+    static constexpr int ES = D + K + 2;
+    XT_HD double& zm(int i) const { return AOS ? base[i * ES] : base[i]; }
+    XT_HD double& m(int d, int i) const { return AOS ? base[i * ES + 1 + d] : base[(int64_t)plane * (1 + d) + i]; }
+    XT_HD double& u(int k, int i) const { return AOS ? base[i * ES + 1 + D + k] : base[(int64_t)plane * (1 + D + k) + i]; }
+    XT_HD int& ze(int i) const { return AOS ? ((int*)base)[(i * ES + 1 + D + K) * 2] : ((int*)(base + (int64_t)plane * (1 + D + K)))[i]; }
 };
 
 XT_HD int xt_th_hm(int F, int NS) { return F + NS; }
-XT_HD int64_t xt_th_buf_doubles(int plane, int D, int K) { return (int64_t)plane * (1 + D + K) + (plane + 1) / 2; }
+XT_HD int64_t xt_th_buf_doubles(int plane, int D, int K) { return (int64_t)plane * (2 + D + K); }
 XT_HD int64_t xt_th_ws_doubles(int capE, int D, int K, int F, int NS, int S)
 {
     const int plane = XT_TH_PILOT * capE;
@@ -71,42 +98,44 @@ XT_HD int64_t xt_th_ws_doubles(int capE, int D, int K, int F, int NS, int S)
 }
 XT_HD int xt_th_plan_lds_doubles(int S, int G, int capE, int D, int K)
 {
-    // tables | pivot m, s | wave counts | bytes: newest[2][capE], grouped[capE], mem u16[capE], gst u16[capE + 1]
-    const int bytes = 3 * capE + 2 * capE + 2 * (capE + 1);
+    // tables | pivot m, s | wave counts | bytes: mpk u32[capE], newest[2][capE], grouped[capE], mem u16[capE], gst u16[capE + 1]
+    const int bytes = 4 * capE + 3 * capE + 2 * capE + 2 * (capE + 1);
     return ((xt_tab_doubles(S, G) + 1) & ~1) + XT_TH_PILOT * (D + K) + 8 + (bytes + 7) / 8 + 2;
 }
-XT_HD int xt_th_apply_lds_doubles(int S, int G, int capG, int TT, int D, int K, int KS)
+XT_HD int xt_th_apply_lds_doubles(int S, int G, int capG, int TT, int D, int K, int KS, int L, int plan_cap, bool uni)
 {
     const int plane = capG * TT;
     const int capEl = capG * G;
-    const int bytes = 2 * capG + 2 * capEl + 2 * (capEl + 1) + 4 * TT;
+    // plan region: member words + group starts (+ per-step offsets) for all steps (plan_cap > 0) or for one step;
+    // none in the wave-uniform mode (scalar loads from global memory)
+    const int pm = uni ? 0 : (plan_cap > 0 ? plan_cap : capEl);
+    const int pg = uni ? 0 : (plan_cap > 0 ? plan_cap + L : capEl + 1);
+    const int bytes = 4 * pm + 2 * pg + 16 * L + capG + 4 * TT + 16;
     return ((xt_tab_doubles(S, G) + 1) & ~1) + 2 * (int)xt_th_buf_doubles(plane, D, K) + XT_TH_STAGE * (D + KS) * (TT + 1) + TT + (bytes + 7) / 8 + 2;
 }
 
-XT_HD void xt_th_carve(double*& w, XtThBuf& b, int plane, int D, int K)
+template <class V>
+XT_HD void xt_th_carve(double*& w, V& b, int plane, int D, int K)
 {
-    b.zm = w;
-    b.m = b.zm + plane;
-    b.u = b.m + (int64_t)D * plane;
-    b.ze = (int*)(b.u + (int64_t)K * plane);
+    b.base = w;
     b.plane = plane;
     w += xt_th_buf_doubles(plane, D, K);
 }
 
 // Gaussian integration of one position into one parent sequence, in place (tracking.py:76-98 log_integrale_dif without
 // the diffusion term, which depends on the new digits and is added in the gather).
-template <int D, int K>
-XT_HD void xt_th_integrate(const XtThBuf& b, int idx, const double* c, const double* l2, const double* T64)
+template <int D, int K, class V>
+XT_HD void xt_th_integrate(const V& b, int idx, const double* c, const double* l2, const double* T64)
 {
-    const double z = b.zm[idx];
+    const double z = b.zm(idx);
     double dm[D], dsq = 0.0;
     for (int d = 0; d < D; ++d) {
-        dm[d] = c[d] - b.m[d * b.plane + idx];
+        dm[d] = c[d] - b.m(d, idx);
         dsq = xt_fma(dm[d], dm[d], dsq);
     }
     double quad, gf, tt[K];
     if (K == 1) {
-        const double s2 = b.u[idx];
+        const double s2 = b.u(0, idx);
         const double r = xt_rcp(l2[0] + s2);
         tt[0] = s2 * r;
         quad = 0.5 * dsq * r;
@@ -115,7 +144,7 @@ XT_HD void xt_th_integrate(const XtThBuf& b, int idx, const double* c, const dou
         quad = 0.0;
         gf = 1.0;
         for (int d = 0; d < D; ++d) {
-            const double s2 = b.u[d * b.plane + idx];
+            const double s2 = b.u(d, idx);
             const double r = xt_rcp(l2[d] + s2);
             tt[d] = s2 * r;
             quad = xt_fma(0.5 * dm[d] * dm[d], r, quad);
@@ -126,62 +155,102 @@ XT_HD void xt_th_integrate(const XtThBuf& b, int idx, const double* c, const dou
     double p;
     int j, n;
     xt_exp_tab(-quad, p, j, n);
-    b.zm[idx] = z * (gf * T64[j]) * p;
-    const int en = b.ze[idx] + n;
-    b.ze[idx] = (z != 0.0 && en > XT_EMIN) ? en : XT_EMIN;
-    for (int d = 0; d < D; ++d) b.m[d * b.plane + idx] = xt_fma(dm[d], tt[K == 1 ? 0 : d], b.m[d * b.plane + idx]);
-    for (int k = 0; k < K; ++k) b.u[k * b.plane + idx] = l2[k] * tt[k];
+    b.zm(idx) = z * (gf * T64[j]) * p;
+    const int en = b.ze(idx) + n;
+    b.ze(idx) = (z != 0.0 && en > XT_EMIN) ? en : XT_EMIN;
+    for (int d = 0; d < D; ++d) b.m(d, idx) = xt_fma(dm[d], tt[K == 1 ? 0 : d], b.m(d, idx));
+    for (int k = 0; k < K; ++k) b.u(k, idx) = l2[k] * tt[k];
 }
 
-// One merge group of one track: gather over the members (parent g = j / G, new digits r = j % G) of the integrated
-// parents in `src`; weight = parent weight * T[newest(parent)][r], variance = parent variance + d2[newest(parent)][r]
-// (tracking.py:548-600 expansion + tracking.py:703-741 softmax-weighted merge, in the linear domain).
-template <int D, int K, class MemT, class NewT>
-XT_HD void xt_th_gather(const XtThBuf& src, int gs, int xoff, const MemT* members, int k0, int k1, int G, const NewT* newest,
-                        const double* TT, const double* TD2, const XtThBuf& dst, int didx)
+// One merge group of one track: gather over the members (parent g, table offset o = newest(g) * G + r, packed as
+// g << 16 | o) of the integrated parents in `src`; weight = parent weight * T[o], variance = parent variance + d2[o]
+// (tracking.py:548-600 expansion + tracking.py:703-741 softmax-weighted merge, in the linear domain).  Two passes: the
+// largest exponent of the group, then a branch-free accumulation (zero-weight parents carry exponent XT_EMIN and
+// scale to exactly 0).
+template <int D, int K, class V, class MemP, class TabP>
+XT_HD void xt_th_gather_regs(const V& src, int gs, int xoff, MemP members, int k0, int k1, TabP TT, TabP TD2, double& W, int& E, double* M,
+                             double* U)
 {
-    double W = 0.0, M[D], U[K];
-    int E = XT_EMIN;
-    for (int d = 0; d < D; ++d) M[d] = 0.0;
-    for (int k = 0; k < K; ++k) U[k] = 0.0;
     if (k1 - k0 == 1) {
-        const int j = members[k0];
-        const int g = j / G, r = j - g * G, o = (int)newest[g] * G + r, idx = g * gs + xoff;
-        W = src.zm[idx] * TT[o];
-        E = src.ze[idx];
-        for (int d = 0; d < D; ++d) M[d] = src.m[d * src.plane + idx];
-        for (int k = 0; k < K; ++k) U[k] = src.u[k * src.plane + idx] + TD2[o];
+        const uint32_t pk = members[k0];
+        const int o = (int)(pk & 0xffffu), idx = (int)(pk >> 16) * gs + xoff;
+        W = src.zm(idx) * TT[o];
+        E = src.ze(idx);
+        for (int d = 0; d < D; ++d) M[d] = src.m(d, idx);
+        for (int k = 0; k < K; ++k) U[k] = src.u(k, idx) + TD2[o];
     } else {
+        E = XT_EMIN;
         for (int kk = k0; kk < k1; ++kk) {
-            const int j = members[kk];
-            const int g = j / G, r = j - g * G, o = (int)newest[g] * G + r, idx = g * gs + xoff;
-            const double wm = src.zm[idx] * TT[o];
-            if (wm == 0.0) continue;
-            const int we = src.ze[idx];
-            double av;
-            if (we > E) {
-                const double sc = xt_ldexp(1.0, E - we);  // E - we may be hugely negative: saturates to 0
-                W *= sc;
-                for (int d = 0; d < D; ++d) M[d] *= sc;
-                for (int k = 0; k < K; ++k) U[k] *= sc;
-                E = we;
-                av = wm;
-            } else {
-                av = xt_ldexp(wm, we - E);
-            }
+            const int e = src.ze((int)(members[kk] >> 16) * gs + xoff);
+            E = e > E ? e : E;
+        }
+        W = 0.0;
+        for (int d = 0; d < D; ++d) M[d] = 0.0;
+        for (int k = 0; k < K; ++k) U[k] = 0.0;
+        for (int kk = k0; kk < k1; ++kk) {
+            const uint32_t pk = members[kk];
+            const int o = (int)(pk & 0xffffu), idx = (int)(pk >> 16) * gs + xoff;
+            const double av = xt_ldexp(src.zm(idx) * TT[o], src.ze(idx) - E);  // hugely negative shift saturates to 0
             W += av;
-            for (int d = 0; d < D; ++d) M[d] = xt_fma(av, src.m[d * src.plane + idx], M[d]);
-            for (int k = 0; k < K; ++k) U[k] = xt_fma(av, src.u[k * src.plane + idx] + TD2[o], U[k]);
+            for (int d = 0; d < D; ++d) M[d] = xt_fma(av, src.m(d, idx), M[d]);
+            for (int k = 0; k < K; ++k) U[k] = xt_fma(av, src.u(k, idx) + TD2[o], U[k]);
         }
         const double rW = (W == 0.0) ? 0.0 : xt_rcp(W);
         for (int d = 0; d < D; ++d) M[d] *= rW;
         for (int k = 0; k < K; ++k) U[k] *= rW;
     }
     const bool live = W != 0.0;
-    dst.zm[didx] = xt_frexp_mant(W);
-    dst.ze[didx] = live ? E + xt_frexp_exp(W) : XT_EMIN;
-    for (int d = 0; d < D; ++d) dst.m[d * dst.plane + didx] = M[d];
-    for (int k = 0; k < K; ++k) dst.u[k * dst.plane + didx] = U[k];
+    E = live ? E + xt_frexp_exp(W) : XT_EMIN;
+    W = xt_frexp_mant(W);
+}
+
+template <int D, int K, class V, class V2, class MemP, class TabP>
+XT_HD void xt_th_gather(const V& src, int gs, int xoff, MemP members, int k0, int k1, TabP TT, TabP TD2, const V2& dst, int didx)
+{
+    double W, M[D], U[K];
+    int E;
+    xt_th_gather_regs<D, K>(src, gs, xoff, members, k0, k1, TT, TD2, W, E, M, U);
+    dst.zm(didx) = W;
+    dst.ze(didx) = E;
+    for (int d = 0; d < D; ++d) dst.m(d, didx) = M[d];
+    for (int k = 0; k < K; ++k) dst.u(k, didx) = U[k];
+}
+
+// Gaussian integration of one position into a merged sequence held in registers; result stored as entry didx of dst.
+template <int D, int K, class V>
+XT_HD void xt_th_integrate_store(double z, int e, const double* m, const double* s2v, const double* c, const double* l2, const double* T64,
+                                 const V& dst, int didx)
+{
+    double dm[D], dsq = 0.0;
+    for (int d = 0; d < D; ++d) {
+        dm[d] = c[d] - m[d];
+        dsq = xt_fma(dm[d], dm[d], dsq);
+    }
+    double quad, gf, tt[K];
+    if (K == 1) {
+        const double r = xt_rcp(l2[0] + s2v[0]);
+        tt[0] = s2v[0] * r;
+        quad = 0.5 * dsq * r;
+        gf = xt_pow_half<D>(r);
+    } else {
+        quad = 0.0;
+        gf = 1.0;
+        for (int d = 0; d < D; ++d) {
+            const double r = xt_rcp(l2[d] + s2v[d]);
+            tt[d] = s2v[d] * r;
+            quad = xt_fma(0.5 * dm[d] * dm[d], r, quad);
+            gf *= r;
+        }
+        gf = sqrt(gf);
+    }
+    double p;
+    int j, n;
+    xt_exp_tab(-quad, p, j, n);
+    dst.zm(didx) = z * (gf * T64[j]) * p;
+    const int en = e + n;
+    dst.ze(didx) = (z != 0.0 && en > XT_EMIN) ? en : XT_EMIN;
+    for (int d = 0; d < D; ++d) dst.m(d, didx) = xt_fma(dm[d], tt[K == 1 ? 0 : d], m[d]);
+    for (int k = 0; k < K; ++k) dst.u(k, didx) = l2[k] * tt[k];
 }
 
 XT_HD double xt_th_l2_from_sigma(double s, int mode, const double* hdr)
@@ -212,7 +281,8 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
     double* pm = smem + ((ntab + 1) & ~1);
     double* ps = pm + XT_TH_PILOT * D;
     int* wcnt = (int*)(ps + XT_TH_PILOT * K);
-    uint8_t* newA = (uint8_t*)(wcnt + 16);
+    uint32_t* mpk = (uint32_t*)(wcnt + 16);
+    uint8_t* newA = (uint8_t*)(mpk + capE);
     uint8_t* newB = newA + capE;
     uint8_t* grouped = newB + capE;
     uint16_t* mem = (uint16_t*)(grouped + capE + (capE & 1));
@@ -220,7 +290,8 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
 
     double* w = a.ws + (int64_t)cx.block() * a.ws_stride;
     const int plane = XT_TH_PILOT * capE;
-    XtThBuf A, B;
+    typedef XtThView<D, K, false> View;
+    View A, B;
     xt_th_carve(w, A, plane, D, K);
     xt_th_carve(w, B, plane, D, K);
     double* sE = w;
@@ -242,7 +313,9 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
         const int n = (int)((a.N - c0) < a.chunk ? (a.N - c0) : a.chunk);
         const int P = n < XT_TH_PILOT ? n : XT_TH_PILOT;
         uint16_t* mem_g = a.members + (int64_t)ch * L * capE;
+        uint32_t* mpk_g = a.mpack + (int64_t)ch * L * capE;
         uint16_t* gst_g = a.gstart + (int64_t)ch * L * (capE + 1);
+        uint8_t* gnew_g = a.gnew + (int64_t)ch * L * capE;
         int32_t* hdr_g = a.hdr + (int64_t)ch * L * 2;
         cx.sync();  // tables loaded / previous chunk done
 
@@ -260,19 +333,19 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
             const int x = i / S, s = i - x * S, idx = x * capE + s;
             double l2[K];
             load_l2(x, 0, l2);
-            A.zm[idx] = hdr[8 + s];
-            A.ze[idx] = 0;
-            for (int d = 0; d < D; ++d) A.m[d * plane + idx] = a.tracks[((c0 + x) * L + 0) * D + d];
-            for (int k = 0; k < K; ++k) A.u[k * plane + idx] = l2[k];
+            A.zm(idx) = hdr[8 + s];
+            A.ze(idx) = 0;
+            for (int d = 0; d < D; ++d) A.m(d, idx) = a.tracks[((c0 + x) * L + 0) * D + d];
+            for (int k = 0; k < K; ++k) A.u(k, idx) = l2[k];
         }
         for (int i = tid; i < S * S; i += nt) catA[(i / S) * HM * S + (i % S)] = (i / S == i % S) ? 1.0 : 0.0;
         for (int i = tid; i < S; i += nt) newA[i] = (uint8_t)i;
-        int nPar = S, Hc = 1, maxE = 0, maxG = S, overflow = 0, nfuse = 0;
+        int nPar = S, Hc = 1, maxE = 0, maxG = S, overflow = 0, nfuse = 0, sumE = 0;
         double thr = a.threshold;
         uint8_t *nwA = newA, *nwB = newB;
         double *ctA = catA, *ctB = catB;
         unsigned long long *kyA = keyA, *kyB = keyB;
-        XtThBuf bA = A, bB = B;
+        View bA = A, bB = B;
         cx.sync();
 
         for (int t = 1; t <= L - 1; ++t) {
@@ -309,7 +382,7 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
                     for (int i = tid; i < P * nE; i += nt) {
                         const int x = i / nE, j = i - x * nE, g = j / G, r = j - g * G;
                         for (int k = 0; k < K; ++k)
-                            sE[k * plane + x * capE + j] = sqrt(bA.u[k * plane + x * capE + g] + TD2[(int)nwA[g] * G + r]);
+                            sE[k * plane + x * capE + j] = sqrt(bA.u(k, x * capE + g) + TD2[(int)nwA[g] * G + r]);
                     }
                     for (int i = tid; i < nE; i += nt) grouped[i] = 0;
                     cx.sync();
@@ -321,7 +394,7 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
                         for (int i = tid; i < P * (D + K); i += nt) {
                             const int x = i / (D + K), f = i - x * (D + K);
                             if (f < D)
-                                pm[x * D + f] = bA.m[f * plane + x * capE + gb];
+                                pm[x * D + f] = bA.m(f, x * capE + gb);
                             else
                                 ps[x * K + (f - D)] = sE[(f - D) * plane + x * capE + b];
                         }
@@ -340,7 +413,7 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
                                     int cm = 0, cs = 0;
                                     for (int x = 0; x < P; ++x) {
                                         double dmn = 0.0, dsd = 0.0, sj[K];
-                                        for (int d = 0; d < D; ++d) dmn += fabs(bA.m[d * plane + x * capE + gj] - pm[x * D + d]);
+                                        for (int d = 0; d < D; ++d) dmn += fabs(bA.m(d, x * capE + gj) - pm[x * D + d]);
                                         dmn = dmn / (double)D;
                                         for (int k = 0; k < K; ++k) {
                                             sj[k] = sE[k * plane + x * capE + j];
@@ -378,12 +451,19 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
                     if (tid == 0) gst[nG] = (uint16_t)mpos;
                 }
                 cx.sync();
+                // members as (parent, table offset) words: what the gathers (here and in the apply kernel) consume
+                for (int i = tid; i < nE; i += nt) {
+                    const int j = mem[i], g = j / G, r = j - g * G;
+                    mpk[i] = ((uint32_t)g << 16) | (uint32_t)((int)nwA[g] * G + r);
+                }
+                sumE += nE;
+                cx.sync();
                 // ---- merge: pilots' states, the shared state history, newest state of each group; publish the plan
                 const bool stay = t >= 2 && t >= a.min_len;
                 const double* TTl = TAB + (stay ? 1 : 0) * S * G;
                 for (int i = tid; i < P * nG; i += nt) {
                     const int x = i / nG, g2 = i - x * nG;
-                    xt_th_gather<D, K>(bA, 1, x * capE, mem, (int)gst[g2], (int)gst[g2 + 1], G, nwA, TTl, TD2, bB, x * capE + g2);
+                    xt_th_gather<D, K>(bA, 1, x * capE, mpk, (int)gst[g2], (int)gst[g2 + 1], TTl, TD2, bB, x * capE + g2);
                 }
                 const int Hn = (t == 1) ? He : (He < F ? He : F);  // fit mode keeps frame_len entries (tracking.py:699-701)
                 const int Pc = nfuse == 0 ? 1 : P;                 // rows of the reference's cat array (tracking.py:726-729)
@@ -409,8 +489,15 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
                     }
                     ctB[(g2 * HM + h) * S + s] = o;
                 }
-                for (int i = tid; i < nG; i += nt) nwB[i] = (uint8_t)((int)mem[gst[i]] % S);
-                for (int i = tid; i < nE; i += nt) mem_g[(int64_t)t * capE + i] = mem[i];
+                for (int i = tid; i < nG; i += nt) {
+                    const uint8_t nw = (uint8_t)((int)mem[gst[i]] % S);
+                    nwB[i] = nw;
+                    gnew_g[(int64_t)t * capE + i] = nw;
+                }
+                for (int i = tid; i < nE; i += nt) {
+                    mem_g[(int64_t)t * capE + i] = mem[i];
+                    mpk_g[(int64_t)t * capE + i] = mpk[i];
+                }
                 for (int i = tid; i <= nG; i += nt) gst_g[(int64_t)t * (capE + 1) + i] = gst[i];
                 cx.sync();
                 // history keys of the new parents: argmax over states of the first Fk entries
@@ -432,7 +519,7 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
                 }
                 if (t >= 2) ++nfuse;
                 {
-                    XtThBuf tb = bA;
+                    View tb = bA;
                     bA = bB;
                     bB = tb;
                     uint8_t* tn = nwA;
@@ -459,31 +546,45 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
             a.status[ch * 4 + 0] = overflow;
             a.status[ch * 4 + 1] = maxE;
             a.status[ch * 4 + 2] = maxG;
-            a.status[ch * 4 + 3] = 0;
+            a.status[ch * 4 + 3] = sumE;
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// APPLY kernel body: tiles of TT tracks of one chunk per workgroup.
+// APPLY kernel body: a workgroup serves tiles of TT tracks of ONE chunk.
+//   UNI = true : TT == 64, a wavefront = the 64 tracks of the tile for ONE parent / group at a time, so every plan and
+//                table index is wave-uniform: the plan (global memory) and the model tables are read with scalar loads,
+//                the vector unit only touches the per-track state records in LDS.
+//   UNI = false: TT < 64 (many live sequences: fewer tracks fit the LDS); a wavefront spans several groups, the chunk's
+//                plan is staged in LDS (all merged steps when they fit, else step by step).
 // ------------------------------------------------------------------------------------------------------------------
-template <int D, int K, class Ctx>
+template <int D, int K, bool UNI, class Ctx>
 XT_HD void xt_th_apply_body(const XtThArgs& a, Ctx& cx)
 {
-    const int S = a.S, G = a.G, L = a.L, capE = a.capE, TT = a.TT, capG = a.capG, KS = a.KS;
+    typedef XtThView<D, K, true> View;
+    const int S = a.S, G = a.G, L = a.L, capE = a.capE, TT = UNI ? 64 : a.TT, capG = a.capG, KS = a.KS;
+    const int logTT = UNI ? 6 : a.logTT;
     const int tid = cx.tid(), nt = cx.nthreads();
     const int TP = TT + 1;  // padded row of the position stage
     double* smem = cx.smem();
     const int ntab = xt_tab_doubles(S, G);
     for (int i = tid; i < ntab; i += nt) smem[i] = a.blob[i];
     const double* hdr = smem;
-    const double* TAB = smem + XT_BLOB_HDR;
-    const double* T64 = TAB + XT_NTAB * S * G;
-    const double* TD2 = TAB + 4 * S * G;
+    const double* TABl = smem + XT_BLOB_HDR;
+    const double* T64 = TABl + XT_NTAB * S * G;
+    // expansion tables: scalar loads straight from the blob when the index is wave-uniform, LDS otherwise
+    typedef XtCPtr<UNI, double> CD;
+    typedef XtCPtr<UNI, uint32_t> CU32;
+    typedef XtCPtr<UNI, uint16_t> CU16;
+    typedef XtCPtr<UNI, uint8_t> CU8;
+    typedef XtCPtr<UNI, int32_t> CI32;
+    const typename CD::type TAB = CD::make(UNI ? a.blob + XT_BLOB_HDR : TABl);
+    const typename CD::type TD2 = TAB + 4 * S * G;
     double* w = smem + ((ntab + 1) & ~1);
     const int plane = capG * TT;
     const int capEl = capG * G;
-    XtThBuf bA, bB;
+    View bA, bB;
     xt_th_carve(w, bA, plane, D, K);
     xt_th_carve(w, bB, plane, D, K);
     double* spos = w;
@@ -492,37 +593,72 @@ XT_HD void xt_th_apply_body(const XtThArgs& a, Ctx& cx)
     w += XT_TH_STAGE * KS * TP;
     double* red = w;
     w += TT;
+    const bool resident = !UNI && a.plan_cap > 0;
+    const int pmcap = UNI ? 0 : (resident ? a.plan_cap : capEl);
+    const int pgcap = UNI ? 0 : (resident ? a.plan_cap + L : capEl + 1);
     int* nanflag = (int*)w;
-    uint8_t* nwA = (uint8_t*)(nanflag + TT);
-    uint8_t* nwB = nwA + capG;
-    uint16_t* mem = (uint16_t*)(nwB + capG);
-    uint16_t* gst = mem + capEl;
+    int* pstep = nanflag + TT;               // [L][4]: member offset, gstart offset, nE, nG
+    uint32_t* pmem = (uint32_t*)(pstep + 4 * L);
+    uint16_t* pgst = (uint16_t*)(pmem + pmcap);
+    uint8_t* nfin = (uint8_t*)(pgst + pgcap + (pgcap & 1));  // newest state of the parents the last position sees
 
-    const int tpc = (a.chunk + TT - 1) / TT;
-    const int64_t ntiles = (int64_t)a.nchunks * tpc;
+    const int ch = cx.block() / a.bpc, sub = cx.block() - ch * a.bpc;
+    const int64_t c0 = (int64_t)ch * a.chunk;
+    const int n = (int)((a.N - c0) < a.chunk ? (a.N - c0) : a.chunk);
+    const int ntile = (n + TT - 1) >> logTT;
+    const uint32_t* mpk_g = a.mpack + (int64_t)ch * L * capE;
+    const uint16_t* gst_g = a.gstart + (int64_t)ch * L * (capE + 1);
+    const uint8_t* gnew_g = a.gnew + (int64_t)ch * L * capE;
+    const int32_t* hdr_g = a.hdr + (int64_t)ch * L * 2;
+    const typename CI32::type hdr_u = CI32::make(hdr_g);
+    const typename CU8::type gnew_u = CU8::make(gnew_g);
     const int x = tid & (TT - 1);  // TT is a power of two <= nthreads
-    const int g0 = tid / TT, gstep = nt / TT;
+    const int g0 = UNI ? cx.uniform(tid >> 6) : (tid >> logTT);
+    const int gstep = nt >> logTT;
     double my_ll = 0.0;  // meaningful in threads with g0 == 0
 
-    for (int64_t tile = cx.block(); tile < ntiles; tile += cx.nblocks()) {
-        const int ch = (int)(tile / tpc);
-        const int64_t first = (int64_t)ch * a.chunk + (tile - (int64_t)ch * tpc) * TT;
-        int64_t cend = (int64_t)(ch + 1) * a.chunk;
-        cend = cend < a.N ? cend : a.N;
-        if (first >= cend) continue;
-        const int nx = (int)((cend - first) < TT ? (cend - first) : TT);
-        const uint16_t* mem_g = a.members + (int64_t)ch * L * capE;
-        const uint16_t* gst_g = a.gstart + (int64_t)ch * L * (capE + 1);
-        const int32_t* hdr_g = a.hdr + (int64_t)ch * L * 2;
+    // ---- the chunk's plan -> LDS (all merged steps, or only the step table when it is streamed / read by scalar loads)
+    if (tid == 0) {
+        int om = 0, og = 0;
+        for (int t = 1; t <= L - 2; ++t) {
+            const int nE = hdr_g[t * 2], nG = hdr_g[t * 2 + 1];
+            pstep[t * 4 + 0] = resident ? om : 0;
+            pstep[t * 4 + 1] = resident ? og : 0;
+            pstep[t * 4 + 2] = nE;
+            pstep[t * 4 + 3] = nG;
+            om += nE;
+            og += nG + 1;
+        }
+    }
+    if (!UNI) {
+        if (L >= 3) {
+            const int nGl = hdr_g[(L - 2) * 2 + 1];
+            for (int i = tid; i < nGl; i += nt) nfin[i] = gnew_g[(int64_t)(L - 2) * capE + i];
+        } else {
+            for (int i = tid; i < S; i += nt) nfin[i] = (uint8_t)i;
+        }
+    }
+    cx.sync();
+    if (resident)
+        for (int t = 1; t <= L - 2; ++t) {
+            const int om = pstep[t * 4], og = pstep[t * 4 + 1], nE = pstep[t * 4 + 2], nG = pstep[t * 4 + 3];
+            for (int i = tid; i < nE; i += nt) pmem[om + i] = mpk_g[(int64_t)t * capE + i];
+            for (int i = tid; i <= nG; i += nt) pgst[og + i] = gst_g[(int64_t)t * (capE + 1) + i];
+        }
+
+    for (int tile = sub; tile < ntile; tile += a.bpc) {
+        const int64_t first = c0 + ((int64_t)tile << logTT);
+        const int nx = (int)((c0 + n - first) < TT ? (c0 + n - first) : TT);
         const bool act = x < nx;
-        cx.sync();  // tables loaded / previous tile's reads done
+        cx.sync();  // tables + plan loaded / previous tile's reads done
         if (tid < TT) nanflag[tid] = 0;
         cx.sync();
 
         auto stage = [&](int p0) {
+            const int np = (L - p0) < XT_TH_STAGE ? (L - p0) : XT_TH_STAGE;  // positions to stage
             for (int i = tid; i < TT * XT_TH_STAGE * D; i += nt) {
                 const int xx = i / (XT_TH_STAGE * D), o = i - xx * (XT_TH_STAGE * D);
-                if (xx < nx && p0 + o / D < L) {
+                if (xx < nx && o < np * D) {
                     const double v = a.tracks[((first + xx) * L + p0) * D + o];
                     spos[o * TP + xx] = v;
                     if (v != v) nanflag[xx] = 1;  // NaN input: the track's result becomes NaN, as in the reference
@@ -531,7 +667,7 @@ XT_HD void xt_th_apply_body(const XtThArgs& a, Ctx& cx)
             if (a.locerr_mode != 0)
                 for (int i = tid; i < TT * XT_TH_STAGE * KS; i += nt) {
                     const int xx = i / (XT_TH_STAGE * KS), o = i - xx * (XT_TH_STAGE * KS);
-                    if (xx < nx && p0 + o / KS < L) {
+                    if (xx < nx && o < np * KS) {
                         const double v = a.sigma[((first + xx) * L + p0) * KS + o];
                         ssig[o * TP + xx] = v;
                         if (v != v) nanflag[xx] = 1;
@@ -555,18 +691,42 @@ XT_HD void xt_th_apply_body(const XtThArgs& a, Ctx& cx)
             load_l2(0, l2);
             for (int g = g0; g < S; g += gstep) {
                 const int idx = g * TT + x;
-                bA.zm[idx] = hdr[8 + g];
-                bA.ze[idx] = 0;
-                for (int d = 0; d < D; ++d) bA.m[d * plane + idx] = spos[d * TP + x];
-                for (int k = 0; k < K; ++k) bA.u[k * plane + idx] = l2[k];
+                bA.zm(idx) = hdr[8 + g];
+                bA.ze(idx) = 0;
+                for (int d = 0; d < D; ++d) bA.m(d, idx) = spos[d * TP + x];
+                for (int k = 0; k < K; ++k) bA.u(k, idx) = l2[k];
             }
         }
-        if (tid < S) nwA[tid] = (uint8_t)tid;
         int nPar = S;
-        XtThBuf cur = bA, nxt = bB;
-        uint8_t *ncur = nwA, *nnxt = nwB;
+        View cur = bA, nxt = bB;
         cx.sync();
 
+        if (UNI) {
+            // merge step t fused with the integration of position t: the merged sequence never leaves the registers, one
+            // workgroup barrier per position
+            for (int t = 1; t <= L - 2; ++t) {
+                if ((t & (XT_TH_STAGE - 1)) == 0) stage(t);
+                const int nG = hdr_u[t * 2 + 1];
+                const typename CU32::type mem = CU32::make(mpk_g + (int64_t)t * capE);
+                const typename CU16::type gst = CU16::make(gst_g + (int64_t)t * (capE + 1));
+                const bool stay = t >= 2 && t >= a.min_len;
+                const double* TTl = TABl + (stay ? 1 : 0) * S * G;
+                double c[D], l2[K];
+                for (int d = 0; d < D; ++d) c[d] = spos[((t & (XT_TH_STAGE - 1)) * D + d) * TP + x];
+                load_l2(t, l2);
+                for (int g2 = g0; g2 < nG; g2 += gstep) {
+                    double W, M[D], U[K];
+                    int E;
+                    xt_th_gather_regs<D, K>(cur, TT, x, mem, (int)gst[g2], (int)gst[g2 + 1], TTl, TABl + 4 * S * G, W, E, M, U);
+                    xt_th_integrate_store<D, K>(W, E, M, U, c, l2, T64, nxt, g2 * TT + x);
+                }
+                cx.sync();
+                View tb = cur;
+                cur = nxt;
+                nxt = tb;
+                nPar = nG;
+            }
+        } else {
         for (int t = 1; t <= L - 1; ++t) {
             if (t >= 2) {
                 const int pos = t - 1;
@@ -579,35 +739,37 @@ XT_HD void xt_th_apply_body(const XtThArgs& a, Ctx& cx)
                 }
             }
             if (t < L - 1) {
-                const int nE = nPar * G;
-                const int nG = hdr_g[t * 2 + 1];
-                for (int i = tid; i < nE; i += nt) mem[i] = mem_g[(int64_t)t * capE + i];
-                for (int i = tid; i <= nG; i += nt) gst[i] = gst_g[(int64_t)t * (capE + 1) + i];
+                const int nE = UNI ? hdr_u[t * 2] : pstep[t * 4 + 2];
+                const int nG = UNI ? hdr_u[t * 2 + 1] : pstep[t * 4 + 3];
+                const typename CU32::type mem = CU32::make(UNI ? mpk_g + (int64_t)t * capE : pmem + pstep[t * 4]);
+                const typename CU16::type gst = CU16::make(UNI ? gst_g + (int64_t)t * (capE + 1) : pgst + pstep[t * 4 + 1]);
+                if (!UNI && !resident) {
+                    for (int i = tid; i < nE; i += nt) pmem[i] = mpk_g[(int64_t)t * capE + i];
+                    for (int i = tid; i <= nG; i += nt) pgst[i] = gst_g[(int64_t)t * (capE + 1) + i];
+                }
                 cx.sync();
                 const bool stay = t >= 2 && t >= a.min_len;
-                const double* TTl = TAB + (stay ? 1 : 0) * S * G;
-                if (act)
+                const typename CD::type TTl = TAB + (stay ? 1 : 0) * S * G;
+                if (act || UNI)  // UNI: keep the control flow wave-uniform (inactive lanes work on slot garbage, never stored out)
                     for (int g2 = g0; g2 < nG; g2 += gstep)
-                        xt_th_gather<D, K>(cur, TT, x, mem, (int)gst[g2], (int)gst[g2 + 1], G, ncur, TTl, TD2, nxt, g2 * TT + x);
-                for (int i = tid; i < nG; i += nt) nnxt[i] = (uint8_t)((int)mem[gst[i]] % S);
+                        xt_th_gather<D, K>(cur, TT, x, mem, (int)gst[g2], (int)gst[g2 + 1], TTl, TD2, nxt, g2 * TT + x);
                 cx.sync();
-                XtThBuf tb = cur;
+                View tb = cur;
                 cur = nxt;
                 nxt = tb;
-                uint8_t* tn = ncur;
-                ncur = nnxt;
-                nnxt = tn;
                 nPar = nG;
+                (void)nE;
             }
         }
         cx.sync();
+        }
 
         // ---- last position (+ leaving/bleaching term, tracking.py:611-633): reduction over (parent, new digits)
         const int tl = L - 1;
-        if ((tl & (XT_TH_STAGE - 1)) == 0 && tl != 0) stage(tl);
+        if ((tl & (XT_TH_STAGE - 1)) == 0) stage(tl);
         if (act) {
             const bool stay = tl >= 2 && tl >= a.min_len;
-            const double* TF = TAB + ((a.isBL ? 2 : 0) + (stay ? 1 : 0)) * S * G;
+            const typename CD::type TF = TAB + ((a.isBL ? 2 : 0) + (stay ? 1 : 0)) * S * G;
             double cl[D], l2l[K];
             for (int d = 0; d < D; ++d) cl[d] = spos[((tl & (XT_TH_STAGE - 1)) * D + d) * TP + x];
             load_l2(tl, l2l);
@@ -615,47 +777,46 @@ XT_HD void xt_th_apply_body(const XtThArgs& a, Ctx& cx)
                 const int idx = g * TT + x;
                 XtAcc acc;
                 acc.clear();
-                const double zq = cur.zm[idx];
-                if (zq != 0.0) {
-                    const int eq = cur.ze[idx];
-                    const int o = (int)ncur[g] * G;
-                    double dq[D], uq[K], dsq = 0.0;
-                    for (int d = 0; d < D; ++d) {
-                        dq[d] = cl[d] - cur.m[d * plane + idx];
-                        dsq = xt_fma(dq[d], dq[d], dsq);
-                    }
-                    for (int k = 0; k < K; ++k) uq[k] = cur.u[k * plane + idx];
-                    for (int r = 0; r < G; ++r) {
-                        double quad, gf;
-                        if (K == 1) {
-                            const double rr = xt_rcp(TD2[o + r] + uq[0] + l2l[0]);
-                            quad = 0.5 * dsq * rr;
-                            gf = xt_pow_half<D>(rr);
-                        } else {
-                            quad = 0.0;
-                            gf = 1.0;
-                            for (int d = 0; d < D; ++d) {
-                                const double rr = xt_rcp(TD2[o + r] + uq[d] + l2l[d]);
-                                quad = xt_fma(0.5 * dq[d] * dq[d], rr, quad);
-                                gf *= rr;
-                            }
-                            gf = sqrt(gf);
-                        }
-                        double p;
-                        int j, n;
-                        xt_exp_tab(-quad, p, j, n);
-                        acc.add(zq * TF[o + r] * (gf * T64[j]) * p, eq + n);
-                    }
+                const double zq = cur.zm(idx);
+                const int eq = cur.ze(idx);
+                const int nw = UNI ? (L >= 3 ? (int)gnew_u[(int64_t)(L - 2) * capE + g] : g) : (int)nfin[g];
+                const int o = nw * G;
+                double dq[D], uq[K], dsq = 0.0;
+                for (int d = 0; d < D; ++d) {
+                    dq[d] = cl[d] - cur.m(d, idx);
+                    dsq = xt_fma(dq[d], dq[d], dsq);
                 }
-                nxt.zm[idx] = acc.m;
-                nxt.ze[idx] = acc.e;
+                for (int k = 0; k < K; ++k) uq[k] = cur.u(k, idx);
+                for (int r = 0; r < G; ++r) {
+                    double quad, gf;
+                    if (K == 1) {
+                        const double rr = xt_rcp(TD2[o + r] + uq[0] + l2l[0]);
+                        quad = 0.5 * dsq * rr;
+                        gf = xt_pow_half<D>(rr);
+                    } else {
+                        quad = 0.0;
+                        gf = 1.0;
+                        for (int d = 0; d < D; ++d) {
+                            const double rr = xt_rcp(TD2[o + r] + uq[d] + l2l[d]);
+                            quad = xt_fma(0.5 * dq[d] * dq[d], rr, quad);
+                            gf *= rr;
+                        }
+                        gf = sqrt(gf);
+                    }
+                    double p;
+                    int j, n2;
+                    xt_exp_tab(-quad, p, j, n2);
+                    acc.add(zq * TF[o + r] * (gf * T64[j]) * p, eq + n2);
+                }
+                nxt.zm(idx) = acc.m;
+                nxt.ze(idx) = acc.e;
             }
         }
         cx.sync();
         if (act && g0 == 0) {
             XtAcc tot;
             tot.clear();
-            for (int g = 0; g < nPar; ++g) tot.add(nxt.zm[g * TT + x], nxt.ze[g * TT + x]);
+            for (int g = 0; g < nPar; ++g) tot.add(nxt.zm(g * TT + x), nxt.ze(g * TT + x));
             const double ll = nanflag[x] ? NAN : log(tot.m) + (double)tot.e * XT_LN2 + a.ll_const;
             if (a.ll_out) a.ll_out[first + x] = ll;
             my_ll += ll;
@@ -667,8 +828,8 @@ XT_HD void xt_th_apply_body(const XtThArgs& a, Ctx& cx)
     if (g0 == 0) red[x] = my_ll;
     cx.sync();
     if (tid == 0) {
-        double s = 0.0;
-        for (int i = 0; i < TT; ++i) s += red[i];
-        a.partials[cx.block()] = s;
+        double s2 = 0.0;
+        for (int i = 0; i < TT; ++i) s2 += red[i];
+        a.partials[cx.block()] = s2;
     }
 }

@@ -22,6 +22,7 @@ struct HostCtx {
     pthread_barrier_t* wbar_ = nullptr;  // this wave's barrier
     double* wscr_ = nullptr;             // this wave's 64-entry shuffle scratch
     int lane() const { return tid_ & 63; }
+    int uniform(int v) const { return v; }
     int wave_in_block() const { return tid_ >> 6; }
     int waves_per_block() const { return nthreads_ >> 6; }
     void wave_sync() { pthread_barrier_wait(wbar_); }
@@ -355,12 +356,16 @@ extern "C" int xt_emul_th_run(const double* tracks, const double* sigma, long lo
     a.threshold = threshold;
     a.ll_const = -(double)(L - 1) * D * 0.5 * XT_LOG2PI;
     std::vector<uint16_t> mem((size_t)a.nchunks * L * capE, 0), gst((size_t)a.nchunks * L * (capE + 1), 0);
+    std::vector<uint32_t> mpack((size_t)a.nchunks * L * capE, 0);
+    std::vector<uint8_t> gnew((size_t)a.nchunks * L * capE, 0);
+    a.mpack = mpack.data();
+    a.gnew = gnew.data();
     std::vector<int32_t> hdr((size_t)a.nchunks * L * 2, 0), status((size_t)a.nchunks * 4, 0);
     a.members = mem.data();
     a.gstart = gst.data();
     a.hdr = hdr.data();
     a.status = status.data();
-    const int plan_blocks = nblocks < a.nchunks ? nblocks : a.nchunks;
+    const int plan_blocks = (nblocks < 0 ? -nblocks : nblocks) < a.nchunks ? (nblocks < 0 ? -nblocks : nblocks) : a.nchunks;
     a.ws_stride = xt_th_ws_doubles(capE, D, K, F, NS, S);
     std::vector<double> ws((size_t)a.ws_stride * plan_blocks, 0.0);
     a.ws = ws.data();
@@ -380,17 +385,37 @@ extern "C" int xt_emul_th_run(const double* tracks, const double* sigma, long lo
     if (members_out) memcpy(members_out, mem.data(), mem.size() * sizeof(uint16_t));
     if (gstart_out) memcpy(gstart_out, gst.data(), gst.size() * sizeof(uint16_t));
     if (status_out) memcpy(status_out, status.data(), status.size() * sizeof(int32_t));
-    int maxG = 0;
+    int maxG = 0, sumE = 0;
     for (int c = 0; c < a.nchunks; ++c) {
         if (status[(size_t)c * 4]) return -5;  // plan capacity overflow
         maxG = status[(size_t)c * 4 + 2] > maxG ? status[(size_t)c * 4 + 2] : maxG;
+        sumE = status[(size_t)c * 4 + 3] > sumE ? status[(size_t)c * 4 + 3] : sumE;
     }
     a.capG = maxG;
     a.TT = TT;
-    std::vector<double> partials(nblocks, 0.0);
+    a.logTT = 0;
+    while ((1 << a.logTT) < TT) ++a.logTT;
+    // nblocks doubles as "workgroups per chunk"; a negative value asks for the streamed-plan mode
+    a.bpc = nblocks < 0 ? -nblocks : nblocks;
+    a.plan_cap = nblocks < 0 ? 0 : (sumE > 0 ? sumE : 1);
+    const int grid = a.nchunks * a.bpc;
+    std::vector<double> partials(grid, 0.0);
     a.partials = partials.data();
-    const size_t apply_lds = xt_th_apply_lds_doubles(S, G, maxG, TT, D, K, a.KS);
-    TH_RUN(xt_th_apply_body, nblocks, apply_threads, apply_lds);
+    const bool uni = TT == 64;
+    const size_t apply_lds = xt_th_apply_lds_doubles(S, G, maxG, TT, D, K, a.KS, L, a.plan_cap, uni);
+#define TH_APPLY_UNI(DD, KK) th_emul_blocks(grid, apply_threads, apply_lds, [&](HostCtx& cx) { xt_th_apply_body<DD, KK, true>(a, cx); })
+#define TH_APPLY_GEN(DD, KK) th_emul_blocks(grid, apply_threads, apply_lds, [&](HostCtx& cx) { xt_th_apply_body<DD, KK, false>(a, cx); })
+#define TH_APPLY(DD, KK)              \
+    do {                              \
+        if (uni) TH_APPLY_UNI(DD, KK); \
+        else TH_APPLY_GEN(DD, KK);    \
+    } while (0)
+    if (D == 1 && K == 1) TH_APPLY(1, 1);
+    else if (D == 2 && K == 1) TH_APPLY(2, 1);
+    else if (D == 2 && K == 2) TH_APPLY(2, 2);
+    else if (D == 3 && K == 1) TH_APPLY(3, 1);
+    else if (D == 3 && K == 3) TH_APPLY(3, 3);
+    else return -3;
 #undef TH_RUN
     double s = 0.0;
     for (double p : partials) s += p;
