@@ -43,6 +43,7 @@ struct DevCtx {
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
+    __device__ __forceinline__ unsigned long long ballot(bool flag) { return __ballot(flag); }
     // number of lanes below this one with flag set; total = lanes of the wave with flag set
     __device__ __forceinline__ int wave_rank(bool flag, int& total)
     {
@@ -161,6 +162,7 @@ struct extrack_ctx {
     double* d_th_ws = nullptr;  // plan-kernel workspace
     size_t th_ws_cap = 0;
     int th_capE = 128;          // plan capacity (expanded sequences per step); grows on overflow
+    int th_learnP = 0, th_learnE = 0;  // live parent / expanded sequence counts seen by the last plan (+ headroom): LDS workspace sizing
     std::vector<int32_t> th_status_host;
     float th_plan_ms = 0.f;
     int th_force_tt = 0, th_force_threads = 0, th_oversub = 2;  // tuning knobs (EXTRACK_TH_TT / _THREADS / _OVERSUB)
@@ -840,6 +842,7 @@ extern "C" int extrack_loglik_th(extrack_ctx* ctx, const extrack_model* m, doubl
         a.ll_const = -(double)(b.L - 1) * D * 0.5 * XT_LOG2PI;
         hipError_t e = hipSuccess;
         int maxG = 0, sumE = 0;
+        bool force_global = false;
         for (;;) {  // plan, growing the capacity on overflow
             int capE = ctx->th_capE;
             while (capE < S * G) capE *= 2;
@@ -853,18 +856,35 @@ extern "C" int extrack_loglik_th(extrack_ctx* ctx, const extrack_model* m, doubl
             a.hdr = b.th_hdr;
             a.status = b.th_status;
             const int grid = std::min<int64_t>(a.nchunks, (int64_t)ctx->n_cu * 2);
-            a.ws_stride = xt_th_ws_doubles(capE, D, K, F, NS, S);
-            const size_t need = (size_t)a.ws_stride * grid * sizeof(double);
-            if (need > ctx->th_ws_cap) {
-                XT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-                if (ctx->d_th_ws) (void)hipFree(ctx->d_th_ws);
-                ctx->d_th_ws = nullptr;
-                ctx->th_ws_cap = 0;
-                XT_HIP(ctx, hipMalloc(&ctx->d_th_ws, need));
-                ctx->th_ws_cap = need;
+            // pilot-track state: in LDS when the sequence counts of the previous evaluation (+25 %) fit 64 KiB, else in a
+            // global workspace sized for the full plan capacity
+            size_t lds = (size_t)xt_th_plan_lds_doubles(S, G, capE, D, K) * sizeof(double);
+            bool lds_mode = false;
+            a.wsP = a.wsE = capE;
+            if (ctx->th_learnE > 0 && !force_global) {
+                const int wp = std::min(capE, std::max(S * G, ctx->th_learnP)), we = std::min(capE, std::max(S * G, ctx->th_learnE));
+                const size_t need = lds + (size_t)xt_th_ws_doubles(wp, we, D, K, F, NS, S) * sizeof(double);
+                if (need <= 64 * 1024) {
+                    lds_mode = true;
+                    lds = need;
+                    a.wsP = wp;
+                    a.wsE = we;
+                }
+            }
+            a.ws_lds = lds_mode ? 1 : 0;
+            a.ws_stride = xt_th_ws_doubles(a.wsP, a.wsE, D, K, F, NS, S);
+            if (!lds_mode) {
+                const size_t need = (size_t)a.ws_stride * grid * sizeof(double);
+                if (need > ctx->th_ws_cap) {
+                    XT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                    if (ctx->d_th_ws) (void)hipFree(ctx->d_th_ws);
+                    ctx->d_th_ws = nullptr;
+                    ctx->th_ws_cap = 0;
+                    XT_HIP(ctx, hipMalloc(&ctx->d_th_ws, need));
+                    ctx->th_ws_cap = need;
+                }
             }
             a.ws = ctx->d_th_ws;
-            const size_t lds = (size_t)xt_th_plan_lds_doubles(S, G, capE, D, K) * sizeof(double);
             if (lds > 160 * 1024) return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "plan tables do not fit the 160 KiB LDS of a CU");
 #define XT_TH_PLAN_CALL(...) xt_th_launch_plan<__VA_ARGS__>(ctx, a, grid, lds)
             if (D == 1 && K == 1) e = XT_TH_PLAN_CALL(1, 1);
@@ -887,7 +907,15 @@ extern "C" int extrack_loglik_th(extrack_ctx* ctx, const extrack_model* m, doubl
                 maxG = std::max(maxG, ctx->th_status_host[(size_t)c * 4 + 2]);
                 sumE = std::max(sumE, ctx->th_status_host[(size_t)c * 4 + 3]);
             }
-            if (!over) break;
+            if (!over) {
+                ctx->th_learnP = maxG + maxG / 4 + 2;
+                ctx->th_learnE = maxE + maxE / 4 + 2;
+                break;
+            }
+            if (lds_mode) {  // the learned LDS capacities were too small for these parameters: redo with the global workspace
+                force_global = true;
+                continue;
+            }
             int ncap = capE;
             while (ncap < maxE) ncap *= 2;
             if (ncap == capE) ncap *= 2;

@@ -50,8 +50,10 @@ struct XtThArgs {
     uint8_t* gnew;         // [nchunks][L][capE]  newest state of every group after the merge
     int32_t* hdr;          // [nchunks][L][2]: nE (expanded sequences at step t), nG (groups after the merge, 0 if none)
     int32_t* status;       // [nchunks][4]: overflow flag, max nE, max nG, sum over merged steps of nE
-    double* ws;            // plan-kernel workspace, ws_stride doubles per workgroup
+    double* ws;            // plan-kernel workspace in global memory, ws_stride doubles per workgroup (ws_lds == 0)
     int64_t ws_stride;
+    int32_t ws_lds;        // 1: the pilot-track state lives in LDS (capacities learned from the previous evaluation)
+    int32_t wsP, wsE;      // workspace capacities: parent sequences / expanded sequences per pilot track
     int32_t TT, logTT;     // apply kernel: tracks per workgroup tile (power of two)
     int32_t capG;          // apply kernel: parent-sequence capacity of the LDS buffers
     int32_t bpc;           // apply kernel: workgroups per chunk (a workgroup serves tiles of ONE chunk)
@@ -73,6 +75,8 @@ struct XtCPtr<true, T> {
 };
 #endif
 
+XT_HD int xt_popc64(unsigned long long v) { return __builtin_popcountll(v); }
+
 // View of a parent-sequence state buffer {zm, m[D], u[K], ze} per entry.  u = variance: after a merge s2 incl. the diffusion
 // term, after an integration l2*s2/(l2+s2).
 //   AOS = false (plan kernel, global or LDS workspace): field planes of `plane` entries.
@@ -91,15 +95,15 @@ struct XtThView {
 
 XT_HD int xt_th_hm(int F, int NS) { return F + NS; }
 XT_HD int64_t xt_th_buf_doubles(int plane, int D, int K) { return (int64_t)plane * (2 + D + K); }
-XT_HD int64_t xt_th_ws_doubles(int capE, int D, int K, int F, int NS, int S)
+XT_HD int64_t xt_th_ws_doubles(int wsP, int wsE, int D, int K, int F, int NS, int S)
 {
-    const int plane = XT_TH_PILOT * capE;
-    return 2 * xt_th_buf_doubles(plane, D, K) + (int64_t)K * plane + 2 * (int64_t)capE * xt_th_hm(F, NS) * S + 2 * (int64_t)capE + 8;
+    return 2 * xt_th_buf_doubles(XT_TH_PILOT * wsP, D, K) + (int64_t)K * XT_TH_PILOT * wsE + 2 * (int64_t)wsP * xt_th_hm(F, NS) * S +
+           2 * (int64_t)wsP + 8;
 }
 XT_HD int xt_th_plan_lds_doubles(int S, int G, int capE, int D, int K)
 {
     // tables | pivot m, s | wave counts | bytes: mpk u32[capE], newest[2][capE], grouped[capE], mem u16[capE], gst u16[capE + 1]
-    const int bytes = 4 * capE + 3 * capE + 2 * capE + 2 * (capE + 1);
+    const int bytes = 4 * capE + 4 * capE + 2 * capE + 2 * (capE + 1);
     return ((xt_tab_doubles(S, G) + 1) & ~1) + XT_TH_PILOT * (D + K) + 8 + (bytes + 7) / 8 + 2;
 }
 XT_HD int xt_th_apply_lds_doubles(int S, int G, int capG, int TT, int D, int K, int KS, int L, int plan_cap, bool uni)
@@ -285,23 +289,26 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
     uint8_t* newA = (uint8_t*)(mpk + capE);
     uint8_t* newB = newA + capE;
     uint8_t* grouped = newB + capE;
-    uint16_t* mem = (uint16_t*)(grouped + capE + (capE & 1));
+    uint8_t* sel = grouped + capE;
+    uint16_t* mem = (uint16_t*)(sel + capE);
     uint16_t* gst = mem + capE;
 
-    double* w = a.ws + (int64_t)cx.block() * a.ws_stride;
-    const int plane = XT_TH_PILOT * capE;
+    // pilot-track state: LDS when the learned capacities fit (a.ws_lds), else this workgroup's slice of the global workspace
+    const int wsP = a.wsP, wsE = a.wsE;
+    double* w = a.ws_lds ? smem + xt_th_plan_lds_doubles(S, G, capE, D, K) : a.ws + (int64_t)cx.block() * a.ws_stride;
+    const int plane = XT_TH_PILOT * wsE;  // sE plane
     typedef XtThView<D, K, false> View;
     View A, B;
-    xt_th_carve(w, A, plane, D, K);
-    xt_th_carve(w, B, plane, D, K);
+    xt_th_carve(w, A, XT_TH_PILOT * wsP, D, K);
+    xt_th_carve(w, B, XT_TH_PILOT * wsP, D, K);
     double* sE = w;
     w += (int64_t)K * plane;
     double* catA = w;
-    w += (int64_t)capE * HM * S;
+    w += (int64_t)wsP * HM * S;
     double* catB = w;
-    w += (int64_t)capE * HM * S;
+    w += (int64_t)wsP * HM * S;
     unsigned long long* keyA = (unsigned long long*)w;
-    w += capE;
+    w += wsP;
     unsigned long long* keyB = (unsigned long long*)w;
     const int Fk = F - NS;  // parent history entries inside the frame_len window of an expanded sequence
     int pwS[8];
@@ -330,7 +337,7 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
 
         // ---- position 0: S parents (the oldest state a), history = [a]
         for (int i = tid; i < P * S; i += nt) {
-            const int x = i / S, s = i - x * S, idx = x * capE + s;
+            const int x = i / S, s = i - x * S, idx = x * wsP + s;
             double l2[K];
             load_l2(x, 0, l2);
             A.zm(idx) = hdr[8 + s];
@@ -356,12 +363,12 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
                     double c[D], l2[K];
                     for (int d = 0; d < D; ++d) c[d] = a.tracks[((c0 + x) * L + pos) * D + d];
                     load_l2(x, pos, l2);
-                    xt_th_integrate<D, K>(bA, x * capE + g, c, l2, T64);
+                    xt_th_integrate<D, K>(bA, x * wsP + g, c, l2, T64);
                 }
                 cx.sync();
             }
             const int nE = nPar * G;
-            if (nE > capE) {
+            if (nE > capE || nE > wsE) {
                 overflow = 1;
                 maxE = nE;
                 break;
@@ -382,7 +389,7 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
                     for (int i = tid; i < P * nE; i += nt) {
                         const int x = i / nE, j = i - x * nE, g = j / G, r = j - g * G;
                         for (int k = 0; k < K; ++k)
-                            sE[k * plane + x * capE + j] = sqrt(bA.u(k, x * capE + g) + TD2[(int)nwA[g] * G + r]);
+                            sE[k * plane + x * wsE + j] = sqrt(bA.u(k, x * wsP + g) + TD2[(int)nwA[g] * G + r]);
                     }
                     for (int i = tid; i < nE; i += nt) grouped[i] = 0;
                     cx.sync();
@@ -394,40 +401,55 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
                         for (int i = tid; i < P * (D + K); i += nt) {
                             const int x = i / (D + K), f = i - x * (D + K);
                             if (f < D)
-                                pm[x * D + f] = bA.m(f, x * capE + gb);
+                                pm[x * D + f] = bA.m(f, x * wsP + gb);
                             else
-                                ps[x * K + (f - D)] = sE[(f - D) * plane + x * capE + b];
+                                ps[x * K + (f - D)] = sE[(f - D) * plane + x * wsE + b];
                         }
                         if (tid == 0) gst[nG] = (uint16_t)mpos;
                         cx.sync();
+                        // candidates x pilots in parallel: a wavefront evaluates two candidates at a time, 32 pilot slots each;
+                        // the per-candidate counts of the reference's np.mean(...) > 0.8 tests come from wave ballots
+                        {
+                            const int lane = cx.lane(), half = lane >> 5, x = lane & 31;
+                            const unsigned long long hmask = half ? 0xffffffff00000000ull : 0x00000000ffffffffull;
+                            for (int jb = b + 2 * cx.wave_in_block(); jb < nE; jb += 2 * cx.waves_per_block()) {
+                                const int j = jb + half;
+                                int mode = 0;  // 0: not selected, 1: selected without test, 2: mean / std test on the pilots
+                                int gj = 0;
+                                if (j < nE && !grouped[j]) {
+                                    gj = j / G;
+                                    const int rj = j - gj * G;
+                                    if (j == b || (useA && rj == rb && kyA[gj] == kyA[gb]))
+                                        mode = 1;  // the pivot itself / same last frame_len states
+                                    else if (rj % S == rb % S)
+                                        mode = 2;
+                                }
+                                int cm = 0, cs = 0;
+                                double dmn = 0.0, dsd = 0.0, sj[K];
+                                const bool live = mode == 2 && x < P;
+                                if (live) {
+                                    for (int d = 0; d < D; ++d) dmn += fabs(bA.m(d, x * wsP + gj) - pm[x * D + d]);
+                                    dmn = dmn / (double)D;
+                                    for (int k = 0; k < K; ++k) {
+                                        sj[k] = sE[k * plane + x * wsE + j];
+                                        dsd += fabs(sj[k] - ps[x * K + k]);
+                                    }
+                                    dsd = dsd / (double)K;
+                                }
+                                for (int k = 0; k < K; ++k) {
+                                    const unsigned long long bm = cx.ballot(live && (dmn / sj[k] < thr));
+                                    const unsigned long long bs = cx.ballot(live && (dsd / sj[k] < thr));
+                                    cm += xt_popc64(bm & hmask);
+                                    cs += xt_popc64(bs & hmask);
+                                }
+                                const bool flag = mode == 1 || (mode == 2 && ((double)cm / cntn > 0.8) && ((double)cs / cntn > 0.8));
+                                if (x == 0 && j < nE) sel[j] = flag ? 1 : 0;
+                            }
+                        }
+                        cx.sync();
                         for (int base = b; base < nE; base += nt) {
                             const int j = base + tid;
-                            bool flag = false;
-                            if (j < nE && !grouped[j]) {
-                                const int gj = j / G, rj = j - gj * G;
-                                if (j == b) {
-                                    flag = true;
-                                } else if (useA && rj == rb && kyA[gj] == kyA[gb]) {
-                                    flag = true;  // same last frame_len states
-                                } else if (rj % S == rb % S) {
-                                    int cm = 0, cs = 0;
-                                    for (int x = 0; x < P; ++x) {
-                                        double dmn = 0.0, dsd = 0.0, sj[K];
-                                        for (int d = 0; d < D; ++d) dmn += fabs(bA.m(d, x * capE + gj) - pm[x * D + d]);
-                                        dmn = dmn / (double)D;
-                                        for (int k = 0; k < K; ++k) {
-                                            sj[k] = sE[k * plane + x * capE + j];
-                                            dsd += fabs(sj[k] - ps[x * K + k]);
-                                        }
-                                        dsd = dsd / (double)K;
-                                        for (int k = 0; k < K; ++k) {
-                                            cm += (dmn / sj[k] < thr) ? 1 : 0;
-                                            cs += (dsd / sj[k] < thr) ? 1 : 0;
-                                        }
-                                    }
-                                    flag = ((double)cm / cntn > 0.8) && ((double)cs / cntn > 0.8);
-                                }
-                            }
+                            const bool flag = j < nE && sel[j] != 0;
                             // ordered compaction of the selected candidates (ascending j, as np.where gives them)
                             int wtot;
                             const int rank = cx.wave_rank(flag, wtot);
@@ -451,6 +473,11 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
                     if (tid == 0) gst[nG] = (uint16_t)mpos;
                 }
                 cx.sync();
+                if (nG > wsP) {
+                    overflow = 1;
+                    maxG = nG;
+                    break;
+                }
                 // members as (parent, table offset) words: what the gathers (here and in the apply kernel) consume
                 for (int i = tid; i < nE; i += nt) {
                     const int j = mem[i], g = j / G, r = j - g * G;
@@ -463,7 +490,7 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
                 const double* TTl = TAB + (stay ? 1 : 0) * S * G;
                 for (int i = tid; i < P * nG; i += nt) {
                     const int x = i / nG, g2 = i - x * nG;
-                    xt_th_gather<D, K>(bA, 1, x * capE, mpk, (int)gst[g2], (int)gst[g2 + 1], TTl, TD2, bB, x * capE + g2);
+                    xt_th_gather<D, K>(bA, 1, x * wsP, mpk, (int)gst[g2], (int)gst[g2 + 1], TTl, TD2, bB, x * wsP + g2);
                 }
                 const int Hn = (t == 1) ? He : (He < F ? He : F);  // fit mode keeps frame_len entries (tracking.py:699-701)
                 const int Pc = nfuse == 0 ? 1 : P;                 // rows of the reference's cat array (tracking.py:726-729)

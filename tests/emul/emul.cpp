@@ -35,6 +35,16 @@ struct HostCtx {
         return o;
     }
     int shfl_xor_i32(int v, int m) { return (int)shfl_xor_f64((double)v, m); }
+    unsigned long long ballot(bool flag)
+    {
+        wscr_[lane()] = flag ? 1.0 : 0.0;
+        pthread_barrier_wait(wbar_);
+        unsigned long long m = 0;
+        for (int i = 0; i < 64; ++i)
+            if (wscr_[i] != 0.0) m |= 1ull << i;
+        pthread_barrier_wait(wbar_);
+        return m;
+    }
     int wave_rank(bool flag, int& total)
     {
         wscr_[lane()] = flag ? 1.0 : 0.0;
@@ -366,10 +376,17 @@ extern "C" int xt_emul_th_run(const double* tracks, const double* sigma, long lo
     a.hdr = hdr.data();
     a.status = status.data();
     const int plan_blocks = (nblocks < 0 ? -nblocks : nblocks) < a.nchunks ? (nblocks < 0 ? -nblocks : nblocks) : a.nchunks;
-    a.ws_stride = xt_th_ws_doubles(capE, D, K, F, NS, S);
+    a.wsP = a.wsE = capE;
+    a.ws_lds = 0;
+    if (getenv("XT_EMUL_TH_WSP")) {  // exercise the LDS-resident workspace with explicit capacities
+        a.wsP = atoi(getenv("XT_EMUL_TH_WSP"));
+        a.wsE = atoi(getenv("XT_EMUL_TH_WSE"));
+        a.ws_lds = 1;
+    }
+    a.ws_stride = xt_th_ws_doubles(a.wsP, a.wsE, D, K, F, NS, S);
     std::vector<double> ws((size_t)a.ws_stride * plan_blocks, 0.0);
     a.ws = ws.data();
-    const size_t plan_lds = xt_th_plan_lds_doubles(S, G, capE, D, K);
+    const size_t plan_lds = xt_th_plan_lds_doubles(S, G, capE, D, K) + (a.ws_lds ? (size_t)a.ws_stride : 0);
     const int plan_threads = apply_threads;  // same block size for both kernels in the emulation
 #define TH_RUN(BODY, NB, NT, LDS)                                                                             \
     do {                                                                                                      \
