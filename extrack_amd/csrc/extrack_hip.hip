@@ -93,11 +93,11 @@ __global__ void __launch_bounds__(256) xt_th_plan_kernel(XtThArgs a)
     xt_th_plan_body<D, K>(a, cx);
 }
 
-template <int D, int K, bool UNI>
+template <int D, int K, bool UNI, bool SINGLE>
 __global__ void __launch_bounds__(1024) xt_th_apply_kernel(XtThArgs a)
 {
     DevCtx cx;
-    xt_th_apply_body<D, K, UNI>(a, cx);
+    xt_th_apply_body<D, K, UNI, SINGLE>(a, cx);
 }
 
 // Fixed-order reduction of the per-block partial sums (deterministic for a given launch geometry).
@@ -165,6 +165,7 @@ struct extrack_ctx {
     int th_learnP = 0, th_learnE = 0;  // live parent / expanded sequence counts seen by the last plan (+ headroom): LDS workspace sizing
     std::vector<int32_t> th_status_host;
     float th_plan_ms = 0.f;
+    int th_force_single = 0;
     int th_force_tt = 0, th_force_threads = 0, th_oversub = 2;  // tuning knobs (EXTRACK_TH_TT / _THREADS / _OVERSUB)
     std::string err;
 };
@@ -230,6 +231,7 @@ extern "C" int extrack_create(int device_id, extrack_ctx** out)
         int v = atoi(ev);
         if (v >= 64 && v <= 1024 && v % 64 == 0) c->th_force_threads = v;
     }
+    if (const char* ev = getenv("EXTRACK_TH_SINGLE")) c->th_force_single = atoi(ev) != 0;
     if (const char* ev = getenv("EXTRACK_TH_OVERSUB")) {
         int v = atoi(ev);
         if (v >= 1 && v <= 64) c->th_oversub = v;
@@ -725,19 +727,22 @@ static hipError_t xt_th_launch_plan(extrack_ctx* ctx, const XtThArgs& a, int gri
     return hipGetLastError();
 }
 
-template <int D, int K>
-static hipError_t xt_th_launch_apply(extrack_ctx* ctx, const XtThArgs& a, int grid, int threads, size_t lds, bool uni)
+template <int D, int K, bool UNI, bool SINGLE>
+static hipError_t xt_th_launch_apply_v(extrack_ctx* ctx, const XtThArgs& a, int grid, int threads, size_t lds)
 {
-    if (uni) {
-        hipError_t e = xt_th_set_lds(ctx, xt_th_apply_kernel<D, K, true>, lds);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((xt_th_apply_kernel<D, K, true>), dim3(grid), dim3(threads), lds, ctx->stream, a);
-        return hipGetLastError();
-    }
-    hipError_t e = xt_th_set_lds(ctx, xt_th_apply_kernel<D, K, false>, lds);
+    hipError_t e = xt_th_set_lds(ctx, xt_th_apply_kernel<D, K, UNI, SINGLE>, lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((xt_th_apply_kernel<D, K, false>), dim3(grid), dim3(threads), lds, ctx->stream, a);
+    hipLaunchKernelGGL((xt_th_apply_kernel<D, K, UNI, SINGLE>), dim3(grid), dim3(threads), lds, ctx->stream, a);
     return hipGetLastError();
+}
+
+// mode 0: general (fewer than 64 tracks per tile), 1: wave-uniform, two state buffers, 2: wave-uniform, one state buffer
+template <int D, int K>
+static hipError_t xt_th_launch_apply(extrack_ctx* ctx, const XtThArgs& a, int grid, int threads, size_t lds, int mode)
+{
+    if (mode == 2) return xt_th_launch_apply_v<D, K, true, true>(ctx, a, grid, threads, lds);
+    if (mode == 1) return xt_th_launch_apply_v<D, K, true, false>(ctx, a, grid, threads, lds);
+    return xt_th_launch_apply_v<D, K, false, false>(ctx, a, grid, threads, lds);
 }
 
 // Grows the partial-sum array to n entries, keeping what earlier launches of this evaluation wrote.
@@ -927,17 +932,27 @@ extern "C" int extrack_loglik_th(extrack_ctx* ctx, const extrack_model* m, doubl
         // small enough (always, for the usual 2-3 state models); TT = as many tracks as keep the tile within ~48 KiB of LDS
         a.capG = maxG;
         a.plan_cap = (size_t)sumE * 6 + 2 * (size_t)b.L <= 24 * 1024 ? std::max(sumE, 1) : 0;
-        auto lds_of = [&](int tt) { return (size_t)xt_th_apply_lds_doubles(S, G, maxG, tt, D, K, a.KS, b.L, a.plan_cap, tt == 64) * 8; };
-        // 64 tracks per tile (wave-uniform scalar path) when two workgroups of that size fit a CU's LDS, else fewer tracks
+        auto lds_of = [&](int tt, bool single = false) {
+            return (size_t)xt_th_apply_lds_doubles(S, G, maxG, tt, D, K, a.KS, b.L, a.plan_cap, tt == 64, single) * 8;
+        };
+        // 64 tracks per tile (wave-uniform scalar path): two state buffers when two such workgroups fit a CU's LDS, one
+        // buffer (merged sequences wait in registers) while at most XT_TH_GPW groups fall to a wavefront; else fewer tracks
         int TT = 64;
+        int single_buf = 0;
         if (ctx->th_force_tt > 0) TT = ctx->th_force_tt;
         else if (chunk < 48 || lds_of(64) > 76 * 1024) {
-            TT = 32;
-            while (TT > 1 && (TT > chunk * 2 || lds_of(TT) > 48 * 1024)) TT >>= 1;
+            if (chunk >= 48 && maxG <= 16 * XT_TH_GPW && lds_of(64, true) <= 160 * 1024) {
+                single_buf = 1;
+            } else {
+                TT = 32;
+                while (TT > 1 && (TT > chunk * 2 || lds_of(TT) > 48 * 1024)) TT >>= 1;
+            }
         }
-        while (TT > 1 && lds_of(TT) > 160 * 1024) TT >>= 1;
+        if (TT == 64 && ctx->th_force_single && maxG <= 16 * XT_TH_GPW) single_buf = 1;
+        while (TT > 1 && lds_of(TT, single_buf) > 160 * 1024) TT >>= 1;
+        if (TT != 64) single_buf = 0;
         const bool uni = TT == 64;
-        const size_t lds = lds_of(TT);
+        const size_t lds = lds_of(TT, single_buf);
         if (lds > 160 * 1024) return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "live state sequences do not fit the 160 KiB LDS of a CU");
         a.TT = TT;
         a.logTT = 0;
@@ -946,6 +961,7 @@ extern "C" int extrack_loglik_th(extrack_ctx* ctx, const extrack_model* m, doubl
         threads = threads > 256 ? 256 : threads;
         threads = threads < TT ? TT : threads;
         if (uni) threads = 64 * std::max(4, std::min(16, maxG));  // one wavefront per live parent sequence of the 64-track tile
+        if (uni && single_buf && ctx->th_force_threads > 0 && (ctx->th_force_threads / 64) * XT_TH_GPW < maxG) ctx->th_force_threads = 0;
         if (ctx->th_force_threads > 0 && ctx->th_force_threads % TT == 0) threads = ctx->th_force_threads;
         const int64_t tpc = (chunk + TT - 1) / TT;
         int blocks_per_cu = (int)std::min<size_t>(8, (160 * 1024) / lds);
@@ -957,7 +973,7 @@ extern "C" int extrack_loglik_th(extrack_ctx* ctx, const extrack_model* m, doubl
         const int grid = (int)(a.nchunks * bpc);
         if ((rc = xt_grow_partials(ctx, poff + (size_t)grid))) return rc;
         a.partials = ctx->d_partials + poff;
-#define XT_TH_APPLY_CALL(...) xt_th_launch_apply<__VA_ARGS__>(ctx, a, grid, threads, lds, uni)
+#define XT_TH_APPLY_CALL(...) xt_th_launch_apply<__VA_ARGS__>(ctx, a, grid, threads, lds, uni ? (single_buf ? 2 : 1) : 0)
         if (D == 1 && K == 1) e = XT_TH_APPLY_CALL(1, 1);
         else if (D == 2 && K == 1) e = XT_TH_APPLY_CALL(2, 1);
         else if (D == 2 && K == 2) e = XT_TH_APPLY_CALL(2, 2);

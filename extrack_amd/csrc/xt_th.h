@@ -29,6 +29,7 @@
 #define XT_TH_PILOT 30  // tracking.py:678-679
 #define XT_TH_STAGE 8   // positions staged in LDS per refill (apply kernel)
 #define XT_TH_MAXCAP 8192
+#define XT_TH_GPW 4      // single-buffer apply kernel: merge groups per wavefront held in registers
 
 struct XtThArgs {
     const double* tracks;  // [N][L][D]
@@ -106,7 +107,7 @@ XT_HD int xt_th_plan_lds_doubles(int S, int G, int capE, int D, int K)
     const int bytes = 4 * capE + 4 * capE + 2 * capE + 2 * (capE + 1);
     return ((xt_tab_doubles(S, G) + 1) & ~1) + XT_TH_PILOT * (D + K) + 8 + (bytes + 7) / 8 + 2;
 }
-XT_HD int xt_th_apply_lds_doubles(int S, int G, int capG, int TT, int D, int K, int KS, int L, int plan_cap, bool uni)
+XT_HD int xt_th_apply_lds_doubles(int S, int G, int capG, int TT, int D, int K, int KS, int L, int plan_cap, bool uni, bool single = false)
 {
     const int plane = capG * TT;
     const int capEl = capG * G;
@@ -115,7 +116,8 @@ XT_HD int xt_th_apply_lds_doubles(int S, int G, int capG, int TT, int D, int K, 
     const int pm = uni ? 0 : (plan_cap > 0 ? plan_cap : capEl);
     const int pg = uni ? 0 : (plan_cap > 0 ? plan_cap + L : capEl + 1);
     const int bytes = 4 * pm + 2 * pg + 16 * L + capG + 4 * TT + 16;
-    return ((xt_tab_doubles(S, G) + 1) & ~1) + 2 * (int)xt_th_buf_doubles(plane, D, K) + XT_TH_STAGE * (D + KS) * (TT + 1) + TT + (bytes + 7) / 8 + 2;
+    return ((xt_tab_doubles(S, G) + 1) & ~1) + (single ? 1 : 2) * (int)xt_th_buf_doubles(plane, D, K) + XT_TH_STAGE * (D + KS) * (TT + 1) + TT +
+           (bytes + 7) / 8 + 2;
 }
 
 template <class V>
@@ -583,10 +585,12 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
 //   UNI = true : TT == 64, a wavefront = the 64 tracks of the tile for ONE parent / group at a time, so every plan and
 //                table index is wave-uniform: the plan (global memory) and the model tables are read with scalar loads,
 //                the vector unit only touches the per-track state records in LDS.
+//                SINGLE = true: ONE state buffer (half the LDS, for models with more live sequences): every wavefront merges
+//                its (at most XT_TH_GPW) groups into registers, a barrier, then the integrated results overwrite the buffer.
 //   UNI = false: TT < 64 (many live sequences: fewer tracks fit the LDS); a wavefront spans several groups, the chunk's
 //                plan is staged in LDS (all merged steps when they fit, else step by step).
 // ------------------------------------------------------------------------------------------------------------------
-template <int D, int K, bool UNI, class Ctx>
+template <int D, int K, bool UNI, bool SINGLE, class Ctx>
 XT_HD void xt_th_apply_body(const XtThArgs& a, Ctx& cx)
 {
     typedef XtThView<D, K, true> View;
@@ -613,7 +617,10 @@ XT_HD void xt_th_apply_body(const XtThArgs& a, Ctx& cx)
     const int capEl = capG * G;
     View bA, bB;
     xt_th_carve(w, bA, plane, D, K);
-    xt_th_carve(w, bB, plane, D, K);
+    if (UNI && SINGLE)
+        bB = bA;  // the tail then parks its per-parent terms in the records it has just consumed
+    else
+        xt_th_carve(w, bB, plane, D, K);
     double* spos = w;
     w += XT_TH_STAGE * D * TP;
     double* ssig = w;
@@ -741,6 +748,32 @@ XT_HD void xt_th_apply_body(const XtThArgs& a, Ctx& cx)
                 double c[D], l2[K];
                 for (int d = 0; d < D; ++d) c[d] = spos[((t & (XT_TH_STAGE - 1)) * D + d) * TP + x];
                 load_l2(t, l2);
+                if (SINGLE) {
+                    // half the LDS: every wavefront first merges its (at most XT_TH_GPW) groups into registers, and the
+                    // integrated results overwrite the buffer only after all wavefronts have finished reading it
+                    double Wq[XT_TH_GPW], Mq[XT_TH_GPW][D], Uq[XT_TH_GPW][K];
+                    int Eq[XT_TH_GPW];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+                    for (int q = 0; q < XT_TH_GPW; ++q) {
+                        const int g2 = g0 + q * gstep;
+                        if (g2 < nG)
+                            xt_th_gather_regs<D, K>(cur, TT, x, mem, (int)gst[g2], (int)gst[g2 + 1], TTl, TABl + 4 * S * G, Wq[q], Eq[q], Mq[q],
+                                                    Uq[q]);
+                    }
+                    cx.sync();
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+                    for (int q = 0; q < XT_TH_GPW; ++q) {
+                        const int g2 = g0 + q * gstep;
+                        if (g2 < nG) xt_th_integrate_store<D, K>(Wq[q], Eq[q], Mq[q], Uq[q], c, l2, T64, cur, g2 * TT + x);
+                    }
+                    cx.sync();
+                    nPar = nG;
+                    continue;
+                }
                 for (int g2 = g0; g2 < nG; g2 += gstep) {
                     double W, M[D], U[K];
                     int E;

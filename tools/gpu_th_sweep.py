@@ -13,8 +13,8 @@ N, L = 1_000_000, 30
 Ds, Tm, Fs = [0.0, 0.25], [[.9, .1], [.1, .9]], [.6, .4]
 X = synth.brownian_tracks(N, L, Ds, Tm, Fs, seed=0)
 ds = np.sqrt(2 * np.maximum(np.array(Ds), 1e-3 * 0.25) * 0.02)
-for tt, thr, ov in [(0, 0, 2), (64, 256, 2), (64, 512, 2), (64, 768, 2), (64, 1024, 2), (64, 768, 1), (64, 768, 4), (64, 384, 2), (32, 256, 2), (32, 512, 2), (32, 1024, 2), (16, 512, 2)]:
-    for k, v in (("EXTRACK_TH_TT", tt), ("EXTRACK_TH_THREADS", thr), ("EXTRACK_TH_OVERSUB", ov)):
+for tt, thr, ov, sg in [(0, 0, 2, 0), (64, 768, 2, 0), (64, 256, 2, 1), (64, 192, 2, 1), (64, 384, 2, 1), (64, 512, 2, 1), (64, 256, 4, 1), (64, 256, 1, 1)]:
+    for k, v in (("EXTRACK_TH_TT", tt), ("EXTRACK_TH_THREADS", thr), ("EXTRACK_TH_OVERSUB", ov), ("EXTRACK_TH_SINGLE", sg)):
         if v:
             os.environ[k] = str(v)
         else:
@@ -26,5 +26,5 @@ for tt, thr, ov in [(0, 0, 2), (64, 256, 2), (64, 512, 2), (64, 768, 2), (64, 10
     for _ in range(5):
         tot = ts.loglik_th(model, 0.2, 120, 2000)
     wall = (time.perf_counter() - t0) / 5
-    print("TT=%d threads=%d oversub=%d: wall %.2f ms total %.4f launch %s" % (tt, thr, ov, wall * 1e3, tot, ts.ctx.last_launch_info()), flush=True)
+    print("single=%d " % sg, end=""); print("TT=%d threads=%d oversub=%d: wall %.2f ms total %.4f launch %s" % (tt, thr, ov, wall * 1e3, tot, ts.ctx.last_launch_info()), flush=True)
     ts.close()
