@@ -1,0 +1,77 @@
+"""The threshold-fusion kernel bodies (extrack_amd/csrc/xt_th.h: plan kernel, the three apply-kernel variants), compiled for the
+host and run on CPU threads (tests/emul), against the reference-generated golden vectors and the pinned oracle
+(oracle/oracle_th.py).  The merge groups (index work) must be identical, log-likelihoods within 1e-10.  The GPU run of the
+same source is tests/test_hip_th_parity.py."""
+import json
+import os
+import shutil
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from oracle import oracle_th as OT
+from oracle.oracle_np import p_stay_table
+
+pytestmark = pytest.mark.skipif(shutil.which("g++") is None, reason="needs g++")
+
+
+def _emul():
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "emul"))
+    import run_emul as E
+    return E
+
+
+def test_th_bodies_on_golden_subset():
+    E = _emul()
+    meta = json.load(open(os.path.join(GOLDEN, "th_kernel_cases.json")))
+    data = np.load(os.path.join(GOLDEN, "th_kernel_cases.npz"))
+    rows = [r for r in meta if not r["do_preds"]][::9]
+    worst = 0.0
+    for row in rows:
+        pre = "t%04d_" % row["id"]
+        Cs, LE, ds, Fs, T = [data[pre + k] for k in ("Cs", "LE", "ds", "Fs", "T")]
+        ps = p_stay_table(ds, len(ds), row["ns"], row["cell_dims"])
+        tr = []
+        OT.p_cs_inter_bound_stats_th(Cs, LE, ds, Fs, T, row["pBL"], row["isBL"], row["cell_dims"], row["ns"], row["F"], 0, row["min_len"],
+                                     row["threshold"], row["max_nb_states"], trace=tr)
+        ll, tot, plan, hdr, status = E.run_th(Cs, LE, ds, Fs, T, row["pBL"], row["isBL"], ps, row["ns"], row["F"], row["min_len"],
+                                              row["threshold"], row["max_nb_states"], chunk=len(Cs), capE=256, TT=8, threads=64, nblocks=2)
+        for i, t in enumerate(range(2, row["L"] - 1)):
+            assert [list(g) for g in tr[i]] == [list(g) for g in plan[0][t]], (row, t)
+        worst = max(worst, np.abs(ll - data[pre + "LPC"]).max())
+        assert abs(tot - ll.sum()) < 1e-9
+    assert len(rows) >= 20 and worst < 1e-10, (len(rows), worst)
+
+
+@pytest.mark.parametrize("variant", ["general", "streamed", "uniform", "uniform_single", "lds_workspace"])
+def test_th_apply_variants_chunked(variant, monkeypatch):
+    """Two chunks (the second ragged), 3 states, per-peak errors: every apply-kernel variant and the LDS-resident plan workspace."""
+    E = _emul()
+    rng = np.random.default_rng(17)
+    S, ns, F, L, N, chunk = 3, 1, 4, 9, 100, 70
+    ds = np.sort(rng.uniform(0.005, 0.2, S))
+    Fs = rng.dirichlet(np.ones(S) * 2)
+    T = rng.uniform(0.02, 0.25, (S, S))
+    T[np.arange(S), np.arange(S)] = 0
+    T[np.arange(S), np.arange(S)] = 1 - T.sum(1)
+    Cs = np.cumsum(rng.normal(0, 1, (N, L, 2)) * ds[rng.integers(0, S, (N, L, 1))], 1) + rng.normal(0, 0.02, (N, L, 2))
+    LE = rng.uniform(0.01, 0.04, (N, L, 2))
+    ps = p_stay_table(ds, S, ns, [0.8])
+    ref = np.concatenate([OT.proba_cs_th(Cs[a:a + chunk], LE[a:a + chunk], ds, Fs, T, 0.07, 1, [0.8], ns, F, 3, 0.2, 30) for a in range(0, N, chunk)])
+    kw = dict(chunk=chunk, capE=128, TT=8, threads=128, nblocks=2)
+    if variant == "streamed":
+        kw["nblocks"] = -2
+    elif variant == "uniform":
+        kw.update(TT=64, threads=256)
+    elif variant == "uniform_single":
+        kw.update(TT=64, threads=256)
+        monkeypatch.setenv("XT_EMUL_TH_SINGLE", "1")
+    elif variant == "lds_workspace":
+        monkeypatch.setenv("XT_EMUL_TH_WSP", "24")
+        monkeypatch.setenv("XT_EMUL_TH_WSE", "60")
+    ll, tot, plan, hdr, status = E.run_th(Cs, LE, ds, Fs, T, 0.07, 1, ps, ns, F, 3, 0.2, 30, **kw)
+    assert status[:, 0].max() == 0
+    assert np.abs(ll - ref).max() < 1e-10
+    assert abs(tot - ref.sum()) < 1e-9
