@@ -86,11 +86,11 @@ __global__ void __launch_bounds__(MAXT) xt_entry_kernel(XtKernelArgs a)
     xt_entry_body<GP, D, K>(a, cx);
 }
 
-template <int D, int K>
+template <int D, int K, bool PREDS>
 __global__ void __launch_bounds__(256) xt_th_plan_kernel(XtThArgs a)
 {
     DevCtx cx;
-    xt_th_plan_body<D, K>(a, cx);
+    xt_th_plan_body<D, K, PREDS>(a, cx);
 }
 
 template <int D, int K, bool UNI, bool SINGLE>
@@ -721,9 +721,9 @@ static hipError_t xt_th_set_lds(extrack_ctx* ctx, KernT kern, size_t lds)
 template <int D, int K>
 static hipError_t xt_th_launch_plan(extrack_ctx* ctx, const XtThArgs& a, int grid, size_t lds)
 {
-    hipError_t e = xt_th_set_lds(ctx, xt_th_plan_kernel<D, K>, lds);
+    hipError_t e = xt_th_set_lds(ctx, xt_th_plan_kernel<D, K, false>, lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((xt_th_plan_kernel<D, K>), dim3(grid), dim3(256), lds, ctx->stream, a);
+    hipLaunchKernelGGL((xt_th_plan_kernel<D, K, false>), dim3(grid), dim3(256), lds, ctx->stream, a);
     return hipGetLastError();
 }
 
@@ -844,6 +844,7 @@ extern "C" int extrack_loglik_th(extrack_ctx* ctx, const extrack_model* m, doubl
         a.nchunks = (int32_t)((b.N + chunk - 1) / chunk);
         a.max_nb = max_nb_states;
         a.threshold = threshold;
+        a.pcap = std::min(chunk, XT_TH_PILOT);
         a.ll_const = -(double)(b.L - 1) * D * 0.5 * XT_LOG2PI;
         hipError_t e = hipSuccess;
         int maxG = 0, sumE = 0;
@@ -868,7 +869,7 @@ extern "C" int extrack_loglik_th(extrack_ctx* ctx, const extrack_model* m, doubl
             a.wsP = a.wsE = capE;
             if (ctx->th_learnE > 0 && !force_global) {
                 const int wp = std::min(capE, std::max(S * G, ctx->th_learnP)), we = std::min(capE, std::max(S * G, ctx->th_learnE));
-                const size_t need = lds + (size_t)xt_th_ws_doubles(wp, we, D, K, F, NS, S) * sizeof(double);
+                const size_t need = lds + (size_t)xt_th_ws_doubles(wp, we, D, K, F, NS, S, a.pcap) * sizeof(double);
                 if (need <= 64 * 1024) {
                     lds_mode = true;
                     lds = need;
@@ -877,7 +878,7 @@ extern "C" int extrack_loglik_th(extrack_ctx* ctx, const extrack_model* m, doubl
                 }
             }
             a.ws_lds = lds_mode ? 1 : 0;
-            a.ws_stride = xt_th_ws_doubles(a.wsP, a.wsE, D, K, F, NS, S);
+            a.ws_stride = xt_th_ws_doubles(a.wsP, a.wsE, D, K, F, NS, S, a.pcap);
             if (!lds_mode) {
                 const size_t need = (size_t)a.ws_stride * grid * sizeof(double);
                 if (need > ctx->th_ws_cap) {
@@ -1005,6 +1006,147 @@ extern "C" int extrack_loglik_th(extrack_ctx* ctx, const extrack_model* m, doubl
     XT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     *total_ll = *ctx->h_total;
     return EXTRACK_OK;
+}
+
+template <int D, int K>
+static hipError_t xt_th_launch_predict(extrack_ctx* ctx, const XtThArgs& a, int grid, int threads, size_t lds)
+{
+    hipError_t e = xt_th_set_lds(ctx, xt_th_plan_kernel<D, K, true>, lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((xt_th_plan_kernel<D, K, true>), dim3(grid), dim3(threads), lds, ctx->stream, a);
+    return hipGetLastError();
+}
+
+extern "C" int extrack_predict_th(extrack_ctx* ctx, const extrack_model* m, int32_t bucket_id, double threshold, int32_t max_nb_states,
+                                  int32_t nb_max, double* preds)
+{
+    if (!ctx || !preds) return xt_fail(ctx, EXTRACK_E_INVALID, "null argument");
+    int rc = xt_validate_model(ctx, m);
+    if (rc) return rc;
+    if (bucket_id < 0 || bucket_id >= (int)ctx->buckets.size()) return xt_fail(ctx, EXTRACK_E_INVALID, "bucket id out of range");
+    if (m->nb_substeps != 1) return xt_fail(ctx, EXTRACK_E_INVALID, "state predictions require nb_substeps == 1");
+    if (nb_max < 1) return xt_fail(ctx, EXTRACK_E_INVALID, "nb_max must be >= 1");
+    if (nb_max > XT_TH_PILOT)
+        return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "nb_max > 30 (chunks larger than the pilot set) is not built for the threshold-fusion posteriors");
+    if (!(threshold >= 0.0)) return xt_fail(ctx, EXTRACK_E_INVALID, "threshold must be >= 0");
+    if (m->frame_len <= 1 || m->frame_len > 15) return xt_fail(ctx, EXTRACK_E_INVALID, "frame_len must be in (1, 15]");
+    XT_HIP(ctx, hipSetDevice(ctx->device));
+    XtModelHost mh;
+    xt_model_host(m, mh);
+    std::vector<double> blob;
+    int G = 0;
+    std::string err = xt_th_build_blob(mh, blob, G);
+    if (!err.empty()) return xt_fail(ctx, EXTRACK_E_INVALID, err);
+    if ((rc = xt_upload_blob(ctx, blob))) return rc;
+    XtBucket& b = ctx->buckets[bucket_id];
+    const int S = m->n_states, F = m->frame_len, D = b.D;
+    int K;
+    if (m->locerr_mode == 0) {
+        K = m->locerr_dims;
+    } else {
+        if (!b.d_sigma) return xt_fail(ctx, EXTRACK_E_INVALID, "per-peak localisation error mode but the bucket has no sigma");
+        K = b.KS;
+    }
+    if (!((K == 1) || (K == D && D > 1))) return xt_fail(ctx, EXTRACK_E_INVALID, "locerr_dims must be 1 or the track dimensionality");
+    const size_t nbytes = (size_t)b.N * b.L * S * sizeof(double);
+    double* d_preds = nullptr;
+    XT_HIP(ctx, hipMalloc(&d_preds, nbytes));
+    XtThArgs a;
+    memset(&a, 0, sizeof(a));
+    a.tracks = b.d_tracks;
+    a.sigma = m->locerr_mode ? b.d_sigma : nullptr;
+    a.blob = ctx->d_blob;
+    a.preds_out = d_preds;
+    a.N = b.N;
+    a.L = b.L;
+    a.S = S;
+    a.NS = 1;
+    a.G = G;
+    a.F = F;
+    a.isBL = (b.L != m->max_len) ? 1 : 0;
+    a.min_len = m->min_len;
+    a.locerr_mode = m->locerr_mode;
+    a.KS = b.KS ? b.KS : 1;
+    a.chunk = nb_max;
+    a.nchunks = (int32_t)((b.N + nb_max - 1) / nb_max);
+    a.max_nb = max_nb_states;
+    a.threshold = threshold;
+    a.pcap = nb_max;
+    int32_t* d_status = nullptr;
+    hipError_t e = hipMalloc(&d_status, (size_t)a.nchunks * 4 * sizeof(int32_t));
+    if (e != hipSuccess) {
+        (void)hipFree(d_preds);
+        return xt_fail(ctx, EXTRACK_E_HIP, std::string("predict_th: ") + hipGetErrorString(e));
+    }
+    a.status = d_status;
+    rc = EXTRACK_OK;
+    hipEventRecord(ctx->ev0, ctx->stream);
+    for (;;) {
+        int capE = ctx->th_capE;
+        while (capE < S * G) capE *= 2;
+        ctx->th_capE = capE;
+        a.capE = a.wsP = a.wsE = capE;
+        a.ws_lds = 0;
+        const int threads = nb_max <= 2 ? 64 : 256;
+        const int grid = (int)std::min<int64_t>(a.nchunks, (int64_t)ctx->n_cu * (threads == 64 ? 16 : 4));
+        a.ws_stride = xt_th_ws_doubles(capE, capE, D, K, F, 1, S, a.pcap, true, b.L);
+        const size_t need = (size_t)a.ws_stride * grid * sizeof(double);
+        if (need > ctx->th_ws_cap) {
+            (void)hipStreamSynchronize(ctx->stream);
+            if (ctx->d_th_ws) (void)hipFree(ctx->d_th_ws);
+            ctx->d_th_ws = nullptr;
+            ctx->th_ws_cap = 0;
+            if ((e = hipMalloc(&ctx->d_th_ws, need)) != hipSuccess) {
+                rc = xt_fail(ctx, EXTRACK_E_HIP, std::string("predict_th workspace: ") + hipGetErrorString(e));
+                break;
+            }
+            ctx->th_ws_cap = need;
+        }
+        a.ws = ctx->d_th_ws;
+        const size_t lds = (size_t)xt_th_plan_lds_doubles(S, G, capE, D, K) * sizeof(double);
+        if (lds > 160 * 1024) {
+            rc = xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "plan tables do not fit the 160 KiB LDS of a CU");
+            break;
+        }
+        if (D == 1 && K == 1) e = xt_th_launch_predict<1, 1>(ctx, a, grid, threads, lds);
+        else if (D == 2 && K == 1) e = xt_th_launch_predict<2, 1>(ctx, a, grid, threads, lds);
+        else if (D == 2 && K == 2) e = xt_th_launch_predict<2, 2>(ctx, a, grid, threads, lds);
+        else if (D == 3 && K == 1) e = xt_th_launch_predict<3, 1>(ctx, a, grid, threads, lds);
+        else e = xt_th_launch_predict<3, 3>(ctx, a, grid, threads, lds);
+        if (e == hipSuccess) {
+            ctx->th_status_host.resize((size_t)a.nchunks * 4);
+            e = hipMemcpyAsync(ctx->th_status_host.data(), d_status, (size_t)a.nchunks * 4 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) {
+            rc = xt_fail(ctx, EXTRACK_E_HIP, std::string("predict_th: ") + hipGetErrorString(e));
+            break;
+        }
+        int over = 0, maxE = 0;
+        for (int c = 0; c < a.nchunks; ++c) {
+            over |= ctx->th_status_host[(size_t)c * 4];
+            maxE = std::max(maxE, std::max(ctx->th_status_host[(size_t)c * 4 + 1], ctx->th_status_host[(size_t)c * 4 + 2]));
+        }
+        if (!over) break;
+        int ncap = capE;
+        while (ncap < maxE) ncap *= 2;
+        if (ncap == capE) ncap *= 2;
+        if (ncap > XT_TH_MAXCAP) {
+            rc = xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "more than 8192 live state sequences per step: raise threshold or lower max_nb_states");
+            break;
+        }
+        ctx->th_capE = ncap;
+    }
+    if (rc == EXTRACK_OK) {
+        hipEventRecord(ctx->ev1, ctx->stream);
+        ctx->timed = true;
+        e = hipMemcpyAsync(preds, d_preds, nbytes, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) rc = xt_fail(ctx, EXTRACK_E_HIP, std::string("predict_th: ") + hipGetErrorString(e));
+    }
+    (void)hipFree(d_status);
+    (void)hipFree(d_preds);
+    return rc;
 }
 
 extern "C" int extrack_th_plan_step(extrack_ctx* ctx, int32_t bucket_id, int64_t chunk_index, int32_t t, int32_t* n_expanded,

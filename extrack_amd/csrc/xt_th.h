@@ -53,6 +53,8 @@ struct XtThArgs {
     int32_t* status;       // [nchunks][4]: overflow flag, max nE, max nG, sum over merged steps of nE
     double* ws;            // plan-kernel workspace in global memory, ws_stride doubles per workgroup (ws_lds == 0)
     int64_t ws_stride;
+    int32_t pcap;          // pilot-track capacity of the workspace: min(30, chunk)
+    double* preds_out;     // [N][L][S] state posteriors (prediction kernel)
     int32_t ws_lds;        // 1: the pilot-track state lives in LDS (capacities learned from the previous evaluation)
     int32_t wsP, wsE;      // workspace capacities: parent sequences / expanded sequences per pilot track
     int32_t TT, logTT;     // apply kernel: tracks per workgroup tile (power of two)
@@ -96,10 +98,12 @@ struct XtThView {
 
 XT_HD int xt_th_hm(int F, int NS) { return F + NS; }
 XT_HD int64_t xt_th_buf_doubles(int plane, int D, int K) { return (int64_t)plane * (2 + D + K); }
-XT_HD int64_t xt_th_ws_doubles(int wsP, int wsE, int D, int K, int F, int NS, int S)
+XT_HD int64_t xt_th_ws_doubles(int wsP, int wsE, int D, int K, int F, int NS, int S, int pcap = XT_TH_PILOT, bool preds = false, int L = 0)
 {
-    return 2 * xt_th_buf_doubles(XT_TH_PILOT * wsP, D, K) + (int64_t)K * XT_TH_PILOT * wsE + 2 * (int64_t)wsP * xt_th_hm(F, NS) * S +
-           2 * (int64_t)wsP + 8;
+    const int HM = preds ? L + 1 : xt_th_hm(F, NS);
+    const int NC = preds ? pcap : 1;
+    return 2 * xt_th_buf_doubles(pcap * wsP, D, K) + (int64_t)K * pcap * wsE + 2 * (int64_t)NC * wsP * HM * S + 2 * (int64_t)NC * wsP +
+           (preds ? (int64_t)pcap * wsE + ((int64_t)pcap * wsE + 1) / 2 : 0) + 8;
 }
 XT_HD int xt_th_plan_lds_doubles(int S, int G, int capE, int D, int K)
 {
@@ -271,12 +275,13 @@ XT_HD double xt_th_l2_from_sigma(double s, int mode, const double* hdr)
 // ------------------------------------------------------------------------------------------------------------------
 // PLAN kernel body: one workgroup per chunk.
 // ------------------------------------------------------------------------------------------------------------------
-template <int D, int K, class Ctx>
+template <int D, int K, bool PREDS, class Ctx>
 XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
 {
     const int S = a.S, G = a.G, NS = a.NS, F = a.F, L = a.L, capE = a.capE;
     const int tid = cx.tid(), nt = cx.nthreads();
-    const int HM = xt_th_hm(F, NS);
+    const int HM = PREDS ? L + 1 : xt_th_hm(F, NS);  // history entries kept per sequence
+    const int PC = a.pcap;                          // pilot capacity: min(30, chunk)
     double* smem = cx.smem();
     const int ntab = xt_tab_doubles(S, G);
     for (int i = tid; i < ntab; i += nt) smem[i] = a.blob[i];
@@ -298,20 +303,26 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
     // pilot-track state: LDS when the learned capacities fit (a.ws_lds), else this workgroup's slice of the global workspace
     const int wsP = a.wsP, wsE = a.wsE;
     double* w = a.ws_lds ? smem + xt_th_plan_lds_doubles(S, G, capE, D, K) : a.ws + (int64_t)cx.block() * a.ws_stride;
-    const int plane = XT_TH_PILOT * wsE;  // sE plane
+    const int plane = PC * wsE;  // sE plane
     typedef XtThView<D, K, false> View;
     View A, B;
-    xt_th_carve(w, A, XT_TH_PILOT * wsP, D, K);
-    xt_th_carve(w, B, XT_TH_PILOT * wsP, D, K);
+    xt_th_carve(w, A, PC * wsP, D, K);
+    xt_th_carve(w, B, PC * wsP, D, K);
     double* sE = w;
     w += (int64_t)K * plane;
+    // state history ("cat", tracking.py:515-520): one per chunk in fit mode, one per track when predicting
+    const int64_t cstride = (int64_t)wsP * HM * S;  // per pilot
+    const int NC = PREDS ? PC : 1;
     double* catA = w;
-    w += (int64_t)wsP * HM * S;
+    w += NC * cstride;
     double* catB = w;
-    w += (int64_t)wsP * HM * S;
+    w += NC * cstride;
     unsigned long long* keyA = (unsigned long long*)w;
-    w += wsP;
+    w += (int64_t)NC * wsP;
     unsigned long long* keyB = (unsigned long long*)w;
+    w += (int64_t)NC * wsP;
+    double* wgt = w;  // PREDS: normalised member weights / final sequence weights [PC][wsE]
+    int* wexp = (int*)(wgt + (PREDS ? plane : 0));
     const int Fk = F - NS;  // parent history entries inside the frame_len window of an expanded sequence
     int pwS[8];
     pwS[0] = 1;
@@ -347,7 +358,10 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
             for (int d = 0; d < D; ++d) A.m(d, idx) = a.tracks[((c0 + x) * L + 0) * D + d];
             for (int k = 0; k < K; ++k) A.u(k, idx) = l2[k];
         }
-        for (int i = tid; i < S * S; i += nt) catA[(i / S) * HM * S + (i % S)] = (i / S == i % S) ? 1.0 : 0.0;
+        for (int i = tid; i < (PREDS ? P : 1) * S * S; i += nt) {
+            const int x = i / (S * S), q = i - x * (S * S);
+            catA[x * cstride + (q / S) * HM * S + (q % S)] = (q / S == q % S) ? 1.0 : 0.0;
+        }
         for (int i = tid; i < S; i += nt) newA[i] = (uint8_t)i;
         int nPar = S, Hc = 1, maxE = 0, maxG = S, overflow = 0, nfuse = 0, sumE = 0;
         double thr = a.threshold;
@@ -421,7 +435,10 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
                                 if (j < nE && !grouped[j]) {
                                     gj = j / G;
                                     const int rj = j - gj * G;
-                                    if (j == b || (useA && rj == rb && kyA[gj] == kyA[gb]))
+                                    bool same_hist = useA && rj == rb;
+                                    if (same_hist)  // predicting: on every pilot track (mean > 0.999, tracking.py:686)
+                                        for (int xx = 0; xx < (PREDS ? P : 1); ++xx) same_hist = same_hist && kyA[xx * wsP + gj] == kyA[xx * wsP + gb];
+                                    if (j == b || same_hist)
                                         mode = 1;  // the pivot itself / same last frame_len states
                                     else if (rj % S == rb % S)
                                         mode = 2;
@@ -494,9 +511,48 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
                     const int x = i / nG, g2 = i - x * nG;
                     xt_th_gather<D, K>(bA, 1, x * wsP, mpk, (int)gst[g2], (int)gst[g2 + 1], TTl, TD2, bB, x * wsP + g2);
                 }
-                const int Hn = (t == 1) ? He : (He < F ? He : F);  // fit mode keeps frame_len entries (tracking.py:699-701)
-                const int Pc = nfuse == 0 ? 1 : P;                 // rows of the reference's cat array (tracking.py:726-729)
-                for (int i = tid; i < nG * Hn * S; i += nt) {
+                const int Hn = (t == 1 || PREDS) ? He : (He < F ? He : F);  // fit mode keeps frame_len entries (tracking.py:699-701)
+                const int Pc = nfuse == 0 ? 1 : P;                          // rows of the reference's cat array (tracking.py:726-729)
+                if (PREDS) {
+                    // per-track histories, merged with the tracks' own softmax weights (tracking.py:731-736)
+                    for (int i = tid; i < P * nG; i += nt) {
+                        const int x = i / nG, g2 = i - x * nG;
+                        const int k0 = gst[g2], k1 = gst[g2 + 1];
+                        int E = XT_EMIN;
+                        for (int kk = k0; kk < k1; ++kk) {
+                            const int e = bA.ze(x * wsP + (int)(mpk[kk] >> 16));
+                            E = e > E ? e : E;
+                        }
+                        double W = 0.0;
+                        for (int kk = k0; kk < k1; ++kk) {
+                            const int idx = x * wsP + (int)(mpk[kk] >> 16);
+                            const double av = xt_ldexp(bA.zm(idx) * TTl[mpk[kk] & 0xffffu], bA.ze(idx) - E);
+                            wgt[x * wsE + kk] = av;
+                            W += av;
+                        }
+                        for (int kk = k0; kk < k1; ++kk) wgt[x * wsE + kk] = wgt[x * wsE + kk] / W;
+                    }
+                    cx.sync();
+                    for (int i = tid; i < P * nG * Hn * S; i += nt) {
+                        const int x = i / (nG * Hn * S), q = i - x * (nG * Hn * S);
+                        const int g2 = q / (Hn * S), hs = q - g2 * (Hn * S), h = hs / S, s2 = hs - h * S;
+                        const int k0 = gst[g2], k1 = gst[g2 + 1];
+                        auto val = [&](int jj) -> double {
+                            const int g = jj / G, r = jj - g * G;
+                            if (h < NS) return ((r / pwS[h]) % S == s2) ? 1.0 : 0.0;
+                            return ctA[x * cstride + (g * HM + (h - NS)) * S + s2];
+                        };
+                        double o;
+                        if (k1 - k0 == 1) {
+                            o = val(mem[k0]);
+                        } else {
+                            o = 0.0;
+                            for (int kk = k0; kk < k1; ++kk) o = xt_fma(wgt[x * wsE + kk], val(mem[kk]), o);
+                        }
+                        ctB[x * cstride + (g2 * HM + h) * S + s2] = o;
+                    }
+                }
+                for (int i = tid; i < (PREDS ? 0 : nG * Hn * S); i += nt) {
                     const int g2 = i / (Hn * S), hs = i - g2 * (Hn * S), h = hs / S, s = hs - h * S;
                     const int k0 = gst[g2], k1 = gst[g2 + 1];
                     auto val = [&](int j) -> double {
@@ -521,22 +577,26 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
                 for (int i = tid; i < nG; i += nt) {
                     const uint8_t nw = (uint8_t)((int)mem[gst[i]] % S);
                     nwB[i] = nw;
-                    gnew_g[(int64_t)t * capE + i] = nw;
+                    if (!PREDS) gnew_g[(int64_t)t * capE + i] = nw;
                 }
-                for (int i = tid; i < nE; i += nt) {
-                    mem_g[(int64_t)t * capE + i] = mem[i];
-                    mpk_g[(int64_t)t * capE + i] = mpk[i];
+                if (!PREDS) {
+                    for (int i = tid; i < nE; i += nt) {
+                        mem_g[(int64_t)t * capE + i] = mem[i];
+                        mpk_g[(int64_t)t * capE + i] = mpk[i];
+                    }
+                    for (int i = tid; i <= nG; i += nt) gst_g[(int64_t)t * (capE + 1) + i] = gst[i];
                 }
-                for (int i = tid; i <= nG; i += nt) gst_g[(int64_t)t * (capE + 1) + i] = gst[i];
                 cx.sync();
                 // history keys of the new parents: argmax over states of the first Fk entries
-                for (int i = tid; i < nG; i += nt) {
+                for (int i = tid; i < (PREDS ? P : 1) * nG; i += nt) {
+                    const int x = i / nG, g2 = i - x * nG;
+                    const double* cb = ctB + x * cstride + (int64_t)g2 * HM * S;
                     unsigned long long key = 0;
                     for (int h = 0; h < Fk && h < Hn; ++h) {
                         int best = 0;
-                        double bv = ctB[(i * HM + h) * S];
+                        double bv = cb[h * S];
                         for (int s = 1; s < S; ++s) {
-                            const double v = ctB[(i * HM + h) * S + s];
+                            const double v = cb[h * S + s];
                             if (v > bv) {
                                 bv = v;
                                 best = s;
@@ -544,7 +604,7 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
                         }
                         key |= (unsigned long long)best << (3 * h);
                     }
-                    kyB[i] = key;
+                    kyB[x * wsP + g2] = key;
                 }
                 if (t >= 2) ++nfuse;
                 {
@@ -566,10 +626,73 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
                 maxG = nG > maxG ? nG : maxG;
                 cx.sync();
             }
-            if (tid == 0) {
+            if (tid == 0 && !PREDS) {
                 hdr_g[t * 2] = nE;
                 hdr_g[t * 2 + 1] = nG;
             }
+        }
+        if (PREDS && !overflow) {
+            // ---- posteriors (tracking.py:611-648): weights of the final sequences (parent g, new state r) at the last
+            // position, then the weighted mean of their state histories; history index 0 = last position
+            cx.sync();
+            const int tl = L - 1, nE = nPar * G, Hf = Hc + NS;
+            const bool stay = tl >= 2 && tl >= a.min_len;
+            const double* TF = TAB + ((a.isBL ? 2 : 0) + (stay ? 1 : 0)) * S * G;
+            for (int i = tid; i < P * nE; i += nt) {
+                const int x = i / nE, jj = i - x * nE, g = jj / G, r = jj - g * G, idx = x * wsP + g, o = (int)nwA[g] * G + r;
+                double cl[D], l2l[K], dq[D], dsq = 0.0;
+                load_l2(x, tl, l2l);
+                for (int d = 0; d < D; ++d) {
+                    cl[d] = a.tracks[((c0 + x) * L + tl) * D + d];
+                    dq[d] = cl[d] - bA.m(d, idx);
+                    dsq = xt_fma(dq[d], dq[d], dsq);
+                }
+                double quad, gf;
+                if (K == 1) {
+                    const double rr = xt_rcp(TD2[o] + bA.u(0, idx) + l2l[0]);
+                    quad = 0.5 * dsq * rr;
+                    gf = xt_pow_half<D>(rr);
+                } else {
+                    quad = 0.0;
+                    gf = 1.0;
+                    for (int d = 0; d < D; ++d) {
+                        const double rr = xt_rcp(TD2[o] + bA.u(d, idx) + l2l[d]);
+                        quad = xt_fma(0.5 * dq[d] * dq[d], rr, quad);
+                        gf *= rr;
+                    }
+                    gf = sqrt(gf);
+                }
+                double p;
+                int j6, n2;
+                xt_exp_tab(-quad, p, j6, n2);
+                const double wm = bA.zm(idx) * TF[o] * (gf * T64[j6]) * p;
+                wgt[x * wsE + jj] = wm;
+                wexp[x * wsE + jj] = (wm != 0.0) ? bA.ze(idx) + n2 : XT_EMIN;
+            }
+            cx.sync();
+            for (int x = tid; x < P; x += nt) {  // per track: common exponent, normalisation
+                int E = XT_EMIN;
+                for (int jj = 0; jj < nE; ++jj) E = wexp[x * wsE + jj] > E ? wexp[x * wsE + jj] : E;
+                double tot = 0.0;
+                for (int jj = 0; jj < nE; ++jj) {
+                    const double v = xt_ldexp(wgt[x * wsE + jj], wexp[x * wsE + jj] - E);
+                    wgt[x * wsE + jj] = v;
+                    tot += v;
+                }
+                pm[x] = tot;
+            }
+            cx.sync();
+            for (int i = tid; i < P * Hf * S; i += nt) {
+                const int x = i / (Hf * S), hs = i - x * (Hf * S), h = hs / S, s2 = hs - h * S;
+                double acc = 0.0;
+                for (int jj = 0; jj < nE; ++jj) {
+                    const int g = jj / G, r = jj - g * G;
+                    const double v = h < NS ? (((r / pwS[h]) % S == s2) ? 1.0 : 0.0) : ctA[x * cstride + (g * HM + (h - NS)) * S + s2];
+                    acc = xt_fma(wgt[x * wsE + jj], v, acc);
+                }
+                if (h < L) a.preds_out[((c0 + x) * L + (L - 1 - h)) * S + s2] = acc / pm[x];
+            }
+            cx.sync();
         }
         if (tid == 0) {
             a.status[ch * 4 + 0] = overflow;

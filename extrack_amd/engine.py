@@ -122,6 +122,9 @@ class TrackSet:
     def loglik_th(self, model, threshold=0.2, max_nb_states=120, chunk=2000, per_track=False):
         return self.ctx.loglik_th(model, threshold, max_nb_states, chunk, per_track=per_track)
 
+    def predict_th(self, model, threshold=0.1, max_nb_states=200, nb_max=1):
+        return [self.ctx.predict_th(model, i, threshold, max_nb_states, nb_max) for i in range(len(self.shapes))]
+
     def predict(self, model):
         """Posteriors for every uploaded bucket, in upload order: list of arrays [N_l, l, S]."""
         return [self.ctx.predict(model, i) for i in range(len(self.shapes))]

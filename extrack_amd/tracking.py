@@ -19,8 +19,8 @@ keyword ``fusion``:
                                  BASELINE.json names); ``threshold`` / ``max_nb_states`` are accepted and ignored.
   ``fusion="threshold"``         the THRESHOLD-FUSION kernel ``P_Cs_inter_bound_stats_th`` (tracking.py:427-743) that
                                  ``extrack.tracking.param_fitting`` calls in v1.6.3, chunked by 2000 tracks like
-                                 ``cum_Proba_Cs`` (tracking.py:1043); log-likelihood only (``predict_Bs`` stays on the
-                                 fixed window).
+                                 ``cum_Proba_Cs`` (tracking.py:1043); ``predict_Bs`` then works in chunks of ``nb_max``
+                                 tracks (tracking.py:856-868; nb_max <= 30).
 ``workers`` is accepted and ignored: the tracks are sharded over GPUs instead (extrack_amd.distributed).
 """
 import numpy as np
@@ -346,7 +346,7 @@ def param_fitting(all_tracks, dt, params=None, nb_states=2, nb_substeps=1, frame
 
 
 def predict_Bs(all_tracks, dt, params, cell_dims=[1], nb_states=4, frame_len=5, max_nb_states=200, threshold=0.1, workers=1,
-               input_LocErr=None, verbose=0, nb_max=1, device=0, comm=None):
+               input_LocErr=None, verbose=0, nb_max=1, device=0, comm=None, fusion="window"):
     """Probability of each localisation to be in each state (extrack/tracking.py:792-906).
 
     Returns {str(len): ndarray[n_tracks, len, nb_states]} keyed by every input key (empty arrays for empty
@@ -359,8 +359,10 @@ def predict_Bs(all_tracks, dt, params, cell_dims=[1], nb_states=4, frame_len=5, 
         loc_tracks = {k: np.asarray(v)[slice(*shard_range(len(v), comm.rank, comm.world))] for k, v in all_tracks.items()}
         loc_sig = None if input_LocErr is None else {k: np.asarray(v)[slice(*shard_range(len(v), comm.rank, comm.world))]
                                                      for k, v in input_LocErr.items()}
+        if _check_fusion(fusion) and nb_max != 1:
+            raise NotImplementedError("fusion='threshold' with nb_max > 1 depends on the chunking of the whole bucket: one GPU only")
         local = predict_Bs(loc_tracks, dt, params, cell_dims, nb_states, frame_len, max_nb_states, threshold, workers, loc_sig, verbose,
-                           nb_max, device, None)
+                           nb_max, device, None, fusion)
         return comm.gather_rows(local)
     keys, tracks, sigmas = engine.sort_buckets(all_tracks, input_LocErr)
     if not is_parameters(params):
@@ -378,7 +380,8 @@ def predict_Bs(all_tracks, dt, params, cell_dims=[1], nb_states=4, frame_len=5, 
             model = ts.make_model(None, ds, Fs, TrMat, pBL, cell_dims, 1, frame_len, slope_offset=so)
         else:
             model = ts.make_model(LocErr[0], ds, Fs, TrMat, pBL, cell_dims, 1, frame_len)
-        for arr, pr in zip(tracks, ts.predict(model)):
+        res = ts.predict_th(model, threshold, max_nb_states, nb_max) if _check_fusion(fusion) else ts.predict(model)
+        for arr, pr in zip(tracks, res):
             out[str(arr.shape[1])] = pr
             if verbose:
                 print(".", end="")

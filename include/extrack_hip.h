@@ -19,6 +19,9 @@
  *       the same sum for the THRESHOLD-FUSION kernel that extrack.tracking calls in v1.6.3: Proba_Cs
  *       (extrack/tracking.py:769-787) -> P_Cs_inter_bound_stats_th (:427-650) + fuse_tracks_th (:652-743),
  *       evaluated in chunks as cum_Proba_Cs does (tracking.py:1043-1069, 2000 tracks per chunk).
+ *   extrack_predict_th
+ *       P_Cs_inter_bound_stats_th(..., do_preds=1)[2] for one bucket in chunks of nb_max tracks (predict_Bs,
+ *       extrack/tracking.py:792-906).
  *   extrack_th_plan_step
  *       the merge groups fuse_tracks_th decided for one chunk and step (tracking.py:681-701) - diagnostic.
  *   extrack_p_stay_table
@@ -116,6 +119,13 @@ int extrack_predict(extrack_ctx* ctx, const extrack_model* model, int32_t bucket
  * total_ll / per_track as in extrack_loglik. */
 int extrack_loglik_th(extrack_ctx* ctx, const extrack_model* model, double threshold, int32_t max_nb_states, int32_t chunk,
                       double* total_ll, double* per_track);
+/* Threshold-fusion state posteriors of one bucket (P_Cs_inter_bound_stats_th(..., do_preds=1), extrack/tracking.py:427-650,
+ * driven as predict_Bs drives it, tracking.py:792-906): preds host [n][len][S].  The bucket is cut into chunks of nb_max
+ * consecutive tracks (predict_Bs default: 1, i.e. every track decides its own merges); nb_max <= 30, so that every track of a
+ * chunk is one of the tracks the merge decisions are taken on.  model->nb_substeps must be 1 (tracking.py:839). */
+int extrack_predict_th(extrack_ctx* ctx, const extrack_model* model, int32_t bucket_id, double threshold, int32_t max_nb_states,
+                       int32_t nb_max, double* preds);
+
 /* Diagnostic: merge groups of the last extrack_loglik_th call for chunk `chunk_index` of a bucket at step t
  * (t = 1 .. len-1; merges happen for t < len-1).  n_expanded = sequences before the merge, n_groups = after
  * (0 when the step has no merge).  members[0..n_expanded) are the expanded sequence indices sorted by group,

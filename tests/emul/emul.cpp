@@ -383,18 +383,19 @@ extern "C" int xt_emul_th_run(const double* tracks, const double* sigma, long lo
         a.wsE = atoi(getenv("XT_EMUL_TH_WSE"));
         a.ws_lds = 1;
     }
-    a.ws_stride = xt_th_ws_doubles(a.wsP, a.wsE, D, K, F, NS, S);
+    a.pcap = chunk < XT_TH_PILOT ? chunk : XT_TH_PILOT;
+    a.ws_stride = xt_th_ws_doubles(a.wsP, a.wsE, D, K, F, NS, S, a.pcap);
     std::vector<double> ws((size_t)a.ws_stride * plan_blocks, 0.0);
     a.ws = ws.data();
     const size_t plan_lds = xt_th_plan_lds_doubles(S, G, capE, D, K) + (a.ws_lds ? (size_t)a.ws_stride : 0);
     const int plan_threads = apply_threads;  // same block size for both kernels in the emulation
 #define TH_RUN(BODY, NB, NT, LDS)                                                                             \
     do {                                                                                                      \
-        if (D == 1 && K == 1) th_emul_blocks(NB, NT, LDS, [&](HostCtx& cx) { BODY<1, 1>(a, cx); });           \
-        else if (D == 2 && K == 1) th_emul_blocks(NB, NT, LDS, [&](HostCtx& cx) { BODY<2, 1>(a, cx); });      \
-        else if (D == 2 && K == 2) th_emul_blocks(NB, NT, LDS, [&](HostCtx& cx) { BODY<2, 2>(a, cx); });      \
-        else if (D == 3 && K == 1) th_emul_blocks(NB, NT, LDS, [&](HostCtx& cx) { BODY<3, 1>(a, cx); });      \
-        else if (D == 3 && K == 3) th_emul_blocks(NB, NT, LDS, [&](HostCtx& cx) { BODY<3, 3>(a, cx); });      \
+        if (D == 1 && K == 1) th_emul_blocks(NB, NT, LDS, [&](HostCtx& cx) { BODY<1, 1, false>(a, cx); });           \
+        else if (D == 2 && K == 1) th_emul_blocks(NB, NT, LDS, [&](HostCtx& cx) { BODY<2, 1, false>(a, cx); });      \
+        else if (D == 2 && K == 2) th_emul_blocks(NB, NT, LDS, [&](HostCtx& cx) { BODY<2, 2, false>(a, cx); });      \
+        else if (D == 3 && K == 1) th_emul_blocks(NB, NT, LDS, [&](HostCtx& cx) { BODY<3, 1, false>(a, cx); });      \
+        else if (D == 3 && K == 3) th_emul_blocks(NB, NT, LDS, [&](HostCtx& cx) { BODY<3, 3, false>(a, cx); });      \
         else return -3;                                                                                       \
     } while (0)
     TH_RUN(xt_th_plan_body, plan_blocks, plan_threads, plan_lds);
@@ -440,5 +441,62 @@ extern "C" int xt_emul_th_run(const double* tracks, const double* sigma, long lo
     double s = 0.0;
     for (double p : partials) s += p;
     if (total) *total = s;
+    return 0;
+}
+
+
+// ---- threshold-fusion posteriors: the plan body in prediction mode (every track of a chunk of <= 30 tracks is a pilot).
+extern "C" int xt_emul_th_predict(const double* tracks, const double* sigma, long long N, int L, int D, int KS, int S, int F, int isBL,
+                                  int min_len, int locerr_mode, int locerr_dims, const double* locerr, double slope, double offset, double pBL,
+                                  const double* ds, const double* Fs, const double* TrMat, const double* p_stay, double threshold, int max_nb,
+                                  int chunk, int capE, int threads, int nblocks, double* preds_out, int* status_out)
+{
+    if (chunk > XT_TH_PILOT) return -6;
+    XtModelHost m{S, 1, locerr_dims, {0, 0, 0}, slope, offset, pBL, ds, Fs, TrMat, p_stay};
+    for (int k = 0; k < 3; ++k) m.locerr[k] = locerr ? locerr[k < locerr_dims ? k : 0] : 0.0;
+    std::vector<double> blob;
+    int G = 0;
+    if (!xt_th_build_blob(m, blob, G).empty()) return -1;
+    const int K = locerr_mode == 0 ? locerr_dims : KS;
+    XtThArgs a;
+    memset(&a, 0, sizeof(a));
+    a.tracks = tracks;
+    a.sigma = locerr_mode ? sigma : nullptr;
+    a.blob = blob.data();
+    a.preds_out = preds_out;
+    a.N = N;
+    a.L = L;
+    a.S = S;
+    a.NS = 1;
+    a.G = G;
+    a.F = F;
+    a.isBL = isBL;
+    a.min_len = min_len;
+    a.locerr_mode = locerr_mode;
+    a.KS = KS ? KS : 1;
+    a.chunk = chunk;
+    a.nchunks = (int)((N + chunk - 1) / chunk);
+    a.capE = capE;
+    a.max_nb = max_nb;
+    a.threshold = threshold;
+    a.pcap = chunk;
+    a.wsP = a.wsE = capE;
+    a.ws_lds = 0;
+    std::vector<int32_t> status((size_t)a.nchunks * 4, 0);
+    a.status = status.data();
+    const int blocks = nblocks < a.nchunks ? nblocks : a.nchunks;
+    a.ws_stride = xt_th_ws_doubles(capE, capE, D, K, F, 1, S, a.pcap, true, L);
+    std::vector<double> ws((size_t)a.ws_stride * blocks, 0.0);
+    a.ws = ws.data();
+    const size_t lds = xt_th_plan_lds_doubles(S, G, capE, D, K);
+    if (D == 1 && K == 1) th_emul_blocks(blocks, threads, lds, [&](HostCtx& cx) { xt_th_plan_body<1, 1, true>(a, cx); });
+    else if (D == 2 && K == 1) th_emul_blocks(blocks, threads, lds, [&](HostCtx& cx) { xt_th_plan_body<2, 1, true>(a, cx); });
+    else if (D == 2 && K == 2) th_emul_blocks(blocks, threads, lds, [&](HostCtx& cx) { xt_th_plan_body<2, 2, true>(a, cx); });
+    else if (D == 3 && K == 1) th_emul_blocks(blocks, threads, lds, [&](HostCtx& cx) { xt_th_plan_body<3, 1, true>(a, cx); });
+    else if (D == 3 && K == 3) th_emul_blocks(blocks, threads, lds, [&](HostCtx& cx) { xt_th_plan_body<3, 3, true>(a, cx); });
+    else return -3;
+    if (status_out) memcpy(status_out, status.data(), status.size() * sizeof(int32_t));
+    for (int c = 0; c < a.nchunks; ++c)
+        if (status[(size_t)c * 4]) return -5;
     return 0;
 }

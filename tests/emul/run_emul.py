@@ -115,3 +115,31 @@ def run_th(Cs, LE, ds, Fs, T, pBL, isBL, p_stay, ns, F, min_len, threshold, max_
             steps[t] = [mem[c, t, gst[c, t, g]:gst[c, t, g + 1]].astype(int) for g in range(nG)]
         plan.append(steps)
     return ll, tot.value, plan, hdr, status
+
+
+def run_th_predict(Cs, LE, ds, Fs, T, pBL, isBL, p_stay, F, min_len, threshold, max_nb, chunk=1, capE=256, threads=64, nblocks=2,
+                   slope=None, offset=None):
+    """Threshold-fusion posteriors (plan body in prediction mode) on CPU threads: preds[N, L, S]."""
+    Cs = np.ascontiguousarray(Cs, float)
+    N, L, D = Cs.shape
+    S = len(ds)
+    LE = np.ascontiguousarray(LE, float)
+    if LE.shape[1] == 1 and L != 1:
+        mode, K, KS = 0, LE.shape[2], 0
+        locerr = np.zeros(3)
+        locerr[:K] = LE[0, 0]
+        sigma = None
+    else:
+        mode, KS = (2 if slope is not None else 1), LE.shape[2]
+        K, locerr, sigma = KS, np.zeros(3), LE
+    nch = (N + chunk - 1) // chunk
+    pr = np.full((N, L, S), np.nan)
+    status = np.zeros((nch, 4), np.int32)
+    ds, Fs, T, p_stay = [np.ascontiguousarray(x, float) for x in (ds, Fs, T, p_stay)]
+    rc = lib().xt_emul_th_predict(dp(Cs), dp(sigma), C.c_longlong(N), L, D, KS, S, F, int(isBL), int(min_len), mode, K, dp(locerr),
+                                  C.c_double(slope or 0.0), C.c_double(offset or 0.0), C.c_double(pBL), dp(ds), dp(Fs), dp(T), dp(p_stay),
+                                  C.c_double(threshold), int(max_nb), int(chunk), int(capE), int(threads), int(nblocks), dp(pr),
+                                  status.ctypes.data_as(C.c_void_p))
+    if rc != 0:
+        raise RuntimeError("emul th predict rc=%d status=%s" % (rc, status.tolist()))
+    return pr
