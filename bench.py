@@ -77,6 +77,32 @@ def cpu_baseline(sample_tracks_per_core=8000):
             "tracks_per_s": tps}
 
 
+def cpu_th_worker(args):
+    from oracle import oracle_th as OT
+    Cs, model = args
+    t0 = time.perf_counter()
+    OT.proba_cs_th(Cs, *model)
+    return time.perf_counter() - t0
+
+
+def cpu_baseline_th(cores, sample_tracks_per_core=16000):
+    """numpy port of the threshold-fusion kernel (oracle/oracle_th.py, pinned to reference fixtures), 2000-track chunks."""
+    import multiprocessing as mp
+    from extrack_amd import synth
+    n = sample_tracks_per_core * cores
+    Cs = synth.brownian_tracks(n, LEN, DS_COEF, TRMAT, FS, LOCERR, DT, DIMS, seed=77)
+    ds = np.sqrt(2 * np.array(DS_COEF) * DT)
+    T = 1 - np.exp(-np.array(TRMAT)); T[np.arange(S), np.arange(S)] = 0; T[np.arange(S), np.arange(S)] = 1 - T.sum(1)
+    model = (np.array([[[LOCERR]]]), ds, np.array(FS), T, PBL, 0, CELL, NS, FRAME, LEN, 0.2, 120)
+    chunks = [(Cs[a:a + 2000], model) for a in range(0, n, 2000)]
+    t0 = time.perf_counter()
+    with mp.get_context("fork").Pool(cores) as pool:
+        pool.map(cpu_th_worker, chunks)
+    wall = time.perf_counter() - t0
+    return {"value": n / wall / N_TRACKS, "unit": "1e6-track LL evals/s", "cores": cores, "kind": "port",
+            "sample": "%d tracks in 2000-track chunks, numpy oracle_th; %.0f tracks/s" % (n, n / wall)}
+
+
 def cpu_baseline_compiled(cores, n=400000):
     """Secondary CPU number: the plain-C restatement (oracle/extrack_oracle.c, gcc -O2 -fopenmp, log domain like the reference)
     on the same socket.  Reported next to the numpy baseline so that the GPU/CPU ratio can also be read against compiled code."""
@@ -158,6 +184,24 @@ def main():
         dt_all = comm.allreduce_scalar(dt_loc, "max")
     else:
         dt_all = dt_loc
+    # secondary measurement (outside the timed region, one GPU only): the threshold-fusion kernel that the reference's
+    # current param_fitting calls (tracking.py:427-743), same data, v1.6.3 defaults (threshold 0.2, max_nb_states 120,
+    # 2000-track chunks): plan kernel + apply kernel per evaluation
+    th = None
+    if world == 1 and a.tracks == N_TRACKS:
+        for _ in range(2):
+            th_val = ts.loglik_th(model, 0.2, 120, 2000)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        th_ms = []
+        for _ in range(max(3, a.steps // 2)):
+            th_val = ts.loglik_th(model, 0.2, 120, 2000)
+            th_ms.append(ts.ctx.last_kernel_ms())
+        th_dt = (time.perf_counter() - t1) / max(3, a.steps // 2)
+        th = {"what": "P_Cs_inter_bound_stats_th path (threshold 0.2, max_nb_states 120, chunk 2000): plan + apply kernels",
+              "value": 1.0 / th_dt, "unit": "1e6-track LL evals/s", "ms_per_eval": th_dt * 1e3, "kernels_ms": float(np.mean(th_ms)),
+              "hbm_gbs": a.tracks * LEN * DIMS * 8 / (float(np.mean(th_ms)) * 1e-3) / 1e9, "neg_loglik": -th_val,
+              "launch": ts.ctx.last_launch_info()}
     if comm is not None:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
@@ -195,6 +239,8 @@ def main():
                                    "valu_issue_floor_ms": valu_issue_cycles / (256 * 4) / 2.4e9 * 1e3}},
         "neg_loglik": -val,
     }
+    if th is not None:
+        out["threshold_fusion"] = th
     if not a.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline()
         out["speedup_vs_cpu_baseline"] = evals_per_s / out["cpu_baseline"]["value"]
@@ -202,6 +248,8 @@ def main():
             out["cpu_baseline_compiled"] = cpu_baseline_compiled(out["cpu_baseline"]["cores"])
         except Exception as e:  # gcc missing on the box: the numpy baseline stands alone
             out["cpu_baseline_compiled"] = {"error": str(e)}
+        if th is not None:
+            th["cpu_baseline"] = cpu_baseline_th(out["cpu_baseline"]["cores"])
     try:  # RCCL's version banner (NCCL_DEBUG=VERSION) sits in the C stdio buffer: flush it so the JSON line comes last
         import ctypes
         ctypes.CDLL(None).fflush(None)

@@ -75,3 +75,20 @@ def test_th_apply_variants_chunked(variant, monkeypatch):
     assert status[:, 0].max() == 0
     assert np.abs(ll - ref).max() < 1e-10
     assert abs(tot - ref.sum()) < 1e-9
+
+
+def test_th_posteriors_body_on_golden_subset():
+    """Prediction mode of the plan body (per-track state histories, weighted merges, posterior read-out)."""
+    E = _emul()
+    meta = json.load(open(os.path.join(GOLDEN, "th_kernel_cases.json")))
+    data = np.load(os.path.join(GOLDEN, "th_kernel_cases.npz"))
+    rows = [r for r in meta if r["do_preds"] and r["N"] <= 30][::9]
+    worst = 0.0
+    for row in rows:
+        pre = "t%04d_" % row["id"]
+        Cs, LE, ds, Fs, T = [data[pre + k] for k in ("Cs", "LE", "ds", "Fs", "T")]
+        ps = p_stay_table(ds, len(ds), 1, row["cell_dims"])
+        pr = E.run_th_predict(Cs, LE, ds, Fs, T, row["pBL"], row["isBL"], ps, row["F"], row["min_len"], row["threshold"], row["max_nb_states"],
+                              chunk=len(Cs), capE=256, threads=64, nblocks=2)
+        worst = max(worst, np.abs(pr - data[pre + "preds"]).max())
+    assert len(rows) >= 8 and worst < 1e-9, (len(rows), worst)
