@@ -187,6 +187,7 @@ def main():
     # secondary measurement (outside the timed region, one GPU only): the threshold-fusion kernel that the reference's
     # current param_fitting calls (tracking.py:427-743), same data, v1.6.3 defaults (threshold 0.2, max_nb_states 120,
     # 2000-track chunks): plan kernel + apply kernel per evaluation
+    launch_info = ts.ctx.last_launch_info()
     th = None
     if world == 1 and a.tracks == N_TRACKS:
         for _ in range(2):
@@ -230,7 +231,7 @@ def main():
         "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "BASELINE configs[1]: %d tracks/GPU, 2 states, len=30, 2-D, nb_substeps=1, frame_len=6, "
                                "single log-likelihood eval per step" % a.tracks,
-                   "tracks_per_gpu": a.tracks, "parallelism": "dp%d" % world, "launch": ts.ctx.last_launch_info()},
+                   "tracks_per_gpu": a.tracks, "parallelism": "dp%d" % world, "launch": launch_info},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes,
                      "note": "the recursion is FP64-VALU bound, not HBM bound (arithmetic intensity ~300 flop/B, DESIGN.md)",

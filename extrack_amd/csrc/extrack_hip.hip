@@ -57,6 +57,10 @@ struct DevCtx {
     {
         __hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
+    __device__ __forceinline__ void atomic_or_u32(uint32_t* p, uint32_t v)
+    {
+        __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
     __device__ __forceinline__ void atomic_add_f64(double* p, double v)
     {
         __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -87,7 +91,7 @@ __global__ void __launch_bounds__(MAXT) xt_entry_kernel(XtKernelArgs a)
 }
 
 template <int D, int K, bool PREDS>
-__global__ void __launch_bounds__(256) xt_th_plan_kernel(XtThArgs a)
+__global__ void __launch_bounds__(1024) xt_th_plan_kernel(XtThArgs a)
 {
     DevCtx cx;
     xt_th_plan_body<D, K, PREDS>(a, cx);
@@ -166,6 +170,7 @@ struct extrack_ctx {
     std::vector<int32_t> th_status_host;
     float th_plan_ms = 0.f;
     int th_force_single = 0;
+    int th_plan_threads = 512;  // workgroup size of the plan kernel (EXTRACK_TH_PLAN_THREADS)
     int th_force_tt = 0, th_force_threads = 0, th_oversub = 2;  // tuning knobs (EXTRACK_TH_TT / _THREADS / _OVERSUB)
     std::string err;
 };
@@ -230,6 +235,10 @@ extern "C" int extrack_create(int device_id, extrack_ctx** out)
     if (const char* ev = getenv("EXTRACK_TH_THREADS")) {
         int v = atoi(ev);
         if (v >= 64 && v <= 1024 && v % 64 == 0) c->th_force_threads = v;
+    }
+    if (const char* ev = getenv("EXTRACK_TH_PLAN_THREADS")) {
+        int v = atoi(ev);
+        if (v >= 64 && v <= 1024 && v % 64 == 0) c->th_plan_threads = v;
     }
     if (const char* ev = getenv("EXTRACK_TH_SINGLE")) c->th_force_single = atoi(ev) != 0;
     if (const char* ev = getenv("EXTRACK_TH_OVERSUB")) {
@@ -723,7 +732,7 @@ static hipError_t xt_th_launch_plan(extrack_ctx* ctx, const XtThArgs& a, int gri
 {
     hipError_t e = xt_th_set_lds(ctx, xt_th_plan_kernel<D, K, false>, lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((xt_th_plan_kernel<D, K, false>), dim3(grid), dim3(256), lds, ctx->stream, a);
+    hipLaunchKernelGGL((xt_th_plan_kernel<D, K, false>), dim3(grid), dim3(ctx->th_plan_threads), lds, ctx->stream, a);
     return hipGetLastError();
 }
 
@@ -878,6 +887,22 @@ extern "C" int extrack_loglik_th(extrack_ctx* ctx, const extrack_model* m, doubl
                 }
             }
             a.ws_lds = lds_mode ? 1 : 0;
+            a.stP = a.stE = a.cmE = 0;
+            if (!lds_mode && ctx->th_learnE > 0 && !force_global) {
+                // LDS copy of what the grouping reads (pilot means, stds), sized by the previous evaluation's sequence counts
+                const int sp = std::min(capE, ctx->th_learnP), se = std::min(capE, ctx->th_learnE);
+                const size_t st = (size_t)a.pcap * ((size_t)sp * D + (size_t)se * K) * sizeof(double);
+                if (lds + st <= 120 * 1024) {
+                    a.stP = sp;
+                    a.stE = se;
+                    lds += st;
+                }
+                const size_t cm = ((size_t)se * ((se + 31) / 32) + (se + 31) / 32 + 2) * sizeof(uint32_t);
+                if (lds + cm <= 150 * 1024) {
+                    a.cmE = se;
+                    lds += cm;
+                }
+            }
             a.ws_stride = xt_th_ws_doubles(a.wsP, a.wsE, D, K, F, NS, S, a.pcap);
             if (!lds_mode) {
                 const size_t need = (size_t)a.ws_stride * grid * sizeof(double);

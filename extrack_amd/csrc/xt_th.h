@@ -57,6 +57,9 @@ struct XtThArgs {
     double* preds_out;     // [N][L][S] state posteriors (prediction kernel)
     int32_t ws_lds;        // 1: the pilot-track state lives in LDS (capacities learned from the previous evaluation)
     int32_t wsP, wsE;      // workspace capacities: parent sequences / expanded sequences per pilot track
+    int32_t cmE;           // capacity (sequences) of the LDS copy of the compatibility bit matrix (0: workspace only)
+    int32_t stP, stE;      // global workspace only: capacities of the LDS staging copy of the pilots' means / stds that the
+                           // grouping reads (0: none); steps with more sequences read the workspace directly
     int32_t TT, logTT;     // apply kernel: tracks per workgroup tile (power of two)
     int32_t capG;          // apply kernel: parent-sequence capacity of the LDS buffers
     int32_t bpc;           // apply kernel: workgroups per chunk (a workgroup serves tiles of ONE chunk)
@@ -80,6 +83,18 @@ struct XtCPtr<true, T> {
 
 XT_HD int xt_popc64(unsigned long long v) { return __builtin_popcountll(v); }
 
+// a / b < thr with the outcome of the correctly rounded IEEE division (what numpy computes, tracking.py:691-694): the
+// hardware reciprocal (rel. error < 1e-7) decides everything that is not within 1e-5 of the threshold, the division proper
+// is only executed for the rare borderline value.  NaN / zero denominators fall through to the exact expression.
+XT_HD bool xt_div_lt(double a, double b, double thr)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const double q = a * __builtin_amdgcn_rcp(b);
+    if (fabs(q - thr) > 1e-5 * thr) return q < thr;
+#endif
+    return a / b < thr;
+}
+
 // View of a parent-sequence state buffer {zm, m[D], u[K], ze} per entry.  u = variance: after a merge s2 incl. the diffusion
 // term, after an integration l2*s2/(l2+s2).
 //   AOS = false (plan kernel, global or LDS workspace): field planes of `plane` entries.
@@ -98,12 +113,13 @@ struct XtThView {
 
 XT_HD int xt_th_hm(int F, int NS) { return F + NS; }
 XT_HD int64_t xt_th_buf_doubles(int plane, int D, int K) { return (int64_t)plane * (2 + D + K); }
+XT_HD int64_t xt_th_cmat_doubles(int wsE) { return ((int64_t)wsE * ((wsE + 31) / 32) + 1) / 2 + 1; }
 XT_HD int64_t xt_th_ws_doubles(int wsP, int wsE, int D, int K, int F, int NS, int S, int pcap = XT_TH_PILOT, bool preds = false, int L = 0)
 {
     const int HM = preds ? L + 1 : xt_th_hm(F, NS);
     const int NC = preds ? pcap : 1;
     return 2 * xt_th_buf_doubles(pcap * wsP, D, K) + (int64_t)K * pcap * wsE + 2 * (int64_t)NC * wsP * HM * S + 2 * (int64_t)NC * wsP +
-           (preds ? (int64_t)pcap * wsE + ((int64_t)pcap * wsE + 1) / 2 : 0) + 8;
+           xt_th_cmat_doubles(wsE) + (wsE + 63) / 64 + 1 + (preds ? (int64_t)pcap * wsE + ((int64_t)pcap * wsE + 1) / 2 : 0) + 8;
 }
 XT_HD int xt_th_plan_lds_doubles(int S, int G, int capE, int D, int K)
 {
@@ -301,7 +317,11 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
     uint16_t* gst = mem + capE;
 
     // pilot-track state: LDS when the learned capacities fit (a.ws_lds), else this workgroup's slice of the global workspace
-    const int wsP = a.wsP, wsE = a.wsE;
+    // (then the grouping works on an LDS copy of the two arrays it reads over and over: pilots' means and stds)
+    const int wsP = a.wsP, wsE = a.wsE, stP = a.ws_lds ? 0 : a.stP, stE = a.ws_lds ? 0 : a.stE;
+    double* stM = smem + xt_th_plan_lds_doubles(S, G, capE, D, K);  // [PC][stP][D]
+    double* stS = stM + (int64_t)a.pcap * stP * D;                  // [PC][stE][K]
+    uint32_t* cmatL = (uint32_t*)(stS + (int64_t)a.pcap * stE * K);  // [cmE][ceil(cmE / 32)] + grouped flags
     double* w = a.ws_lds ? smem + xt_th_plan_lds_doubles(S, G, capE, D, K) : a.ws + (int64_t)cx.block() * a.ws_stride;
     const int plane = PC * wsE;  // sE plane
     typedef XtThView<D, K, false> View;
@@ -321,6 +341,10 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
     w += (int64_t)NC * wsP;
     unsigned long long* keyB = (unsigned long long*)w;
     w += (int64_t)NC * wsP;
+    uint32_t* cmatG = (uint32_t*)w;  // [wsE][ceil(wsE / 32)] pivot -> candidate compatibility bits
+    w += xt_th_cmat_doubles(wsE);
+    uint32_t* gbitsG = (uint32_t*)w;  // [ceil(wsE / 32)] grouped flags of the greedy scan
+    w += (wsE + 63) / 64 + 1;
     double* wgt = w;  // PREDS: normalised member weights / final sequence weights [PC][wsE]
     int* wexp = (int*)(wgt + (PREDS ? plane : 0));
     const int Fk = F - NS;  // parent history entries inside the frame_len window of an expanded sequence
@@ -400,96 +424,107 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
                     for (int i = tid; i <= nE; i += nt) gst[i] = (uint16_t)i;
                     nG = nE;
                 } else {
-                    // ---- greedy grouping on the pilot tracks (tracking.py:652-701)
+                    // ---- greedy grouping on the pilot tracks (tracking.py:652-701), in two phases:
+                    // (1) all (pivot b, candidate j > b with the same newest state) pairs in parallel -> bit matrix
+                    //     "j may join the group opened by b"; candidates of b are b + S, b + 2S, ...  A wavefront evaluates
+                    //     two pairs at a time, 32 pilot slots each; the per-pair counts of the reference's
+                    //     np.mean(...) > 0.8 tests come from wave ballots.
+                    // (2) the greedy scan itself (lowest ungrouped index opens a group and takes every compatible,
+                    //     still ungrouped candidate) is then pure bit arithmetic, done serially by one thread.
                     const bool useA = He > F;
+                    const int NWD = (nE + 31) >> 5;
+                    // the matrix lives in LDS when it fits the reserved capacity (the serial scan is latency bound)
+                    const bool cml = !a.ws_lds && nE <= a.cmE;
+                    uint32_t* cmat = cml ? cmatL : cmatG;
+                    uint32_t* gbits = cml ? cmatL + (int64_t)a.cmE * ((a.cmE + 31) >> 5) : gbitsG;
                     for (int i = tid; i < P * nE; i += nt) {
-                        const int x = i / nE, j = i - x * nE, g = j / G, r = j - g * G;
+                        const int x = i / nE, jj = i - x * nE, g = jj / G, r = jj - g * G;
                         for (int k = 0; k < K; ++k)
-                            sE[k * plane + x * wsE + j] = sqrt(bA.u(k, x * wsP + g) + TD2[(int)nwA[g] * G + r]);
+                            sE[k * plane + x * wsE + jj] = sqrt(bA.u(k, x * wsP + g) + TD2[(int)nwA[g] * G + r]);
                     }
-                    for (int i = tid; i < nE; i += nt) grouped[i] = 0;
-                    cx.sync();
-                    int mpos = 0;
-                    const double cntn = (double)(P * K);
-                    for (int b = 0; b < nE; ++b) {
-                        if (grouped[b]) continue;
-                        const int gb = b / G, rb = b - gb * G;
-                        for (int i = tid; i < P * (D + K); i += nt) {
-                            const int x = i / (D + K), f = i - x * (D + K);
-                            if (f < D)
-                                pm[x * D + f] = bA.m(f, x * wsP + gb);
-                            else
-                                ps[x * K + (f - D)] = sE[(f - D) * plane + x * wsE + b];
+                    for (int i = tid; i < nE * NWD; i += nt) cmat[i] = 0u;
+                    const bool staged = stP > 0 && nPar <= stP && nE <= stE;
+                    if (staged)
+                        for (int i = tid; i < P * nPar * D; i += nt) {
+                            const int x = i / (nPar * D), q = i - x * (nPar * D), g = q / D, d = q - g * D;
+                            stM[(x * stP + g) * D + d] = bA.m(d, x * wsP + g);
                         }
-                        if (tid == 0) gst[nG] = (uint16_t)mpos;
+                    cx.sync();
+                    if (staged) {
+                        for (int i = tid; i < P * nE * K; i += nt) {
+                            const int x = i / (nE * K), q = i - x * (nE * K), jj = q / K, k = q - jj * K;
+                            stS[(x * stE + jj) * K + k] = sE[k * plane + x * wsE + jj];
+                        }
                         cx.sync();
-                        // candidates x pilots in parallel: a wavefront evaluates two candidates at a time, 32 pilot slots each;
-                        // the per-candidate counts of the reference's np.mean(...) > 0.8 tests come from wave ballots
-                        {
-                            const int lane = cx.lane(), half = lane >> 5, x = lane & 31;
-                            const unsigned long long hmask = half ? 0xffffffff00000000ull : 0x00000000ffffffffull;
-                            for (int jb = b + 2 * cx.wave_in_block(); jb < nE; jb += 2 * cx.waves_per_block()) {
-                                const int j = jb + half;
-                                int mode = 0;  // 0: not selected, 1: selected without test, 2: mean / std test on the pilots
-                                int gj = 0;
-                                if (j < nE && !grouped[j]) {
-                                    gj = j / G;
-                                    const int rj = j - gj * G;
-                                    bool same_hist = useA && rj == rb;
-                                    if (same_hist)  // predicting: on every pilot track (mean > 0.999, tracking.py:686)
-                                        for (int xx = 0; xx < (PREDS ? P : 1); ++xx) same_hist = same_hist && kyA[xx * wsP + gj] == kyA[xx * wsP + gb];
-                                    if (j == b || same_hist)
-                                        mode = 1;  // the pivot itself / same last frame_len states
-                                    else if (rj % S == rb % S)
-                                        mode = 2;
-                                }
-                                int cm = 0, cs = 0;
+                    }
+                    auto Mv = [&](int d, int x, int g) -> double { return staged ? stM[(x * stP + g) * D + d] : bA.m(d, x * wsP + g); };
+                    auto Sv = [&](int k, int x, int jj) -> double { return staged ? stS[(x * stE + jj) * K + k] : sE[k * plane + x * wsE + jj]; };
+                    {
+                        const int lane = cx.lane(), half = lane >> 5, x = lane & 31;
+                        const unsigned long long hmask = half ? 0xffffffff00000000ull : 0x00000000ffffffffull;
+                        const double cntn = (double)(P * K);
+                        const bool xl = x < P;
+                        for (int b = cx.wave_in_block(); b < nE; b += cx.waves_per_block()) {
+                            const int gb = b / G, rb = b - gb * G;
+                            double pmv[D], psv[K];
+                            for (int d = 0; d < D; ++d) pmv[d] = xl ? Mv(d, x, gb) : 0.0;
+                            for (int k = 0; k < K; ++k) psv[k] = xl ? Sv(k, x, b) : 1.0;
+                            for (int j0 = b + S; j0 < nE; j0 += 2 * S) {
+                                const int jj = j0 + half * S;
+                                const bool valid = jj < nE;
+                                const int gj = valid ? jj / G : 0;
+                                const int rj = jj - gj * G;
+                                bool same_hist = valid && useA && rj == rb;
+                                if (same_hist)  // predicting: on every pilot track (mean > 0.999, tracking.py:686)
+                                    for (int xx = 0; xx < (PREDS ? P : 1); ++xx) same_hist = same_hist && kyA[xx * wsP + gj] == kyA[xx * wsP + gb];
+                                const bool live = valid && xl && !same_hist;
                                 double dmn = 0.0, dsd = 0.0, sj[K];
-                                const bool live = mode == 2 && x < P;
+                                for (int k = 0; k < K; ++k) sj[k] = 1.0;
                                 if (live) {
-                                    for (int d = 0; d < D; ++d) dmn += fabs(bA.m(d, x * wsP + gj) - pm[x * D + d]);
+                                    for (int d = 0; d < D; ++d) dmn += fabs(Mv(d, x, gj) - pmv[d]);
                                     dmn = dmn / (double)D;
                                     for (int k = 0; k < K; ++k) {
-                                        sj[k] = sE[k * plane + x * wsE + j];
-                                        dsd += fabs(sj[k] - ps[x * K + k]);
+                                        sj[k] = Sv(k, x, jj);
+                                        dsd += fabs(sj[k] - psv[k]);
                                     }
                                     dsd = dsd / (double)K;
                                 }
+                                int cm = 0, cs = 0;
                                 for (int k = 0; k < K; ++k) {
-                                    const unsigned long long bm = cx.ballot(live && (dmn / sj[k] < thr));
-                                    const unsigned long long bs = cx.ballot(live && (dsd / sj[k] < thr));
+                                    const unsigned long long bm = cx.ballot(live && xt_div_lt(dmn, sj[k], thr));
+                                    const unsigned long long bs = cx.ballot(live && xt_div_lt(dsd, sj[k], thr));
                                     cm += xt_popc64(bm & hmask);
                                     cs += xt_popc64(bs & hmask);
                                 }
-                                const bool flag = mode == 1 || (mode == 2 && ((double)cm / cntn > 0.8) && ((double)cs / cntn > 0.8));
-                                if (x == 0 && j < nE) sel[j] = flag ? 1 : 0;
+                                const bool flag = valid && (same_hist || (((double)cm / cntn > 0.8) && ((double)cs / cntn > 0.8)));
+                                if (x == 0 && flag) cx.atomic_or_u32(&cmat[b * NWD + (jj >> 5)], 1u << (jj & 31));
                             }
                         }
-                        cx.sync();
-                        for (int base = b; base < nE; base += nt) {
-                            const int j = base + tid;
-                            const bool flag = j < nE && sel[j] != 0;
-                            // ordered compaction of the selected candidates (ascending j, as np.where gives them)
-                            int wtot;
-                            const int rank = cx.wave_rank(flag, wtot);
-                            if (cx.lane() == 0) wcnt[cx.wave_in_block()] = wtot;
-                            cx.sync();
-                            int off = 0, tot = 0;
-                            for (int wv = 0; wv < cx.waves_per_block(); ++wv) {
-                                const int cnt = wcnt[wv];
-                                off += wv < cx.wave_in_block() ? cnt : 0;
-                                tot += cnt;
-                            }
-                            if (flag) {
-                                mem[mpos + off + rank] = (uint16_t)j;
-                                grouped[j] = 1;
-                            }
-                            mpos += tot;
-                            cx.sync();
-                        }
-                        ++nG;
                     }
-                    if (tid == 0) gst[nG] = (uint16_t)mpos;
+                    cx.sync();
+                    if (tid == 0) {
+                        int mpos = 0, ng = 0;
+                        for (int wd = 0; wd < NWD; ++wd) gbits[wd] = 0u;
+                        for (int b = 0; b < nE; ++b) {
+                            if ((gbits[b >> 5] >> (b & 31)) & 1u) continue;
+                            gst[ng++] = (uint16_t)mpos;
+                            mem[mpos++] = (uint16_t)b;  // the pivot itself
+                            gbits[b >> 5] |= 1u << (b & 31);
+                            for (int wd = b >> 5; wd < NWD; ++wd) {
+                                uint32_t bits = cmat[b * NWD + wd] & ~gbits[wd];
+                                gbits[wd] |= bits;
+                                while (bits) {
+                                    const int bit = __builtin_ctz(bits);
+                                    bits &= bits - 1;
+                                    mem[mpos++] = (uint16_t)((wd << 5) + bit);
+                                }
+                            }
+                        }
+                        gst[ng] = (uint16_t)mpos;
+                        wcnt[0] = ng;
+                    }
+                    cx.sync();
+                    nG = wcnt[0];
                 }
                 cx.sync();
                 if (nG > wsP) {

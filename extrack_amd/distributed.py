@@ -11,8 +11,16 @@ with MIN/MAX all-reduces at shard time, never recomputed from the local shard.
 import numpy as np
 
 
-def shard_range(n, rank, world):
-    """Contiguous rows [start, stop) of a bucket of n tracks owned by `rank` (balanced to +-1)."""
+def shard_range(n, rank, world, chunk=None):
+    """Contiguous rows [start, stop) of a bucket of n tracks owned by `rank` (balanced to +-1).
+
+    With ``chunk`` the unit of distribution is a whole chunk of ``chunk`` consecutive tracks: the threshold-fusion kernel
+    takes its merge decisions per chunk (extrack/tracking.py:678-679, 1043), so a shard boundary inside a chunk would change
+    the result; with chunk-aligned shards every rank evaluates exactly the chunks a single GPU would."""
+    if chunk:
+        nch = -(-int(n) // int(chunk))
+        a, z = shard_range(nch, rank, world)
+        return min(int(n), a * int(chunk)), min(int(n), z * int(chunk))
     base, rem = divmod(int(n), int(world))
     start = rank * base + min(rank, rem)
     return start, start + base + (1 if rank < rem else 0)
@@ -45,24 +53,27 @@ class Comm:
         return int(self.allreduce_scalar(lo, "min")), int(self.allreduce_scalar(hi, "max"))
 
     # ---- sharding -----------------------------------------------------------------------------------------
-    def shard_buckets(self, tracks, sigmas=None):
-        """Row-shards every bucket; buckets whose local share is empty are dropped locally."""
+    def shard_buckets(self, tracks, sigmas=None, chunk=None):
+        """Row-shards every bucket (in whole chunks when ``chunk`` is given); buckets whose local share is empty are dropped
+        locally."""
         t_out, s_out = [], ([] if sigmas is not None else None)
         for i, b in enumerate(tracks):
-            a, z = shard_range(len(b), self.rank, self.world)
+            a, z = shard_range(len(b), self.rank, self.world, chunk)
             if z > a:
                 t_out.append(b[a:z])
                 if sigmas is not None:
                     s_out.append(sigmas[i][a:z])
         return t_out, s_out
 
-    def shard_trackset(self, tracks, sigmas=None, device=0):
+    def shard_trackset(self, tracks, sigmas=None, device=0, chunk=None):
         from .engine import TrackSet
         lo, hi = self.global_min_max_len([b.shape[1] for b in tracks if len(b)])
-        t_loc, s_loc = self.shard_buckets(tracks, sigmas)
+        t_loc, s_loc = self.shard_buckets(tracks, sigmas, chunk)
         if not t_loc:
-            raise ValueError("rank %d received no tracks: fewer tracks than ranks" % self.rank)
-        return TrackSet(t_loc, s_loc, device=device, min_len=lo, max_len=hi)
+            raise ValueError("rank %d received no tracks: fewer tracks%s than ranks" % (self.rank, " (chunks)" if chunk else ""))
+        ts = TrackSet(t_loc, s_loc, device=device, min_len=lo, max_len=hi)
+        ts.shard_chunk = chunk  # chunk alignment of the shard boundaries (None: row-balanced)
+        return ts
 
     # ---- posteriors: no collective in the data path, only an ordered gather of the per-rank row blocks ------------
     def gather_rows(self, local, dst=0):
@@ -73,6 +84,13 @@ class Comm:
         if self.rank != dst:
             return None
         return {k: np.concatenate([p[k] for p in parts], axis=0) for k in local}
+
+    def allreduce_loglik_th(self, ts, model, threshold, max_nb_states, chunk):
+        """Threshold-fusion objective over chunk-aligned shards: local plan + apply kernels, all-reduce(sum) of the scalar."""
+        if getattr(ts, "shard_chunk", None) != chunk:
+            raise ValueError("fusion='threshold' needs shards aligned to the %d-track chunks (Comm.shard_trackset(..., chunk=%d))"
+                             % (chunk, chunk))
+        return self.allreduce_scalar(ts.loglik_th(model, threshold, max_nb_states, chunk), "sum")
 
     # ---- the per-evaluation collective ----------------------------------------------------------------------
     def allreduce_loglik(self, ts, model):

@@ -279,14 +279,15 @@ def cum_Proba_Cs(params, all_tracks, dt, cell_dims, input_LocErr, nb_states, nb_
     ``all_tracks``: list of bucket arrays sorted short->long (as the reference passes it) or a ``TrackSet``.
     ``comm``: optional extrack_amd.distributed.Comm; when given, ``all_tracks`` is this rank's shard and the
     scalar is all-reduced over the ranks.  ``fusion="threshold"``: the v1.6.3 kernel with ``threshold``, ``max_nb_states`` and
-    chunks of ``max_number_of_tracks_per_matrix`` tracks (single GPU: the chunking is part of the result)."""
+    chunks of ``max_number_of_tracks_per_matrix`` tracks (the chunking is part of the result: with ``comm`` the shards must be
+    whole chunks, ``Comm.shard_trackset(..., chunk=...)``)."""
     th = _check_fusion(fusion)
-    if th and comm is not None:
-        raise NotImplementedError("fusion='threshold' depends on the chunking of the whole dataset and is evaluated on one GPU")
     ts = _as_trackset(all_tracks, input_LocErr)
     model = _objective_model(params, ts, dt, cell_dims, input_LocErr, nb_states, nb_substeps, frame_len, Matrix_type)
     if model is not None:
-        if th:
+        if th and comm is not None:  # shards are whole chunks, so the chunking is that of the unsharded dataset
+            Cum_P = comm.allreduce_loglik_th(ts, model, threshold, max_nb_states, max_number_of_tracks_per_matrix)
+        elif th:
             Cum_P = ts.loglik_th(model, threshold, max_nb_states, max_number_of_tracks_per_matrix)
         else:
             Cum_P = ts.loglik(model) if comm is None else comm.allreduce_loglik(ts, model)
@@ -330,7 +331,7 @@ def param_fitting(all_tracks, dt, params=None, nb_states=2, nb_substeps=1, frame
         frame_len = nb_substeps + 1
     print("cell_dims", cell_dims)
     if comm is not None:
-        ts = comm.shard_trackset(tracks, sigmas, device=device)
+        ts = comm.shard_trackset(tracks, sigmas, device=device, chunk=2000 if fusion == "threshold" else None)
     else:
         ts = TrackSet(tracks, sigmas, device=device)
     try:

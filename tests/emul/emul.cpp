@@ -71,6 +71,7 @@ struct HostCtx {
         while (old < v && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {
         }
     }
+    void atomic_or_u32(uint32_t* p, uint32_t v) { __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
     void atomic_add_f64(double* p, double v)
     {
         uint64_t* pi = (uint64_t*)p;
@@ -387,7 +388,13 @@ extern "C" int xt_emul_th_run(const double* tracks, const double* sigma, long lo
     a.ws_stride = xt_th_ws_doubles(a.wsP, a.wsE, D, K, F, NS, S, a.pcap);
     std::vector<double> ws((size_t)a.ws_stride * plan_blocks, 0.0);
     a.ws = ws.data();
-    const size_t plan_lds = xt_th_plan_lds_doubles(S, G, capE, D, K) + (a.ws_lds ? (size_t)a.ws_stride : 0);
+    if (getenv("XT_EMUL_TH_STP") && !a.ws_lds) {  // exercise the LDS staging copy used with the global workspace
+        a.stP = atoi(getenv("XT_EMUL_TH_STP"));
+        a.stE = atoi(getenv("XT_EMUL_TH_STE"));
+        a.cmE = a.stE;
+    }
+    const size_t plan_lds = xt_th_plan_lds_doubles(S, G, capE, D, K) +
+                            (a.ws_lds ? (size_t)a.ws_stride : (size_t)a.pcap * (a.stP * D + a.stE * K) + (size_t)a.cmE * ((a.cmE + 31) / 32 + 1) / 2 + 8);
     const int plan_threads = apply_threads;  // same block size for both kernels in the emulation
 #define TH_RUN(BODY, NB, NT, LDS)                                                                             \
     do {                                                                                                      \

@@ -40,6 +40,12 @@ try:
         fit_c = T.param_fitting(tr, 0.02, params=p0, nb_states=2, frame_len=4, verbose=0, method="bfgs", cell_dims=[1], comm=comm)
         fit_s = T.param_fitting(tr, 0.02, params=p0, nb_states=2, frame_len=4, verbose=0, method="bfgs", cell_dims=[1])
     assert fit_c.nfev == fit_s.nfev and fit_c.residual[0] == fit_s.residual[0], (fit_c.nfev, fit_s.nfev, fit_c.residual, fit_s.residual)
+    # threshold-fusion objective through the communicator: chunk-aligned shards, same value as the single-GPU call
+    ts = comm.shard_trackset(lst, chunk=2000)
+    a_th = T.cum_Proba_Cs(p, ts, 0.02, [1], None, 2, 1, 6, verbose=0, comm=comm, fusion="threshold")
+    b_th = T.cum_Proba_Cs(p, ts, 0.02, [1], None, 2, 1, 6, verbose=0, fusion="threshold")
+    ts.close()
+    assert a_th == b_th and a_th != a, (a_th, b_th, a)
     pa = T.predict_Bs(tr, 0.02, p, cell_dims=[1], nb_states=2, frame_len=5, comm=comm)
     pb = T.predict_Bs(tr, 0.02, p, cell_dims=[1], nb_states=2, frame_len=5)
     assert all(np.array_equal(pa[k], pb[k]) for k in pb)

@@ -53,6 +53,18 @@ def _worker(rank, world, port, q):
             assert all(np.array_equal(full[k], tracks[k]) for k in tracks)
         else:
             assert full is None
+        # threshold-fusion objective: shards are whole chunks, so every chunk keeps the pilot tracks it has on one GPU
+        from oracle import oracle_th as OT
+        chunk = 16
+        th_loc = 0.0
+        t_th, _ = comm.shard_buckets(lst, chunk=chunk)
+        for b in t_th:
+            for a0 in range(0, len(b), chunk):
+                th_loc += OT.proba_cs_th(b[a0:a0 + chunk], LocErr, ds, Fs, T, pBL, 0 if b.shape[1] == hi else 1, [1], 1, 6, lo, 0.2, 120).sum()
+        th_total = comm.allreduce_scalar(th_loc, "sum")
+        th_ref = -OT.cum_proba_cs_th(vals, tracks, 0.02, [1], None, 1, 6, 1, 0.2, 120, chunk=chunk)
+        assert abs(th_total - th_ref) < 1e-12 * abs(th_ref), (th_total, th_ref)
+        assert [shard_range(41, r, world, chunk) for r in range(world)] == [(0, 32), (32, 41)]
         q.put((rank, total, ref, covered, [shard_range(41, r, world) for r in range(world)]))
     finally:
         dist.destroy_process_group()
