@@ -887,7 +887,7 @@ extern "C" int extrack_loglik_th(extrack_ctx* ctx, const extrack_model* m, doubl
                 }
             }
             a.ws_lds = lds_mode ? 1 : 0;
-            a.stP = a.stE = a.cmE = 0;
+            a.stP = a.stE = 0;
             if (!lds_mode && ctx->th_learnE > 0 && !force_global) {
                 // LDS copy of what the grouping reads (pilot means, stds), sized by the previous evaluation's sequence counts
                 const int sp = std::min(capE, ctx->th_learnP), se = std::min(capE, ctx->th_learnE);
@@ -896,11 +896,6 @@ extern "C" int extrack_loglik_th(extrack_ctx* ctx, const extrack_model* m, doubl
                     a.stP = sp;
                     a.stE = se;
                     lds += st;
-                }
-                const size_t cm = ((size_t)se * ((se + 31) / 32) + (se + 31) / 32 + 2) * sizeof(uint32_t);
-                if (lds + cm <= 150 * 1024) {
-                    a.cmE = se;
-                    lds += cm;
                 }
             }
             a.ws_stride = xt_th_ws_doubles(a.wsP, a.wsE, D, K, F, NS, S, a.pcap);
@@ -1106,15 +1101,35 @@ extern "C" int extrack_predict_th(extrack_ctx* ctx, const extrack_model* m, int3
     a.status = d_status;
     rc = EXTRACK_OK;
     hipEventRecord(ctx->ev0, ctx->stream);
+    // Pass 0 (probe): the first chunks with the state in the global workspace -> live-sequence counts of this model.
+    // Pass 1: everything with the state in LDS, capacities = 1.5 x the probe's maxima (when that fits ~40 KiB per workgroup).
+    // Pass 2 (only after an overflow of pass 1, or when LDS does not fit): everything with the global workspace.
+    const int probe_chunks = 512;
+    int pass = a.nchunks <= probe_chunks ? 2 : 0, learnP = 0, learnE = 0;
+    const int32_t all_chunks = a.nchunks;
     for (;;) {
         int capE = ctx->th_capE;
         while (capE < S * G) capE *= 2;
         ctx->th_capE = capE;
         a.capE = a.wsP = a.wsE = capE;
         a.ws_lds = 0;
+        a.nchunks = pass == 0 ? std::min(all_chunks, probe_chunks) : all_chunks;
+        size_t lds = (size_t)xt_th_plan_lds_doubles(S, G, capE, D, K) * sizeof(double);
+        if (pass == 1) {
+            const int wp = std::min(capE, std::max(S * G, learnP)), we = std::min(capE, std::max(S * G, learnE));
+            const size_t need = lds + (size_t)xt_th_ws_doubles(wp, we, D, K, F, 1, S, a.pcap, true) * sizeof(double);
+            if (need <= 40 * 1024) {
+                a.ws_lds = 1;
+                a.wsP = wp;
+                a.wsE = we;
+                lds = need;
+            } else {
+                pass = 2;
+            }
+        }
         const int threads = nb_max <= 2 ? 64 : 256;
         const int grid = (int)std::min<int64_t>(a.nchunks, (int64_t)ctx->n_cu * (threads == 64 ? 16 : 4));
-        a.ws_stride = xt_th_ws_doubles(capE, capE, D, K, F, 1, S, a.pcap, true, b.L);
+        a.ws_stride = xt_th_hist_doubles(a.wsE, a.pcap, true, b.L) + (a.ws_lds ? 0 : xt_th_ws_doubles(a.wsP, a.wsE, D, K, F, 1, S, a.pcap, true));
         const size_t need = (size_t)a.ws_stride * grid * sizeof(double);
         if (need > ctx->th_ws_cap) {
             (void)hipStreamSynchronize(ctx->stream);
@@ -1128,7 +1143,6 @@ extern "C" int extrack_predict_th(extrack_ctx* ctx, const extrack_model* m, int3
             ctx->th_ws_cap = need;
         }
         a.ws = ctx->d_th_ws;
-        const size_t lds = (size_t)xt_th_plan_lds_doubles(S, G, capE, D, K) * sizeof(double);
         if (lds > 160 * 1024) {
             rc = xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "plan tables do not fit the 160 KiB LDS of a CU");
             break;
@@ -1147,21 +1161,36 @@ extern "C" int extrack_predict_th(extrack_ctx* ctx, const extrack_model* m, int3
             rc = xt_fail(ctx, EXTRACK_E_HIP, std::string("predict_th: ") + hipGetErrorString(e));
             break;
         }
-        int over = 0, maxE = 0;
+        int over = 0, maxE = 0, maxG = 0;
         for (int c = 0; c < a.nchunks; ++c) {
             over |= ctx->th_status_host[(size_t)c * 4];
-            maxE = std::max(maxE, std::max(ctx->th_status_host[(size_t)c * 4 + 1], ctx->th_status_host[(size_t)c * 4 + 2]));
+            maxE = std::max(maxE, ctx->th_status_host[(size_t)c * 4 + 1]);
+            maxG = std::max(maxG, ctx->th_status_host[(size_t)c * 4 + 2]);
         }
-        if (!over) break;
-        int ncap = capE;
-        while (ncap < maxE) ncap *= 2;
-        if (ncap == capE) ncap *= 2;
-        if (ncap > XT_TH_MAXCAP) {
-            rc = xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "more than 8192 live state sequences per step: raise threshold or lower max_nb_states");
-            break;
+        if (over && a.ws_lds) {  // the probe's capacities were too small for some track: global workspace for all
+            pass = 2;
+            continue;
         }
-        ctx->th_capE = ncap;
+        if (over) {
+            int ncap = capE;
+            while (ncap < std::max(maxE, maxG)) ncap *= 2;
+            if (ncap == capE) ncap *= 2;
+            if (ncap > XT_TH_MAXCAP) {
+                rc = xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "more than 8192 live state sequences per step: raise threshold or lower max_nb_states");
+                break;
+            }
+            ctx->th_capE = ncap;
+            continue;
+        }
+        if (pass == 0) {
+            learnP = maxG + maxG / 2 + 2;
+            learnE = maxE + maxE / 2 + 2;
+            pass = 1;
+            continue;
+        }
+        break;
     }
+    a.nchunks = all_chunks;
     if (rc == EXTRACK_OK) {
         hipEventRecord(ctx->ev1, ctx->stream);
         ctx->timed = true;

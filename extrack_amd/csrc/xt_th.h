@@ -29,6 +29,7 @@
 #define XT_TH_PILOT 30  // tracking.py:678-679
 #define XT_TH_STAGE 8   // positions staged in LDS per refill (apply kernel)
 #define XT_TH_MAXCAP 8192
+#define XT_TH_CMAT_WORDS 2048  // LDS budget (32-bit words) of the pivot -> candidate compatibility bit matrix
 #define XT_TH_GPW 4      // single-buffer apply kernel: merge groups per wavefront held in registers
 
 struct XtThArgs {
@@ -57,7 +58,6 @@ struct XtThArgs {
     double* preds_out;     // [N][L][S] state posteriors (prediction kernel)
     int32_t ws_lds;        // 1: the pilot-track state lives in LDS (capacities learned from the previous evaluation)
     int32_t wsP, wsE;      // workspace capacities: parent sequences / expanded sequences per pilot track
-    int32_t cmE;           // capacity (sequences) of the LDS copy of the compatibility bit matrix (0: workspace only)
     int32_t stP, stE;      // global workspace only: capacities of the LDS staging copy of the pilots' means / stds that the
                            // grouping reads (0: none); steps with more sequences read the workspace directly
     int32_t TT, logTT;     // apply kernel: tracks per workgroup tile (power of two)
@@ -113,19 +113,30 @@ struct XtThView {
 
 XT_HD int xt_th_hm(int F, int NS) { return F + NS; }
 XT_HD int64_t xt_th_buf_doubles(int plane, int D, int K) { return (int64_t)plane * (2 + D + K); }
-XT_HD int64_t xt_th_cmat_doubles(int wsE) { return ((int64_t)wsE * ((wsE + 31) / 32) + 1) / 2 + 1; }
-XT_HD int64_t xt_th_ws_doubles(int wsP, int wsE, int D, int K, int F, int NS, int S, int pcap = XT_TH_PILOT, bool preds = false, int L = 0)
+XT_HD int64_t xt_th_cmat_doubles(int wsE) { return ((int64_t)wsE * ((wsE / 2 + 32) / 32) + 1) / 2 + 1; }
+// Workspace of one workgroup of the plan kernel.  State part (LDS or global): pilot sequences, stds, histories, keys,
+// bit matrix (+ prediction mode: member / final weights, sequence masses).  History part (prediction mode, always global):
+// what the backward pass reads - members, group starts and counts of every merge step, the members' weights per track.
+XT_HD int64_t xt_th_hist_doubles(int wsE, int pcap, bool preds, int L)
 {
-    const int HM = preds ? L + 1 : xt_th_hm(F, NS);
+    if (!preds) return 0;
+    return ((int64_t)L * wsE + 1) / 2 + ((int64_t)L * (wsE + 1) + 3) / 4 + L + (int64_t)pcap * L * wsE + 4;
+}
+XT_HD int64_t xt_th_ws_doubles(int wsP, int wsE, int D, int K, int F, int NS, int S, int pcap = XT_TH_PILOT, bool preds = false)
+{
+    const int HM = xt_th_hm(F, NS);
     const int NC = preds ? pcap : 1;
-    return 2 * xt_th_buf_doubles(pcap * wsP, D, K) + (int64_t)K * pcap * wsE + 2 * (int64_t)NC * wsP * HM * S + 2 * (int64_t)NC * wsP +
-           xt_th_cmat_doubles(wsE) + (wsE + 63) / 64 + 1 + (preds ? (int64_t)pcap * wsE + ((int64_t)pcap * wsE + 1) / 2 : 0) + 8;
+    int64_t n = 2 * xt_th_buf_doubles(pcap * wsP, D, K) + (int64_t)K * pcap * wsE + 2 * (int64_t)NC * wsP * HM * S + 2 * (int64_t)NC * wsP +
+                xt_th_cmat_doubles(wsE) + (wsE + 63) / 64 + 1 + 8;
+    if (preds) n += (int64_t)pcap * wsE + ((int64_t)pcap * wsE + 1) / 2 + 2 * (int64_t)pcap * wsP + 8;
+    return n;
 }
 XT_HD int xt_th_plan_lds_doubles(int S, int G, int capE, int D, int K)
 {
-    // tables | pivot m, s | wave counts | bytes: mpk u32[capE], newest[2][capE], grouped[capE], mem u16[capE], gst u16[capE + 1]
+    // tables | per-track scalars | wave counts | compatibility bit matrix + grouped flags | bytes: mpk u32[capE], newest[2][capE],
+    // (spare 2 x capE), mem u16[capE], gst u16[capE + 1]
     const int bytes = 4 * capE + 4 * capE + 2 * capE + 2 * (capE + 1);
-    return ((xt_tab_doubles(S, G) + 1) & ~1) + XT_TH_PILOT * (D + K) + 8 + (bytes + 7) / 8 + 2;
+    return ((xt_tab_doubles(S, G) + 1) & ~1) + XT_TH_PILOT * (D + K) + 8 + XT_TH_CMAT_WORDS / 2 + (capE + 63) / 64 + 1 + (bytes + 7) / 8 + 2;
 }
 XT_HD int xt_th_apply_lds_doubles(int S, int G, int capG, int TT, int D, int K, int KS, int L, int plan_cap, bool uni, bool single = false)
 {
@@ -296,7 +307,7 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
 {
     const int S = a.S, G = a.G, NS = a.NS, F = a.F, L = a.L, capE = a.capE;
     const int tid = cx.tid(), nt = cx.nthreads();
-    const int HM = PREDS ? L + 1 : xt_th_hm(F, NS);  // history entries kept per sequence
+    const int HM = xt_th_hm(F, NS);                 // history entries kept per sequence
     const int PC = a.pcap;                          // pilot capacity: min(30, chunk)
     double* smem = cx.smem();
     const int ntab = xt_tab_doubles(S, G);
@@ -308,7 +319,9 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
     double* pm = smem + ((ntab + 1) & ~1);
     double* ps = pm + XT_TH_PILOT * D;
     int* wcnt = (int*)(ps + XT_TH_PILOT * K);
-    uint32_t* mpk = (uint32_t*)(wcnt + 16);
+    uint32_t* cmatL = (uint32_t*)(wcnt + 16);
+    uint32_t* gbitsL = cmatL + XT_TH_CMAT_WORDS;
+    uint32_t* mpk = gbitsL + 2 * ((capE + 63) / 64) + 2;
     uint8_t* newA = (uint8_t*)(mpk + capE);
     uint8_t* newB = newA + capE;
     uint8_t* grouped = newB + capE;
@@ -321,8 +334,8 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
     const int wsP = a.wsP, wsE = a.wsE, stP = a.ws_lds ? 0 : a.stP, stE = a.ws_lds ? 0 : a.stE;
     double* stM = smem + xt_th_plan_lds_doubles(S, G, capE, D, K);  // [PC][stP][D]
     double* stS = stM + (int64_t)a.pcap * stP * D;                  // [PC][stE][K]
-    uint32_t* cmatL = (uint32_t*)(stS + (int64_t)a.pcap * stE * K);  // [cmE][ceil(cmE / 32)] + grouped flags
-    double* w = a.ws_lds ? smem + xt_th_plan_lds_doubles(S, G, capE, D, K) : a.ws + (int64_t)cx.block() * a.ws_stride;
+    double* wh = a.ws + (int64_t)cx.block() * a.ws_stride;  // history part (prediction mode), then the state part unless it is in LDS
+    double* w = a.ws_lds ? smem + xt_th_plan_lds_doubles(S, G, capE, D, K) : wh + xt_th_hist_doubles(wsE, a.pcap, PREDS, L);
     const int plane = PC * wsE;  // sE plane
     typedef XtThView<D, K, false> View;
     View A, B;
@@ -347,6 +360,16 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
     w += (wsE + 63) / 64 + 1;
     double* wgt = w;  // PREDS: normalised member weights / final sequence weights [PC][wsE]
     int* wexp = (int*)(wgt + (PREDS ? plane : 0));
+    // PREDS: what the backward pass needs - per merge step the members (parent << 16 | new state), group starts, counts
+    // (shared by the chunk) and the members' normalised merge weights per track; two vectors of sequence masses per track
+    double* beta = wgt + (PREDS ? plane + (plane + 1) / 2 : 0);  // [PC][2][wsP]
+    uint32_t* hmem = (uint32_t*)wh;          // [L][wsE]
+    wh += PREDS ? ((int64_t)L * wsE + 1) / 2 : 0;
+    uint16_t* hgst = (uint16_t*)wh;          // [L][wsE + 1]
+    wh += PREDS ? ((int64_t)L * (wsE + 1) + 3) / 4 : 0;
+    int* hn = (int*)wh;                      // [L][2]
+    wh += PREDS ? L : 0;
+    double* hw = wh;                         // [PC][L][wsE]
     const int Fk = F - NS;  // parent history entries inside the frame_len window of an expanded sequence
     int pwS[8];
     pwS[0] = 1;
@@ -432,11 +455,12 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
                     // (2) the greedy scan itself (lowest ungrouped index opens a group and takes every compatible,
                     //     still ungrouped candidate) is then pure bit arithmetic, done serially by one thread.
                     const bool useA = He > F;
-                    const int NWD = (nE + 31) >> 5;
-                    // the matrix lives in LDS when it fits the reserved capacity (the serial scan is latency bound)
-                    const bool cml = !a.ws_lds && nE <= a.cmE;
+                    // row b of the matrix: bit c <-> candidate b + S (c + 1); in LDS when it fits the reserved words (the serial
+                    // scan below is latency bound), else in the workspace
+                    const int NWD = (nE / S + 32) >> 5;
+                    const bool cml = nE * NWD <= XT_TH_CMAT_WORDS;
                     uint32_t* cmat = cml ? cmatL : cmatG;
-                    uint32_t* gbits = cml ? cmatL + (int64_t)a.cmE * ((a.cmE + 31) >> 5) : gbitsG;
+                    uint32_t* gbits = cml ? gbitsL : gbitsG;
                     for (int i = tid; i < P * nE; i += nt) {
                         const int x = i / nE, jj = i - x * nE, g = jj / G, r = jj - g * G;
                         for (int k = 0; k < K; ++k)
@@ -459,7 +483,40 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
                     }
                     auto Mv = [&](int d, int x, int g) -> double { return staged ? stM[(x * stP + g) * D + d] : bA.m(d, x * wsP + g); };
                     auto Sv = [&](int k, int x, int jj) -> double { return staged ? stS[(x * stE + jj) * K + k] : sE[k * plane + x * wsE + jj]; };
-                    {
+                    if (P <= 4) {
+                        // few pilot tracks (predict_Bs with nb_max <= 4): one lane per (pivot, candidate) pair, pilots in a loop
+                        const double cntn = (double)(P * K);
+                        for (int b = cx.wave_in_block(); b < nE; b += cx.waves_per_block()) {
+                            const int gb = b / G, rb = b - gb * G;
+                            for (int jj = b + S * (1 + cx.lane()); jj < nE; jj += 64 * S) {
+                                const int gj = jj / G, rj = jj - gj * G;
+                                bool same_hist = useA && rj == rb;
+                                if (same_hist)
+                                    for (int xx = 0; xx < (PREDS ? P : 1); ++xx) same_hist = same_hist && kyA[xx * wsP + gj] == kyA[xx * wsP + gb];
+                                bool flag = same_hist;
+                                if (!same_hist) {
+                                    int cm = 0, cs = 0;
+                                    for (int x = 0; x < P; ++x) {
+                                        double dmn = 0.0, dsd = 0.0, sj[K];
+                                        for (int d = 0; d < D; ++d) dmn += fabs(Mv(d, x, gj) - Mv(d, x, gb));
+                                        dmn = dmn / (double)D;
+                                        for (int k = 0; k < K; ++k) {
+                                            sj[k] = Sv(k, x, jj);
+                                            dsd += fabs(sj[k] - Sv(k, x, b));
+                                        }
+                                        dsd = dsd / (double)K;
+                                        for (int k = 0; k < K; ++k) {
+                                            cm += xt_div_lt(dmn, sj[k], thr) ? 1 : 0;
+                                            cs += xt_div_lt(dsd, sj[k], thr) ? 1 : 0;
+                                        }
+                                    }
+                                    flag = ((double)cm / cntn > 0.8) && ((double)cs / cntn > 0.8);
+                                }
+                                const int ci = (jj - b) / S - 1;
+                                if (flag) cx.atomic_or_u32(&cmat[b * NWD + (ci >> 5)], 1u << (ci & 31));
+                            }
+                        }
+                    } else {
                         const int lane = cx.lane(), half = lane >> 5, x = lane & 31;
                         const unsigned long long hmask = half ? 0xffffffff00000000ull : 0x00000000ffffffffull;
                         const double cntn = (double)(P * K);
@@ -497,26 +554,30 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
                                     cs += xt_popc64(bs & hmask);
                                 }
                                 const bool flag = valid && (same_hist || (((double)cm / cntn > 0.8) && ((double)cs / cntn > 0.8)));
-                                if (x == 0 && flag) cx.atomic_or_u32(&cmat[b * NWD + (jj >> 5)], 1u << (jj & 31));
+                                const int ci = (jj - b) / S - 1;
+                                if (x == 0 && flag) cx.atomic_or_u32(&cmat[b * NWD + (ci >> 5)], 1u << (ci & 31));
                             }
                         }
                     }
                     cx.sync();
                     if (tid == 0) {
                         int mpos = 0, ng = 0;
-                        for (int wd = 0; wd < NWD; ++wd) gbits[wd] = 0u;
+                        for (int wd = 0; wd < ((nE + 31) >> 5); ++wd) gbits[wd] = 0u;
                         for (int b = 0; b < nE; ++b) {
                             if ((gbits[b >> 5] >> (b & 31)) & 1u) continue;
                             gst[ng++] = (uint16_t)mpos;
                             mem[mpos++] = (uint16_t)b;  // the pivot itself
                             gbits[b >> 5] |= 1u << (b & 31);
-                            for (int wd = b >> 5; wd < NWD; ++wd) {
-                                uint32_t bits = cmat[b * NWD + wd] & ~gbits[wd];
-                                gbits[wd] |= bits;
+                            const int nc = (nE - 1 - b) / S;  // candidates b + S, ..., b + nc S
+                            for (int wd = 0; wd < ((nc + 31) >> 5); ++wd) {
+                                uint32_t bits = cmat[b * NWD + wd];
                                 while (bits) {
-                                    const int bit = __builtin_ctz(bits);
+                                    const int jj = b + S * ((wd << 5) + __builtin_ctz(bits) + 1);
                                     bits &= bits - 1;
-                                    mem[mpos++] = (uint16_t)((wd << 5) + bit);
+                                    if (!((gbits[jj >> 5] >> (jj & 31)) & 1u)) {
+                                        gbits[jj >> 5] |= 1u << (jj & 31);
+                                        mem[mpos++] = (uint16_t)jj;
+                                    }
                                 }
                             }
                         }
@@ -546,7 +607,10 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
                     const int x = i / nG, g2 = i - x * nG;
                     xt_th_gather<D, K>(bA, 1, x * wsP, mpk, (int)gst[g2], (int)gst[g2 + 1], TTl, TD2, bB, x * wsP + g2);
                 }
-                const int Hn = (t == 1 || PREDS) ? He : (He < F ? He : F);  // fit mode keeps frame_len entries (tracking.py:699-701)
+                // fit mode keeps frame_len history entries (tracking.py:699-701); when predicting the reference keeps all of
+                // them, but only the first frame_len are ever looked at before the final read-out, which is done here by a
+                // backward pass over the stored merge weights instead of carrying L entries per sequence through every merge
+                const int Hn = (t == 1) ? He : (He < F ? He : F);
                 const int Pc = nfuse == 0 ? 1 : P;                          // rows of the reference's cat array (tracking.py:726-729)
                 if (PREDS) {
                     // per-track histories, merged with the tracks' own softmax weights (tracking.py:731-736)
@@ -565,7 +629,20 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
                             wgt[x * wsE + kk] = av;
                             W += av;
                         }
-                        for (int kk = k0; kk < k1; ++kk) wgt[x * wsE + kk] = wgt[x * wsE + kk] / W;
+                        for (int kk = k0; kk < k1; ++kk) {
+                            const double wn = (k1 - k0 == 1) ? 1.0 : wgt[x * wsE + kk] / W;
+                            wgt[x * wsE + kk] = wn;
+                            hw[((int64_t)x * L + t) * wsE + kk] = wn;
+                        }
+                    }
+                    for (int i = tid; i < nE; i += nt) {
+                        const int jj = mem[i], g = jj / G;
+                        hmem[(int64_t)t * wsE + i] = ((uint32_t)g << 16) | (uint32_t)(jj - g * G);
+                    }
+                    for (int i = tid; i <= nG; i += nt) hgst[(int64_t)t * (wsE + 1) + i] = gst[i];
+                    if (tid == 0) {
+                        hn[t * 2] = nE;
+                        hn[t * 2 + 1] = nG;
                     }
                     cx.sync();
                     for (int i = tid; i < P * nG * Hn * S; i += nt) {
@@ -670,7 +747,7 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
             // ---- posteriors (tracking.py:611-648): weights of the final sequences (parent g, new state r) at the last
             // position, then the weighted mean of their state histories; history index 0 = last position
             cx.sync();
-            const int tl = L - 1, nE = nPar * G, Hf = Hc + NS;
+            const int tl = L - 1, nE = nPar * G;
             const bool stay = tl >= 2 && tl >= a.min_len;
             const double* TF = TAB + ((a.isBL ? 2 : 0) + (stay ? 1 : 0)) * S * G;
             for (int i = tid; i < P * nE; i += nt) {
@@ -717,15 +794,40 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
                 pm[x] = tot;
             }
             cx.sync();
-            for (int i = tid; i < P * Hf * S; i += nt) {
-                const int x = i / (Hf * S), hs = i - x * (Hf * S), h = hs / S, s2 = hs - h * S;
-                double acc = 0.0;
+            // backward pass (one thread per track, fixed summation order): the mass a final sequence carries flows back
+            // through the merge tree; what passes through a member with new state r at merge step t is the posterior mass
+            // of state r at position t
+            for (int x = tid; x < P; x += nt) {
+                double* post = a.preds_out + (c0 + x) * (int64_t)L * S;
+                for (int i = 0; i < L * S; ++i) post[i] = 0.0;
+                double* bc = beta + (int64_t)x * 2 * wsP;
+                double* bp = bc + wsP;
+                const double rt = 1.0 / pm[x];
+                for (int g = 0; g < nPar; ++g) bc[g] = 0.0;
                 for (int jj = 0; jj < nE; ++jj) {
                     const int g = jj / G, r = jj - g * G;
-                    const double v = h < NS ? (((r / pwS[h]) % S == s2) ? 1.0 : 0.0) : ctA[x * cstride + (g * HM + (h - NS)) * S + s2];
-                    acc = xt_fma(wgt[x * wsE + jj], v, acc);
+                    const double om = wgt[x * wsE + jj] * rt;
+                    post[(int64_t)(L - 1) * S + r] += om;
+                    bc[g] += om;
                 }
-                if (h < L) a.preds_out[((c0 + x) * L + (L - 1 - h)) * S + s2] = acc / pm[x];
+                for (int t = L - 2; t >= 1; --t) {
+                    const int nGt = hn[t * 2 + 1], nPt = t > 1 ? hn[(t - 1) * 2 + 1] : S;
+                    for (int g = 0; g < nPt; ++g) bp[g] = 0.0;
+                    for (int g2 = 0; g2 < nGt; ++g2) {
+                        const double bg = bc[g2];
+                        const int k0 = hgst[(int64_t)t * (wsE + 1) + g2], k1 = hgst[(int64_t)t * (wsE + 1) + g2 + 1];
+                        for (int kk = k0; kk < k1; ++kk) {
+                            const uint32_t pk = hmem[(int64_t)t * wsE + kk];
+                            const double cc = bg * hw[((int64_t)x * L + t) * wsE + kk];
+                            post[(int64_t)t * S + (int)(pk & 0xffffu)] += cc;
+                            bp[pk >> 16] += cc;
+                        }
+                    }
+                    double* tb = bc;
+                    bc = bp;
+                    bp = tb;
+                }
+                for (int s2 = 0; s2 < S; ++s2) post[s2] = bc[s2];
             }
             cx.sync();
         }

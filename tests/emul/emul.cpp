@@ -391,10 +391,9 @@ extern "C" int xt_emul_th_run(const double* tracks, const double* sigma, long lo
     if (getenv("XT_EMUL_TH_STP") && !a.ws_lds) {  // exercise the LDS staging copy used with the global workspace
         a.stP = atoi(getenv("XT_EMUL_TH_STP"));
         a.stE = atoi(getenv("XT_EMUL_TH_STE"));
-        a.cmE = a.stE;
     }
     const size_t plan_lds = xt_th_plan_lds_doubles(S, G, capE, D, K) +
-                            (a.ws_lds ? (size_t)a.ws_stride : (size_t)a.pcap * (a.stP * D + a.stE * K) + (size_t)a.cmE * ((a.cmE + 31) / 32 + 1) / 2 + 8);
+                            (a.ws_lds ? (size_t)a.ws_stride : (size_t)a.pcap * (a.stP * D + a.stE * K) + 8);
     const int plan_threads = apply_threads;  // same block size for both kernels in the emulation
 #define TH_RUN(BODY, NB, NT, LDS)                                                                             \
     do {                                                                                                      \
@@ -492,10 +491,16 @@ extern "C" int xt_emul_th_predict(const double* tracks, const double* sigma, lon
     std::vector<int32_t> status((size_t)a.nchunks * 4, 0);
     a.status = status.data();
     const int blocks = nblocks < a.nchunks ? nblocks : a.nchunks;
-    a.ws_stride = xt_th_ws_doubles(capE, capE, D, K, F, 1, S, a.pcap, true, L);
+    if (getenv("XT_EMUL_TH_WSP")) {  // LDS-resident state with explicit capacities
+        a.wsP = atoi(getenv("XT_EMUL_TH_WSP"));
+        a.wsE = atoi(getenv("XT_EMUL_TH_WSE"));
+        a.ws_lds = 1;
+    }
+    const int64_t state = xt_th_ws_doubles(a.wsP, a.wsE, D, K, F, 1, S, a.pcap, true);
+    a.ws_stride = xt_th_hist_doubles(a.wsE, a.pcap, true, L) + (a.ws_lds ? 0 : state);
     std::vector<double> ws((size_t)a.ws_stride * blocks, 0.0);
     a.ws = ws.data();
-    const size_t lds = xt_th_plan_lds_doubles(S, G, capE, D, K);
+    const size_t lds = xt_th_plan_lds_doubles(S, G, capE, D, K) + (a.ws_lds ? (size_t)state : 0);
     if (D == 1 && K == 1) th_emul_blocks(blocks, threads, lds, [&](HostCtx& cx) { xt_th_plan_body<1, 1, true>(a, cx); });
     else if (D == 2 && K == 1) th_emul_blocks(blocks, threads, lds, [&](HostCtx& cx) { xt_th_plan_body<2, 1, true>(a, cx); });
     else if (D == 2 && K == 2) th_emul_blocks(blocks, threads, lds, [&](HostCtx& cx) { xt_th_plan_body<2, 2, true>(a, cx); });
