@@ -168,6 +168,13 @@ struct extrack_ctx {
     int th_capE = 128;          // plan capacity (expanded sequences per step); grows on overflow
     int th_learnP = 0, th_learnE = 0;  // live parent / expanded sequence counts seen by the last plan (+ headroom): LDS workspace sizing
     std::vector<int32_t> th_status_host;
+    int32_t* h_th_status = nullptr;  // pinned: plan status of every chunk of a launch group
+    int32_t* d_th_status = nullptr;
+    size_t th_status_cap = 0;        // ints
+    XtThBucket* d_th_desc = nullptr;  // bucket descriptors of a launch group
+    size_t th_desc_cap = 0;
+    int32_t* d_th_cend = nullptr;     // chunk prefix of a launch group
+    size_t th_cend_cap = 0;
     float th_plan_ms = 0.f;
     int th_force_single = 0;
     int th_plan_threads = 512;  // workgroup size of the plan kernel (EXTRACK_TH_PLAN_THREADS)
@@ -298,6 +305,10 @@ extern "C" void extrack_destroy(extrack_ctx* ctx)
     if (ctx->d_base_tab) (void)hipFree(ctx->d_base_tab);
     if (ctx->d_off_tab) (void)hipFree(ctx->d_off_tab);
     if (ctx->d_th_ws) (void)hipFree(ctx->d_th_ws);
+    if (ctx->h_th_status) (void)hipHostFree(ctx->h_th_status);
+    if (ctx->d_th_status) (void)hipFree(ctx->d_th_status);
+    if (ctx->d_th_desc) (void)hipFree(ctx->d_th_desc);
+    if (ctx->d_th_cend) (void)hipFree(ctx->d_th_cend);
     if (ctx->d_blob) (void)hipFree(ctx->d_blob);
     if (ctx->h_blob) (void)hipHostFree(ctx->h_blob);
     if (ctx->d_partials) (void)hipFree(ctx->d_partials);
@@ -728,30 +739,30 @@ static hipError_t xt_th_set_lds(extrack_ctx* ctx, KernT kern, size_t lds)
 }
 
 template <int D, int K>
-static hipError_t xt_th_launch_plan(extrack_ctx* ctx, const XtThArgs& a, int grid, size_t lds)
+static hipError_t xt_th_launch_plan(extrack_ctx* ctx, const XtThArgs& a, int grid, size_t lds, hipStream_t stream)
 {
     hipError_t e = xt_th_set_lds(ctx, xt_th_plan_kernel<D, K, false>, lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((xt_th_plan_kernel<D, K, false>), dim3(grid), dim3(ctx->th_plan_threads), lds, ctx->stream, a);
+    hipLaunchKernelGGL((xt_th_plan_kernel<D, K, false>), dim3(grid), dim3(ctx->th_plan_threads), lds, stream, a);
     return hipGetLastError();
 }
 
 template <int D, int K, bool UNI, bool SINGLE>
-static hipError_t xt_th_launch_apply_v(extrack_ctx* ctx, const XtThArgs& a, int grid, int threads, size_t lds)
+static hipError_t xt_th_launch_apply_v(extrack_ctx* ctx, const XtThArgs& a, int grid, int threads, size_t lds, hipStream_t stream)
 {
     hipError_t e = xt_th_set_lds(ctx, xt_th_apply_kernel<D, K, UNI, SINGLE>, lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((xt_th_apply_kernel<D, K, UNI, SINGLE>), dim3(grid), dim3(threads), lds, ctx->stream, a);
+    hipLaunchKernelGGL((xt_th_apply_kernel<D, K, UNI, SINGLE>), dim3(grid), dim3(threads), lds, stream, a);
     return hipGetLastError();
 }
 
 // mode 0: general (fewer than 64 tracks per tile), 1: wave-uniform, two state buffers, 2: wave-uniform, one state buffer
 template <int D, int K>
-static hipError_t xt_th_launch_apply(extrack_ctx* ctx, const XtThArgs& a, int grid, int threads, size_t lds, int mode)
+static hipError_t xt_th_launch_apply(extrack_ctx* ctx, const XtThArgs& a, int grid, int threads, size_t lds, int mode, hipStream_t stream)
 {
-    if (mode == 2) return xt_th_launch_apply_v<D, K, true, true>(ctx, a, grid, threads, lds);
-    if (mode == 1) return xt_th_launch_apply_v<D, K, true, false>(ctx, a, grid, threads, lds);
-    return xt_th_launch_apply_v<D, K, false, false>(ctx, a, grid, threads, lds);
+    if (mode == 2) return xt_th_launch_apply_v<D, K, true, true>(ctx, a, grid, threads, lds, stream);
+    if (mode == 1) return xt_th_launch_apply_v<D, K, true, false>(ctx, a, grid, threads, lds, stream);
+    return xt_th_launch_apply_v<D, K, false, false>(ctx, a, grid, threads, lds, stream);
 }
 
 // Grows the partial-sum array to n entries, keeping what earlier launches of this evaluation wrote.
@@ -798,6 +809,250 @@ static int xt_th_reserve_plan(extrack_ctx* ctx, XtBucket& b, int chunk, int capE
     return EXTRACK_OK;
 }
 
+// Device-side copy of a small host array (bucket descriptors, chunk prefix): grows on demand.
+static int xt_th_upload_small(extrack_ctx* ctx, void** d_buf, size_t* cap, const void* src, size_t bytes)
+{
+    if (bytes > *cap) {
+        XT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (*d_buf) (void)hipFree(*d_buf);
+        *d_buf = nullptr;
+        *cap = 0;
+        XT_HIP(ctx, hipMalloc(d_buf, bytes * 2));
+        *cap = bytes * 2;
+    }
+    XT_HIP(ctx, hipMemcpyAsync(*d_buf, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return EXTRACK_OK;
+}
+
+// One launch group of a threshold-fusion evaluation: all buckets that share (dims, sigma dims) are served by ONE plan launch
+// and ONE apply launch through a device table of bucket descriptors (a real dataset has one bucket per track length; the plan
+// kernel of a single small bucket could not fill the GPU and its latency would add up bucket after bucket).
+static int xt_th_run_group(extrack_ctx* ctx, const extrack_model* m, const std::vector<XtBucket*>& bks, double threshold, int32_t max_nb_states,
+                           int32_t chunk, int G, bool per_track, size_t& poff)
+{
+    const int S = m->n_states, NS = m->nb_substeps, F = m->frame_len;
+    const XtBucket& b0 = *bks[0];
+    const int D = b0.D;
+    int K;
+    if (m->locerr_mode == 0) {
+        K = m->locerr_dims;
+    } else {
+        for (XtBucket* b : bks)
+            if (!b->d_sigma) return xt_fail(ctx, EXTRACK_E_INVALID, "per-peak localisation error mode but the bucket has no sigma");
+        K = b0.KS;
+    }
+    if (!(K == 1 || (K == D && D > 1))) return xt_fail(ctx, EXTRACK_E_INVALID, "locerr_dims must be 1 or the track dimensionality");
+    const int nbk = (int)bks.size();
+    XtThArgs a;
+    memset(&a, 0, sizeof(a));
+    a.blob = ctx->d_blob;
+    a.S = S;
+    a.NS = NS;
+    a.G = G;
+    a.F = F;
+    a.min_len = m->min_len;
+    a.locerr_mode = m->locerr_mode;
+    a.KS = b0.KS ? b0.KS : 1;
+    a.chunk = chunk;
+    a.max_nb = max_nb_states;
+    a.threshold = threshold;
+    a.pcap = std::min(chunk, XT_TH_PILOT);
+    a.nbuckets = nbk;
+    std::vector<int32_t> chunk_end(nbk);
+    int64_t total = 0;
+    int Lmax = 0;
+    for (int i = 0; i < nbk; ++i) {
+        total += (bks[i]->N + chunk - 1) / chunk;
+        if (total > (int64_t)1 << 30) return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "too many chunks");
+        chunk_end[i] = (int32_t)total;
+        Lmax = std::max(Lmax, bks[i]->L);
+    }
+    a.nchunks = (int32_t)total;
+    a.Lmax = Lmax;
+    a.L = Lmax;
+    // status of every chunk of the group: one device array, one pinned host copy
+    if ((size_t)total * 4 > ctx->th_status_cap) {
+        XT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->h_th_status) (void)hipHostFree(ctx->h_th_status);
+        if (ctx->d_th_status) (void)hipFree(ctx->d_th_status);
+        ctx->h_th_status = ctx->d_th_status = nullptr;
+        ctx->th_status_cap = 0;
+        XT_HIP(ctx, hipHostMalloc(&ctx->h_th_status, (size_t)total * 8 * sizeof(int32_t), hipHostMallocDefault));
+        XT_HIP(ctx, hipMalloc(&ctx->d_th_status, (size_t)total * 8 * sizeof(int32_t)));
+        ctx->th_status_cap = (size_t)total * 8;
+    }
+    std::vector<XtThBucket> desc(nbk);
+    hipError_t e = hipSuccess;
+    int rc, maxG = 0, sumE = 0;
+    bool force_global = false;
+    for (;;) {  // plan, growing the capacity on overflow
+        int capE = ctx->th_capE;
+        while (capE < S * G) capE *= 2;
+        ctx->th_capE = capE;
+        a.capE = capE;
+        for (int i = 0; i < nbk; ++i) {
+            XtBucket& b = *bks[i];
+            if ((rc = xt_th_reserve_plan(ctx, b, chunk, capE))) return rc;
+            XtThBucket& k = desc[i];
+            k.tracks = b.d_tracks;
+            k.sigma = m->locerr_mode ? b.d_sigma : nullptr;
+            k.ll_out = per_track ? b.d_ll : nullptr;
+            k.preds_out = nullptr;
+            k.N = b.N;
+            k.L = b.L;
+            k.isBL = (b.L != m->max_len) ? 1 : 0;  // tracking.py:1037-1040
+            k.ll_const = -(double)(b.L - 1) * D * 0.5 * XT_LOG2PI;
+            k.members = b.th_members;
+            k.mpack = b.th_mpack;
+            k.gstart = b.th_gstart;
+            k.gnew = b.th_gnew;
+            k.hdr = b.th_hdr;
+            k.status = ctx->d_th_status + (size_t)(i ? chunk_end[i - 1] : 0) * 4;
+        }
+        if ((rc = xt_th_upload_small(ctx, (void**)&ctx->d_th_desc, &ctx->th_desc_cap, desc.data(), desc.size() * sizeof(XtThBucket)))) return rc;
+        if ((rc = xt_th_upload_small(ctx, (void**)&ctx->d_th_cend, &ctx->th_cend_cap, chunk_end.data(), chunk_end.size() * sizeof(int32_t)))) return rc;
+        a.buckets = ctx->d_th_desc;
+        a.chunk_end = ctx->d_th_cend;
+        const int grid = (int)std::min<int64_t>(a.nchunks, (int64_t)ctx->n_cu * 2);
+        // pilot-track state: in LDS when the sequence counts of the previous evaluation (+25 %) fit 64 KiB, else in a global
+        // workspace sized for the full plan capacity
+        size_t lds = (size_t)xt_th_plan_lds_doubles(S, G, capE, D, K) * sizeof(double);
+        bool lds_mode = false;
+        a.wsP = a.wsE = capE;
+        if (ctx->th_learnE > 0 && !force_global) {
+            const int wp = std::min(capE, std::max(S * G, ctx->th_learnP)), we = std::min(capE, std::max(S * G, ctx->th_learnE));
+            const size_t need = lds + (size_t)xt_th_ws_doubles(wp, we, D, K, F, NS, S, a.pcap) * sizeof(double);
+            if (need <= 64 * 1024) {
+                lds_mode = true;
+                lds = need;
+                a.wsP = wp;
+                a.wsE = we;
+            }
+        }
+        a.ws_lds = lds_mode ? 1 : 0;
+        a.stP = a.stE = 0;
+        if (!lds_mode && ctx->th_learnE > 0 && !force_global) {
+            // LDS copy of what the grouping reads (pilot means, stds), sized by the previous evaluation's sequence counts
+            const int sp = std::min(capE, ctx->th_learnP), se = std::min(capE, ctx->th_learnE);
+            const size_t st = (size_t)a.pcap * ((size_t)sp * D + (size_t)se * K) * sizeof(double);
+            if (lds + st <= 120 * 1024) {
+                a.stP = sp;
+                a.stE = se;
+                lds += st;
+            }
+        }
+        a.ws_stride = xt_th_ws_doubles(a.wsP, a.wsE, D, K, F, NS, S, a.pcap);
+        if (!lds_mode) {
+            const size_t need = (size_t)a.ws_stride * grid * sizeof(double);
+            if (need > ctx->th_ws_cap) {
+                XT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                if (ctx->d_th_ws) (void)hipFree(ctx->d_th_ws);
+                ctx->d_th_ws = nullptr;
+                ctx->th_ws_cap = 0;
+                XT_HIP(ctx, hipMalloc(&ctx->d_th_ws, need));
+                ctx->th_ws_cap = need;
+            }
+        }
+        a.ws = ctx->d_th_ws;
+        if (lds > 160 * 1024) return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "plan tables do not fit the 160 KiB LDS of a CU");
+#define XT_TH_PLAN_CALL(...) xt_th_launch_plan<__VA_ARGS__>(ctx, a, grid, lds, ctx->stream)
+        if (D == 1 && K == 1) e = XT_TH_PLAN_CALL(1, 1);
+        else if (D == 2 && K == 1) e = XT_TH_PLAN_CALL(2, 1);
+        else if (D == 2 && K == 2) e = XT_TH_PLAN_CALL(2, 2);
+        else if (D == 3 && K == 1) e = XT_TH_PLAN_CALL(3, 1);
+        else e = XT_TH_PLAN_CALL(3, 3);
+#undef XT_TH_PLAN_CALL
+        if (e != hipSuccess) return xt_fail(ctx, EXTRACK_E_HIP, std::string("plan kernel launch: ") + hipGetErrorString(e));
+        XT_HIP(ctx, hipMemcpyAsync(ctx->h_th_status, ctx->d_th_status, (size_t)a.nchunks * 4 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+        XT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        int over = 0, maxE = 0;
+        maxG = sumE = 0;
+        for (int c = 0; c < a.nchunks; ++c) {
+            over |= ctx->h_th_status[(size_t)c * 4];
+            maxE = std::max(maxE, ctx->h_th_status[(size_t)c * 4 + 1]);
+            maxG = std::max(maxG, ctx->h_th_status[(size_t)c * 4 + 2]);
+            sumE = std::max(sumE, ctx->h_th_status[(size_t)c * 4 + 3]);
+        }
+        if (!over) {
+            ctx->th_learnP = maxG + maxG / 4 + 2;
+            ctx->th_learnE = maxE + maxE / 4 + 2;
+            break;
+        }
+        if (lds_mode) {  // the learned LDS capacities were too small for these parameters: redo with the global workspace
+            force_global = true;
+            continue;
+        }
+        int ncap = capE;
+        while (ncap < std::max(maxE, maxG)) ncap *= 2;
+        if (ncap == capE) ncap *= 2;
+        if (ncap > XT_TH_MAXCAP)
+            return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "more than 8192 live state sequences per step: raise threshold or lower max_nb_states");
+        ctx->th_capE = ncap;
+    }
+    // apply geometry: a workgroup serves tiles of TT tracks of one chunk and keeps that chunk's plan in LDS when it is small
+    // enough (always, for the usual 2-3 state models); TT = as many tracks as keep the tile within ~48 KiB of LDS
+    a.capG = maxG;
+    a.plan_cap = (size_t)sumE * 6 + 2 * (size_t)Lmax <= 24 * 1024 ? std::max(sumE, 1) : 0;
+    auto lds_of = [&](int tt, bool single = false) {
+        return (size_t)xt_th_apply_lds_doubles(S, G, maxG, tt, D, K, a.KS, Lmax, a.plan_cap, tt == 64, single) * 8;
+    };
+    // 64 tracks per tile (wave-uniform scalar path): two state buffers when two such workgroups fit a CU's LDS, one buffer
+    // (merged sequences wait in registers) while at most XT_TH_GPW groups fall to a wavefront; else fewer tracks
+    int TT = 64;
+    int single_buf = 0;
+    if (ctx->th_force_tt > 0) TT = ctx->th_force_tt;
+    else if (chunk < 48 || lds_of(64) > 76 * 1024) {
+        if (chunk >= 48 && maxG <= 16 * XT_TH_GPW && lds_of(64, true) <= 160 * 1024) {
+            single_buf = 1;
+        } else {
+            TT = 32;
+            while (TT > 1 && (TT > chunk * 2 || lds_of(TT) > 48 * 1024)) TT >>= 1;
+        }
+    }
+    if (TT == 64 && ctx->th_force_single && maxG <= 16 * XT_TH_GPW) single_buf = 1;
+    while (TT > 1 && lds_of(TT, single_buf) > 160 * 1024) TT >>= 1;
+    if (TT != 64) single_buf = 0;
+    const bool uni = TT == 64;
+    const size_t lds = lds_of(TT, single_buf);
+    if (lds > 160 * 1024) return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "live state sequences do not fit the 160 KiB LDS of a CU");
+    a.TT = TT;
+    a.logTT = 0;
+    while ((1 << a.logTT) < TT) ++a.logTT;
+    int threads = (maxG * TT + 63) / 64 * 64;
+    threads = threads > 256 ? 256 : threads;
+    threads = threads < TT ? TT : threads;
+    if (uni) threads = 64 * std::max(4, std::min(16, maxG));  // one wavefront per live parent sequence of the 64-track tile
+    int force_threads = ctx->th_force_threads;
+    if (uni && single_buf && force_threads > 0 && (force_threads / 64) * XT_TH_GPW < maxG) force_threads = 0;
+    if (force_threads > 0 && force_threads % TT == 0) threads = force_threads;
+    const int64_t tpc = (chunk + TT - 1) / TT;
+    int blocks_per_cu = (int)std::min<size_t>(8, (160 * 1024) / lds);
+    blocks_per_cu = std::max(1, std::min(blocks_per_cu, 2048 / threads));
+    const int64_t target = (int64_t)ctx->n_cu * blocks_per_cu * ctx->th_oversub;
+    int64_t bpc = (target + a.nchunks - 1) / a.nchunks;
+    bpc = std::max<int64_t>(1, std::min<int64_t>(bpc, tpc));
+    a.bpc = (int32_t)bpc;
+    const int grid = (int)(a.nchunks * bpc);
+    if ((rc = xt_grow_partials(ctx, poff + (size_t)grid))) return rc;
+    a.partials = ctx->d_partials + poff;
+#define XT_TH_APPLY_CALL(...) xt_th_launch_apply<__VA_ARGS__>(ctx, a, grid, threads, lds, uni ? (single_buf ? 2 : 1) : 0, ctx->stream)
+    if (D == 1 && K == 1) e = XT_TH_APPLY_CALL(1, 1);
+    else if (D == 2 && K == 1) e = XT_TH_APPLY_CALL(2, 1);
+    else if (D == 2 && K == 2) e = XT_TH_APPLY_CALL(2, 2);
+    else if (D == 3 && K == 1) e = XT_TH_APPLY_CALL(3, 1);
+    else e = XT_TH_APPLY_CALL(3, 3);
+#undef XT_TH_APPLY_CALL
+    if (e != hipSuccess) return xt_fail(ctx, EXTRACK_E_HIP, std::string("apply kernel launch: ") + hipGetErrorString(e));
+    poff += (size_t)grid;
+    ctx->launch_info[0] = grid;
+    ctx->launch_info[1] = threads;
+    ctx->launch_info[2] = (int32_t)lds;
+    ctx->launch_info[3] = TT;
+    ctx->launch_info[4] = blocks_per_cu;
+    ctx->launch_info[5] = ctx->n_cu;
+    return EXTRACK_OK;
+}
+
 extern "C" int extrack_loglik_th(extrack_ctx* ctx, const extrack_model* m, double threshold, int32_t max_nb_states, int32_t chunk,
                                  double* total_ll, double* per_track)
 {
@@ -816,201 +1071,26 @@ extern "C" int extrack_loglik_th(extrack_ctx* ctx, const extrack_model* m, doubl
     std::string err = xt_th_build_blob(mh, blob, G);
     if (!err.empty()) return xt_fail(ctx, EXTRACK_E_INVALID, err);
     if ((rc = xt_upload_blob(ctx, blob))) return rc;
-    const int S = m->n_states, NS = m->nb_substeps, F = m->frame_len;
-    if (S * G > XT_TH_MAXCAP) return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "n_states^(nb_substeps+1) exceeds the plan capacity");
+    if (m->n_states * G > XT_TH_MAXCAP) return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "n_states^(nb_substeps+1) exceeds the plan capacity");
     if (per_track)
         for (auto& b : ctx->buckets)
             if (!b.d_ll) XT_HIP(ctx, hipMalloc(&b.d_ll, (size_t)b.N * sizeof(double)));
+    // launch groups: buckets with the same (dims, sigma dims)
+    std::vector<XtBucket*> order;
+    for (auto& b : ctx->buckets) order.push_back(&b);
+    std::stable_sort(order.begin(), order.end(), [](const XtBucket* x, const XtBucket* y) {
+        if (x->D != y->D) return x->D < y->D;
+        return x->KS < y->KS;
+    });
     size_t poff = 0;
-    float plan_ms = 0.f;
     XT_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-    for (auto& b : ctx->buckets) {
-        const int D = b.D;
-        int K;
-        if (m->locerr_mode == 0) {
-            K = m->locerr_dims;
-        } else {
-            if (!b.d_sigma) return xt_fail(ctx, EXTRACK_E_INVALID, "per-peak localisation error mode but the bucket has no sigma");
-            K = b.KS;
-        }
-        XtThArgs a;
-        memset(&a, 0, sizeof(a));
-        a.tracks = b.d_tracks;
-        a.sigma = m->locerr_mode ? b.d_sigma : nullptr;
-        a.blob = ctx->d_blob;
-        a.ll_out = per_track ? b.d_ll : nullptr;
-        a.N = b.N;
-        a.L = b.L;
-        a.S = S;
-        a.NS = NS;
-        a.G = G;
-        a.F = F;
-        a.isBL = (b.L != m->max_len) ? 1 : 0;  // tracking.py:1037-1040
-        a.min_len = m->min_len;
-        a.locerr_mode = m->locerr_mode;
-        a.KS = b.KS ? b.KS : 1;
-        a.chunk = chunk;
-        a.nchunks = (int32_t)((b.N + chunk - 1) / chunk);
-        a.max_nb = max_nb_states;
-        a.threshold = threshold;
-        a.pcap = std::min(chunk, XT_TH_PILOT);
-        a.ll_const = -(double)(b.L - 1) * D * 0.5 * XT_LOG2PI;
-        hipError_t e = hipSuccess;
-        int maxG = 0, sumE = 0;
-        bool force_global = false;
-        for (;;) {  // plan, growing the capacity on overflow
-            int capE = ctx->th_capE;
-            while (capE < S * G) capE *= 2;
-            ctx->th_capE = capE;
-            if ((rc = xt_th_reserve_plan(ctx, b, chunk, capE))) return rc;
-            a.capE = capE;
-            a.members = b.th_members;
-            a.mpack = b.th_mpack;
-            a.gnew = b.th_gnew;
-            a.gstart = b.th_gstart;
-            a.hdr = b.th_hdr;
-            a.status = b.th_status;
-            const int grid = std::min<int64_t>(a.nchunks, (int64_t)ctx->n_cu * 2);
-            // pilot-track state: in LDS when the sequence counts of the previous evaluation (+25 %) fit 64 KiB, else in a
-            // global workspace sized for the full plan capacity
-            size_t lds = (size_t)xt_th_plan_lds_doubles(S, G, capE, D, K) * sizeof(double);
-            bool lds_mode = false;
-            a.wsP = a.wsE = capE;
-            if (ctx->th_learnE > 0 && !force_global) {
-                const int wp = std::min(capE, std::max(S * G, ctx->th_learnP)), we = std::min(capE, std::max(S * G, ctx->th_learnE));
-                const size_t need = lds + (size_t)xt_th_ws_doubles(wp, we, D, K, F, NS, S, a.pcap) * sizeof(double);
-                if (need <= 64 * 1024) {
-                    lds_mode = true;
-                    lds = need;
-                    a.wsP = wp;
-                    a.wsE = we;
-                }
-            }
-            a.ws_lds = lds_mode ? 1 : 0;
-            a.stP = a.stE = 0;
-            if (!lds_mode && ctx->th_learnE > 0 && !force_global) {
-                // LDS copy of what the grouping reads (pilot means, stds), sized by the previous evaluation's sequence counts
-                const int sp = std::min(capE, ctx->th_learnP), se = std::min(capE, ctx->th_learnE);
-                const size_t st = (size_t)a.pcap * ((size_t)sp * D + (size_t)se * K) * sizeof(double);
-                if (lds + st <= 120 * 1024) {
-                    a.stP = sp;
-                    a.stE = se;
-                    lds += st;
-                }
-            }
-            a.ws_stride = xt_th_ws_doubles(a.wsP, a.wsE, D, K, F, NS, S, a.pcap);
-            if (!lds_mode) {
-                const size_t need = (size_t)a.ws_stride * grid * sizeof(double);
-                if (need > ctx->th_ws_cap) {
-                    XT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-                    if (ctx->d_th_ws) (void)hipFree(ctx->d_th_ws);
-                    ctx->d_th_ws = nullptr;
-                    ctx->th_ws_cap = 0;
-                    XT_HIP(ctx, hipMalloc(&ctx->d_th_ws, need));
-                    ctx->th_ws_cap = need;
-                }
-            }
-            a.ws = ctx->d_th_ws;
-            if (lds > 160 * 1024) return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "plan tables do not fit the 160 KiB LDS of a CU");
-#define XT_TH_PLAN_CALL(...) xt_th_launch_plan<__VA_ARGS__>(ctx, a, grid, lds)
-            if (D == 1 && K == 1) e = XT_TH_PLAN_CALL(1, 1);
-            else if (D == 2 && K == 1) e = XT_TH_PLAN_CALL(2, 1);
-            else if (D == 2 && K == 2) e = XT_TH_PLAN_CALL(2, 2);
-            else if (D == 3 && K == 1) e = XT_TH_PLAN_CALL(3, 1);
-            else if (D == 3 && K == 3) e = XT_TH_PLAN_CALL(3, 3);
-            else return xt_fail(ctx, EXTRACK_E_INVALID, "locerr_dims must be 1 or the track dimensionality");
-#undef XT_TH_PLAN_CALL
-            if (e != hipSuccess) return xt_fail(ctx, EXTRACK_E_HIP, std::string("plan kernel launch: ") + hipGetErrorString(e));
-            ctx->th_status_host.resize((size_t)a.nchunks * 4);
-            XT_HIP(ctx, hipMemcpyAsync(ctx->th_status_host.data(), b.th_status, (size_t)a.nchunks * 4 * sizeof(int32_t), hipMemcpyDeviceToHost,
-                                       ctx->stream));
-            XT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            int over = 0, maxE = 0;
-            maxG = sumE = 0;
-            for (int c = 0; c < a.nchunks; ++c) {
-                over |= ctx->th_status_host[(size_t)c * 4];
-                maxE = std::max(maxE, ctx->th_status_host[(size_t)c * 4 + 1]);
-                maxG = std::max(maxG, ctx->th_status_host[(size_t)c * 4 + 2]);
-                sumE = std::max(sumE, ctx->th_status_host[(size_t)c * 4 + 3]);
-            }
-            if (!over) {
-                ctx->th_learnP = maxG + maxG / 4 + 2;
-                ctx->th_learnE = maxE + maxE / 4 + 2;
-                break;
-            }
-            if (lds_mode) {  // the learned LDS capacities were too small for these parameters: redo with the global workspace
-                force_global = true;
-                continue;
-            }
-            int ncap = capE;
-            while (ncap < maxE) ncap *= 2;
-            if (ncap == capE) ncap *= 2;
-            if (ncap > XT_TH_MAXCAP)
-                return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "more than 8192 live state sequences per step: raise threshold or lower max_nb_states");
-            ctx->th_capE = ncap;
-        }
-        // apply geometry: a workgroup serves tiles of TT tracks of one chunk and keeps that chunk's plan in LDS when it is
-        // small enough (always, for the usual 2-3 state models); TT = as many tracks as keep the tile within ~48 KiB of LDS
-        a.capG = maxG;
-        a.plan_cap = (size_t)sumE * 6 + 2 * (size_t)b.L <= 24 * 1024 ? std::max(sumE, 1) : 0;
-        auto lds_of = [&](int tt, bool single = false) {
-            return (size_t)xt_th_apply_lds_doubles(S, G, maxG, tt, D, K, a.KS, b.L, a.plan_cap, tt == 64, single) * 8;
-        };
-        // 64 tracks per tile (wave-uniform scalar path): two state buffers when two such workgroups fit a CU's LDS, one
-        // buffer (merged sequences wait in registers) while at most XT_TH_GPW groups fall to a wavefront; else fewer tracks
-        int TT = 64;
-        int single_buf = 0;
-        if (ctx->th_force_tt > 0) TT = ctx->th_force_tt;
-        else if (chunk < 48 || lds_of(64) > 76 * 1024) {
-            if (chunk >= 48 && maxG <= 16 * XT_TH_GPW && lds_of(64, true) <= 160 * 1024) {
-                single_buf = 1;
-            } else {
-                TT = 32;
-                while (TT > 1 && (TT > chunk * 2 || lds_of(TT) > 48 * 1024)) TT >>= 1;
-            }
-        }
-        if (TT == 64 && ctx->th_force_single && maxG <= 16 * XT_TH_GPW) single_buf = 1;
-        while (TT > 1 && lds_of(TT, single_buf) > 160 * 1024) TT >>= 1;
-        if (TT != 64) single_buf = 0;
-        const bool uni = TT == 64;
-        const size_t lds = lds_of(TT, single_buf);
-        if (lds > 160 * 1024) return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "live state sequences do not fit the 160 KiB LDS of a CU");
-        a.TT = TT;
-        a.logTT = 0;
-        while ((1 << a.logTT) < TT) ++a.logTT;
-        int threads = (maxG * TT + 63) / 64 * 64;
-        threads = threads > 256 ? 256 : threads;
-        threads = threads < TT ? TT : threads;
-        if (uni) threads = 64 * std::max(4, std::min(16, maxG));  // one wavefront per live parent sequence of the 64-track tile
-        if (uni && single_buf && ctx->th_force_threads > 0 && (ctx->th_force_threads / 64) * XT_TH_GPW < maxG) ctx->th_force_threads = 0;
-        if (ctx->th_force_threads > 0 && ctx->th_force_threads % TT == 0) threads = ctx->th_force_threads;
-        const int64_t tpc = (chunk + TT - 1) / TT;
-        int blocks_per_cu = (int)std::min<size_t>(8, (160 * 1024) / lds);
-        blocks_per_cu = std::max(1, std::min(blocks_per_cu, 2048 / threads));
-        const int64_t target = (int64_t)ctx->n_cu * blocks_per_cu * ctx->th_oversub;
-        int64_t bpc = (target + a.nchunks - 1) / a.nchunks;
-        bpc = std::max<int64_t>(1, std::min<int64_t>(bpc, tpc));
-        a.bpc = (int32_t)bpc;
-        const int grid = (int)(a.nchunks * bpc);
-        if ((rc = xt_grow_partials(ctx, poff + (size_t)grid))) return rc;
-        a.partials = ctx->d_partials + poff;
-#define XT_TH_APPLY_CALL(...) xt_th_launch_apply<__VA_ARGS__>(ctx, a, grid, threads, lds, uni ? (single_buf ? 2 : 1) : 0)
-        if (D == 1 && K == 1) e = XT_TH_APPLY_CALL(1, 1);
-        else if (D == 2 && K == 1) e = XT_TH_APPLY_CALL(2, 1);
-        else if (D == 2 && K == 2) e = XT_TH_APPLY_CALL(2, 2);
-        else if (D == 3 && K == 1) e = XT_TH_APPLY_CALL(3, 1);
-        else e = XT_TH_APPLY_CALL(3, 3);
-#undef XT_TH_APPLY_CALL
-        if (e != hipSuccess) return xt_fail(ctx, EXTRACK_E_HIP, std::string("apply kernel launch: ") + hipGetErrorString(e));
-        poff += (size_t)grid;
-        ctx->launch_info[0] = grid;
-        ctx->launch_info[1] = threads;
-        ctx->launch_info[2] = (int32_t)lds;
-        ctx->launch_info[3] = TT;
-        ctx->launch_info[4] = blocks_per_cu;
-        ctx->launch_info[5] = ctx->n_cu;
+    for (size_t i = 0; i < order.size();) {
+        size_t jn = i;
+        std::vector<XtBucket*> grp;
+        while (jn < order.size() && order[jn]->D == order[i]->D && order[jn]->KS == order[i]->KS) grp.push_back(order[jn++]);
+        if ((rc = xt_th_run_group(ctx, m, grp, threshold, max_nb_states, chunk, G, per_track != nullptr, poff))) return rc;
+        i = jn;
     }
-    (void)plan_ms;
     XT_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     ctx->timed = true;
     hipLaunchKernelGGL(xt_reduce_partials, dim3(1), dim3(256), 0, ctx->stream, ctx->d_partials, (int)poff, ctx->d_total);
@@ -1100,7 +1180,7 @@ extern "C" int extrack_predict_th(extrack_ctx* ctx, const extrack_model* m, int3
     }
     a.status = d_status;
     rc = EXTRACK_OK;
-    hipEventRecord(ctx->ev0, ctx->stream);
+    (void)hipEventRecord(ctx->ev0, ctx->stream);
     // Pass 0 (probe): the first chunks with the state in the global workspace -> live-sequence counts of this model.
     // Pass 1: everything with the state in LDS, capacities = 1.5 x the probe's maxima (when that fits ~40 KiB per workgroup).
     // Pass 2 (only after an overflow of pass 1, or when LDS does not fit): everything with the global workspace.
@@ -1192,7 +1272,7 @@ extern "C" int extrack_predict_th(extrack_ctx* ctx, const extrack_model* m, int3
     }
     a.nchunks = all_chunks;
     if (rc == EXTRACK_OK) {
-        hipEventRecord(ctx->ev1, ctx->stream);
+        (void)hipEventRecord(ctx->ev1, ctx->stream);
         ctx->timed = true;
         e = hipMemcpyAsync(preds, d_preds, nbytes, hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);

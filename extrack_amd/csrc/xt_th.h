@@ -32,6 +32,24 @@
 #define XT_TH_CMAT_WORDS 2048  // LDS budget (32-bit words) of the pivot -> candidate compatibility bit matrix
 #define XT_TH_GPW 4      // single-buffer apply kernel: merge groups per wavefront held in registers
 
+// Per-bucket part of the arguments: a launch may serve all length buckets of a dataset at once (XtThArgs::buckets), the
+// global chunk index of a workgroup is then resolved to (bucket, chunk of that bucket) through XtThArgs::chunk_end.
+struct XtThBucket {
+    const double* tracks;  // [N][L][D]
+    const double* sigma;   // [N][L][KS] or nullptr
+    double* ll_out;        // [N] or nullptr
+    double* preds_out;     // [N][L][S] (prediction kernel)
+    int64_t N;
+    int32_t L, isBL;
+    double ll_const;       // -(L-1)*D/2*log(2*pi)
+    uint16_t* members;     // plan arrays of this bucket, see XtThArgs
+    uint32_t* mpack;
+    uint16_t* gstart;
+    uint8_t* gnew;
+    int32_t* hdr;
+    int32_t* status;
+};
+
 struct XtThArgs {
     const double* tracks;  // [N][L][D]
     const double* sigma;   // [N][L][KS] or nullptr
@@ -60,6 +78,10 @@ struct XtThArgs {
     int32_t wsP, wsE;      // workspace capacities: parent sequences / expanded sequences per pilot track
     int32_t stP, stE;      // global workspace only: capacities of the LDS staging copy of the pilots' means / stds that the
                            // grouping reads (0: none); steps with more sequences read the workspace directly
+    const XtThBucket* buckets;  // device array [nbuckets], or nullptr: the single bucket described by the fields above
+    const int32_t* chunk_end;   // device array [nbuckets]: exclusive prefix sum of the buckets' chunk counts
+    int32_t nbuckets;
+    int32_t Lmax;               // longest track length of the launch (LDS sizing of the apply kernel)
     int32_t TT, logTT;     // apply kernel: tracks per workgroup tile (power of two)
     int32_t capG;          // apply kernel: parent-sequence capacity of the LDS buffers
     int32_t bpc;           // apply kernel: workgroups per chunk (a workgroup serves tiles of ONE chunk)
@@ -82,6 +104,58 @@ struct XtCPtr<true, T> {
 #endif
 
 XT_HD int xt_popc64(unsigned long long v) { return __builtin_popcountll(v); }
+
+// Resolves a global chunk index to its bucket (by value) and the chunk index inside that bucket.
+XT_HD XtThBucket xt_th_bind(const XtThArgs& a, int gch, int& lc)
+{
+    XtThBucket k;
+    if (a.buckets == nullptr) {
+        k.tracks = a.tracks;
+        k.sigma = a.sigma;
+        k.ll_out = a.ll_out;
+        k.preds_out = a.preds_out;
+        k.N = a.N;
+        k.L = a.L;
+        k.isBL = a.isBL;
+        k.ll_const = a.ll_const;
+        k.members = a.members;
+        k.mpack = a.mpack;
+        k.gstart = a.gstart;
+        k.gnew = a.gnew;
+        k.hdr = a.hdr;
+        k.status = a.status;
+        lc = gch;
+        return k;
+    }
+    // the table is read through the constant address space: the chunk index is workgroup-uniform, so the descriptor (and every
+    // pointer in it) lands in scalar registers and stays provably uniform for the scalar-load paths of the kernels
+    const typename XtCPtr<true, int32_t>::type cend = XtCPtr<true, int32_t>::make(a.chunk_end);
+    const typename XtCPtr<true, XtThBucket>::type tab = XtCPtr<true, XtThBucket>::make(a.buckets);
+    int lo = 0, hi = a.nbuckets - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (gch >= cend[mid])
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    lc = gch - (lo ? cend[lo - 1] : 0);
+    k.tracks = tab[lo].tracks;
+    k.sigma = tab[lo].sigma;
+    k.ll_out = tab[lo].ll_out;
+    k.preds_out = tab[lo].preds_out;
+    k.N = tab[lo].N;
+    k.L = tab[lo].L;
+    k.isBL = tab[lo].isBL;
+    k.ll_const = tab[lo].ll_const;
+    k.members = tab[lo].members;
+    k.mpack = tab[lo].mpack;
+    k.gstart = tab[lo].gstart;
+    k.gnew = tab[lo].gnew;
+    k.hdr = tab[lo].hdr;
+    k.status = tab[lo].status;
+    return k;
+}
 
 // a / b < thr with the outcome of the correctly rounded IEEE division (what numpy computes, tracking.py:691-694): the
 // hardware reciprocal (rel. error < 1e-7) decides everything that is not within 1e-5 of the threshold, the division proper
@@ -375,15 +449,18 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
     pwS[0] = 1;
     for (int i = 1; i < 8; ++i) pwS[i] = pwS[i - 1] * S;
 
-    for (int ch = cx.block(); ch < a.nchunks; ch += cx.nblocks()) {
+    for (int gch = cx.block(); gch < a.nchunks; gch += cx.nblocks()) {
+        int ch;  // chunk index inside its bucket
+        const XtThBucket bk = xt_th_bind(a, gch, ch);
+        const int L = bk.L;
         const int64_t c0 = (int64_t)ch * a.chunk;
-        const int n = (int)((a.N - c0) < a.chunk ? (a.N - c0) : a.chunk);
+        const int n = (int)((bk.N - c0) < a.chunk ? (bk.N - c0) : a.chunk);
         const int P = n < XT_TH_PILOT ? n : XT_TH_PILOT;
-        uint16_t* mem_g = a.members + (int64_t)ch * L * capE;
-        uint32_t* mpk_g = a.mpack + (int64_t)ch * L * capE;
-        uint16_t* gst_g = a.gstart + (int64_t)ch * L * (capE + 1);
-        uint8_t* gnew_g = a.gnew + (int64_t)ch * L * capE;
-        int32_t* hdr_g = a.hdr + (int64_t)ch * L * 2;
+        uint16_t* mem_g = bk.members + (int64_t)ch * L * capE;
+        uint32_t* mpk_g = bk.mpack + (int64_t)ch * L * capE;
+        uint16_t* gst_g = bk.gstart + (int64_t)ch * L * (capE + 1);
+        uint8_t* gnew_g = bk.gnew + (int64_t)ch * L * capE;
+        int32_t* hdr_g = bk.hdr + (int64_t)ch * L * 2;
         cx.sync();  // tables loaded / previous chunk done
 
         auto load_l2 = [&](int x, int pos, double* l2) {
@@ -391,7 +468,7 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
                 for (int k = 0; k < K; ++k) l2[k] = hdr[k];
             } else {
                 for (int k = 0; k < K; ++k)
-                    l2[k] = xt_th_l2_from_sigma(a.sigma[((c0 + x) * L + pos) * a.KS + (a.KS == 1 ? 0 : k)], a.locerr_mode, hdr);
+                    l2[k] = xt_th_l2_from_sigma(bk.sigma[((c0 + x) * L + pos) * a.KS + (a.KS == 1 ? 0 : k)], a.locerr_mode, hdr);
             }
         };
 
@@ -402,7 +479,7 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
             load_l2(x, 0, l2);
             A.zm(idx) = hdr[8 + s];
             A.ze(idx) = 0;
-            for (int d = 0; d < D; ++d) A.m(d, idx) = a.tracks[((c0 + x) * L + 0) * D + d];
+            for (int d = 0; d < D; ++d) A.m(d, idx) = bk.tracks[((c0 + x) * L + 0) * D + d];
             for (int k = 0; k < K; ++k) A.u(k, idx) = l2[k];
         }
         for (int i = tid; i < (PREDS ? P : 1) * S * S; i += nt) {
@@ -424,7 +501,7 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
                 for (int i = tid; i < P * nPar; i += nt) {
                     const int x = i / nPar, g = i - x * nPar;
                     double c[D], l2[K];
-                    for (int d = 0; d < D; ++d) c[d] = a.tracks[((c0 + x) * L + pos) * D + d];
+                    for (int d = 0; d < D; ++d) c[d] = bk.tracks[((c0 + x) * L + pos) * D + d];
                     load_l2(x, pos, l2);
                     xt_th_integrate<D, K>(bA, x * wsP + g, c, l2, T64);
                 }
@@ -749,13 +826,13 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
             cx.sync();
             const int tl = L - 1, nE = nPar * G;
             const bool stay = tl >= 2 && tl >= a.min_len;
-            const double* TF = TAB + ((a.isBL ? 2 : 0) + (stay ? 1 : 0)) * S * G;
+            const double* TF = TAB + ((bk.isBL ? 2 : 0) + (stay ? 1 : 0)) * S * G;
             for (int i = tid; i < P * nE; i += nt) {
                 const int x = i / nE, jj = i - x * nE, g = jj / G, r = jj - g * G, idx = x * wsP + g, o = (int)nwA[g] * G + r;
                 double cl[D], l2l[K], dq[D], dsq = 0.0;
                 load_l2(x, tl, l2l);
                 for (int d = 0; d < D; ++d) {
-                    cl[d] = a.tracks[((c0 + x) * L + tl) * D + d];
+                    cl[d] = bk.tracks[((c0 + x) * L + tl) * D + d];
                     dq[d] = cl[d] - bA.m(d, idx);
                     dsq = xt_fma(dq[d], dq[d], dsq);
                 }
@@ -798,7 +875,7 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
             // through the merge tree; what passes through a member with new state r at merge step t is the posterior mass
             // of state r at position t
             for (int x = tid; x < P; x += nt) {
-                double* post = a.preds_out + (c0 + x) * (int64_t)L * S;
+                double* post = bk.preds_out + (c0 + x) * (int64_t)L * S;
                 for (int i = 0; i < L * S; ++i) post[i] = 0.0;
                 double* bc = beta + (int64_t)x * 2 * wsP;
                 double* bp = bc + wsP;
@@ -832,10 +909,10 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
             cx.sync();
         }
         if (tid == 0) {
-            a.status[ch * 4 + 0] = overflow;
-            a.status[ch * 4 + 1] = maxE;
-            a.status[ch * 4 + 2] = maxG;
-            a.status[ch * 4 + 3] = sumE;
+            bk.status[ch * 4 + 0] = overflow;
+            bk.status[ch * 4 + 1] = maxE;
+            bk.status[ch * 4 + 2] = maxG;
+            bk.status[ch * 4 + 3] = sumE;
         }
     }
 }
@@ -854,7 +931,12 @@ template <int D, int K, bool UNI, bool SINGLE, class Ctx>
 XT_HD void xt_th_apply_body(const XtThArgs& a, Ctx& cx)
 {
     typedef XtThView<D, K, true> View;
-    const int S = a.S, G = a.G, L = a.L, capE = a.capE, TT = UNI ? 64 : a.TT, capG = a.capG, KS = a.KS;
+    const int S = a.S, G = a.G, capE = a.capE, TT = UNI ? 64 : a.TT, capG = a.capG, KS = a.KS;
+    const int Lmax = a.buckets ? a.Lmax : a.L;
+    const int gch = cx.block() / a.bpc, sub = cx.block() - gch * a.bpc;
+    int ch;  // chunk index inside its bucket
+    const XtThBucket bk = xt_th_bind(a, gch, ch);
+    const int L = bk.L;
     const int logTT = UNI ? 6 : a.logTT;
     const int tid = cx.tid(), nt = cx.nthreads();
     const int TP = TT + 1;  // padded row of the position stage
@@ -889,21 +971,20 @@ XT_HD void xt_th_apply_body(const XtThArgs& a, Ctx& cx)
     w += TT;
     const bool resident = !UNI && a.plan_cap > 0;
     const int pmcap = UNI ? 0 : (resident ? a.plan_cap : capEl);
-    const int pgcap = UNI ? 0 : (resident ? a.plan_cap + L : capEl + 1);
+    const int pgcap = UNI ? 0 : (resident ? a.plan_cap + Lmax : capEl + 1);
     int* nanflag = (int*)w;
     int* pstep = nanflag + TT;               // [L][4]: member offset, gstart offset, nE, nG
-    uint32_t* pmem = (uint32_t*)(pstep + 4 * L);
+    uint32_t* pmem = (uint32_t*)(pstep + 4 * Lmax);
     uint16_t* pgst = (uint16_t*)(pmem + pmcap);
     uint8_t* nfin = (uint8_t*)(pgst + pgcap + (pgcap & 1));  // newest state of the parents the last position sees
 
-    const int ch = cx.block() / a.bpc, sub = cx.block() - ch * a.bpc;
     const int64_t c0 = (int64_t)ch * a.chunk;
-    const int n = (int)((a.N - c0) < a.chunk ? (a.N - c0) : a.chunk);
+    const int n = (int)((bk.N - c0) < a.chunk ? (bk.N - c0) : a.chunk);
     const int ntile = (n + TT - 1) >> logTT;
-    const uint32_t* mpk_g = a.mpack + (int64_t)ch * L * capE;
-    const uint16_t* gst_g = a.gstart + (int64_t)ch * L * (capE + 1);
-    const uint8_t* gnew_g = a.gnew + (int64_t)ch * L * capE;
-    const int32_t* hdr_g = a.hdr + (int64_t)ch * L * 2;
+    const uint32_t* mpk_g = bk.mpack + (int64_t)ch * L * capE;
+    const uint16_t* gst_g = bk.gstart + (int64_t)ch * L * (capE + 1);
+    const uint8_t* gnew_g = bk.gnew + (int64_t)ch * L * capE;
+    const int32_t* hdr_g = bk.hdr + (int64_t)ch * L * 2;
     const typename CI32::type hdr_u = CI32::make(hdr_g);
     const typename CU8::type gnew_u = CU8::make(gnew_g);
     const int x = tid & (TT - 1);  // TT is a power of two <= nthreads
@@ -953,7 +1034,7 @@ XT_HD void xt_th_apply_body(const XtThArgs& a, Ctx& cx)
             for (int i = tid; i < TT * XT_TH_STAGE * D; i += nt) {
                 const int xx = i / (XT_TH_STAGE * D), o = i - xx * (XT_TH_STAGE * D);
                 if (xx < nx && o < np * D) {
-                    const double v = a.tracks[((first + xx) * L + p0) * D + o];
+                    const double v = bk.tracks[((first + xx) * L + p0) * D + o];
                     spos[o * TP + xx] = v;
                     if (v != v) nanflag[xx] = 1;  // NaN input: the track's result becomes NaN, as in the reference
                 }
@@ -962,7 +1043,7 @@ XT_HD void xt_th_apply_body(const XtThArgs& a, Ctx& cx)
                 for (int i = tid; i < TT * XT_TH_STAGE * KS; i += nt) {
                     const int xx = i / (XT_TH_STAGE * KS), o = i - xx * (XT_TH_STAGE * KS);
                     if (xx < nx && o < np * KS) {
-                        const double v = a.sigma[((first + xx) * L + p0) * KS + o];
+                        const double v = bk.sigma[((first + xx) * L + p0) * KS + o];
                         ssig[o * TP + xx] = v;
                         if (v != v) nanflag[xx] = 1;
                     }
@@ -1089,7 +1170,7 @@ XT_HD void xt_th_apply_body(const XtThArgs& a, Ctx& cx)
         if ((tl & (XT_TH_STAGE - 1)) == 0) stage(tl);
         if (act) {
             const bool stay = tl >= 2 && tl >= a.min_len;
-            const typename CD::type TF = TAB + ((a.isBL ? 2 : 0) + (stay ? 1 : 0)) * S * G;
+            const typename CD::type TF = TAB + ((bk.isBL ? 2 : 0) + (stay ? 1 : 0)) * S * G;
             double cl[D], l2l[K];
             for (int d = 0; d < D; ++d) cl[d] = spos[((tl & (XT_TH_STAGE - 1)) * D + d) * TP + x];
             load_l2(tl, l2l);
@@ -1137,8 +1218,8 @@ XT_HD void xt_th_apply_body(const XtThArgs& a, Ctx& cx)
             XtAcc tot;
             tot.clear();
             for (int g = 0; g < nPar; ++g) tot.add(nxt.zm(g * TT + x), nxt.ze(g * TT + x));
-            const double ll = nanflag[x] ? NAN : log(tot.m) + (double)tot.e * XT_LN2 + a.ll_const;
-            if (a.ll_out) a.ll_out[first + x] = ll;
+            const double ll = nanflag[x] ? NAN : log(tot.m) + (double)tot.e * XT_LN2 + bk.ll_const;
+            if (bk.ll_out) bk.ll_out[first + x] = ll;
             my_ll += ll;
         }
     }

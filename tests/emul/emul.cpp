@@ -512,3 +512,99 @@ extern "C" int xt_emul_th_predict(const double* tracks, const double* sigma, lon
         if (status[(size_t)c * 4]) return -5;
     return 0;
 }
+
+
+// ---- threshold-fusion evaluation of several buckets through the bucket-descriptor table (ONE emulated plan launch and ONE
+// apply launch for all of them, the product's launch mode).  Global scalar localisation error only.
+extern "C" int xt_emul_th_run_multi(int nbuckets, const double** tracks, const long long* Ns, const int* Ls, int D, int S, int NS, int F,
+                                    int max_len, int min_len, int locerr_dims, const double* locerr, double pBL, const double* ds,
+                                    const double* Fs, const double* TrMat, const double* p_stay, double threshold, int max_nb, int chunk,
+                                    int capE, int TT, int threads, int bpc, double** ll_out, double* total)
+{
+    XtModelHost m{S, NS, locerr_dims, {0, 0, 0}, 0.0, 0.0, pBL, ds, Fs, TrMat, p_stay};
+    for (int k = 0; k < 3; ++k) m.locerr[k] = locerr[k < locerr_dims ? k : 0];
+    std::vector<double> blob;
+    int G = 0;
+    if (!xt_th_build_blob(m, blob, G).empty()) return -1;
+    const int K = locerr_dims;
+    XtThArgs a;
+    memset(&a, 0, sizeof(a));
+    a.blob = blob.data();
+    a.S = S;
+    a.NS = NS;
+    a.G = G;
+    a.F = F;
+    a.min_len = min_len;
+    a.KS = 1;
+    a.chunk = chunk;
+    a.capE = capE;
+    a.max_nb = max_nb;
+    a.threshold = threshold;
+    a.pcap = chunk < XT_TH_PILOT ? chunk : XT_TH_PILOT;
+    a.wsP = a.wsE = capE;
+    a.nbuckets = nbuckets;
+    std::vector<XtThBucket> desc(nbuckets);
+    std::vector<int32_t> cend(nbuckets);
+    std::vector<std::vector<uint16_t>> mem(nbuckets), gst(nbuckets);
+    std::vector<std::vector<uint32_t>> mpk(nbuckets);
+    std::vector<std::vector<uint8_t>> gnw(nbuckets);
+    std::vector<std::vector<int32_t>> hdr(nbuckets);
+    int total_chunks = 0, Lmax = 0;
+    for (int i = 0; i < nbuckets; ++i) {
+        total_chunks += (int)((Ns[i] + chunk - 1) / chunk);
+        cend[i] = total_chunks;
+        Lmax = Ls[i] > Lmax ? Ls[i] : Lmax;
+    }
+    std::vector<int32_t> status((size_t)total_chunks * 4, 0);
+    for (int i = 0; i < nbuckets; ++i) {
+        const size_t nch = (size_t)(cend[i] - (i ? cend[i - 1] : 0));
+        mem[i].assign(nch * Ls[i] * capE, 0);
+        mpk[i].assign(nch * Ls[i] * capE, 0);
+        gnw[i].assign(nch * Ls[i] * capE, 0);
+        gst[i].assign(nch * Ls[i] * (capE + 1), 0);
+        hdr[i].assign(nch * Ls[i] * 2, 0);
+        desc[i] = XtThBucket{tracks[i], nullptr, ll_out ? ll_out[i] : nullptr, nullptr, Ns[i], Ls[i], Ls[i] != max_len ? 1 : 0,
+                             -(double)(Ls[i] - 1) * D * 0.5 * XT_LOG2PI, mem[i].data(), mpk[i].data(), gst[i].data(), gnw[i].data(),
+                             hdr[i].data(), status.data() + (size_t)(i ? cend[i - 1] : 0) * 4};
+    }
+    a.buckets = desc.data();
+    a.chunk_end = cend.data();
+    a.nchunks = total_chunks;
+    a.Lmax = a.L = Lmax;
+    const int plan_blocks = 3 < total_chunks ? 3 : total_chunks;
+    a.ws_stride = xt_th_ws_doubles(a.wsP, a.wsE, D, K, F, NS, S, a.pcap);
+    std::vector<double> ws((size_t)a.ws_stride * plan_blocks, 0.0);
+    a.ws = ws.data();
+    const size_t plan_lds = xt_th_plan_lds_doubles(S, G, capE, D, K);
+    if (D == 2 && K == 1) th_emul_blocks(plan_blocks, threads, plan_lds, [&](HostCtx& cx) { xt_th_plan_body<2, 1, false>(a, cx); });
+    else if (D == 3 && K == 1) th_emul_blocks(plan_blocks, threads, plan_lds, [&](HostCtx& cx) { xt_th_plan_body<3, 1, false>(a, cx); });
+    else return -3;
+    int maxG = 0, sumE = 0;
+    for (int c = 0; c < total_chunks; ++c) {
+        if (status[(size_t)c * 4]) return -5;
+        maxG = status[(size_t)c * 4 + 2] > maxG ? status[(size_t)c * 4 + 2] : maxG;
+        sumE = status[(size_t)c * 4 + 3] > sumE ? status[(size_t)c * 4 + 3] : sumE;
+    }
+    a.capG = maxG;
+    a.TT = TT;
+    a.logTT = 0;
+    while ((1 << a.logTT) < TT) ++a.logTT;
+    a.bpc = bpc;
+    a.plan_cap = sumE > 0 ? sumE : 1;
+    const int grid = total_chunks * bpc;
+    std::vector<double> partials(grid, 0.0);
+    a.partials = partials.data();
+    const bool uni = TT == 64;
+    const size_t lds = xt_th_apply_lds_doubles(S, G, maxG, TT, D, K, a.KS, Lmax, a.plan_cap, uni, false);
+    if (D == 2 && K == 1) {
+        if (uni) th_emul_blocks(grid, threads, lds, [&](HostCtx& cx) { xt_th_apply_body<2, 1, true, false>(a, cx); });
+        else th_emul_blocks(grid, threads, lds, [&](HostCtx& cx) { xt_th_apply_body<2, 1, false, false>(a, cx); });
+    } else {
+        if (uni) th_emul_blocks(grid, threads, lds, [&](HostCtx& cx) { xt_th_apply_body<3, 1, true, false>(a, cx); });
+        else th_emul_blocks(grid, threads, lds, [&](HostCtx& cx) { xt_th_apply_body<3, 1, false, false>(a, cx); });
+    }
+    double sacc = 0.0;
+    for (double p : partials) sacc += p;
+    if (total) *total = sacc;
+    return 0;
+}

@@ -143,3 +143,28 @@ def run_th_predict(Cs, LE, ds, Fs, T, pBL, isBL, p_stay, F, min_len, threshold, 
     if rc != 0:
         raise RuntimeError("emul th predict rc=%d status=%s" % (rc, status.tolist()))
     return pr
+
+
+def run_th_multi(buckets, locerr, ds, Fs, T, pBL, p_stay, ns, F, min_len, max_len, threshold, max_nb, chunk, capE=128, TT=8, threads=128, bpc=2):
+    """Several buckets through the bucket-descriptor table: one emulated plan launch + one apply launch."""
+    nb = len(buckets)
+    bk = [np.ascontiguousarray(b, float) for b in buckets]
+    D = bk[0].shape[2]
+    S = len(ds)
+    le = np.zeros(3)
+    locerr = np.atleast_1d(np.asarray(locerr, float)).ravel()
+    le[:len(locerr)] = locerr
+    outs = [np.zeros(len(b)) for b in bk]
+    PD = C.POINTER(C.c_double)
+    tr = (PD * nb)(*[dp(b) for b in bk])
+    lo = (PD * nb)(*[dp(o) for o in outs])
+    Ns = (C.c_longlong * nb)(*[len(b) for b in bk])
+    Ls = (C.c_int * nb)(*[b.shape[1] for b in bk])
+    tot = C.c_double(0)
+    ds, Fs, T, p_stay = [np.ascontiguousarray(x, float) for x in (ds, Fs, T, p_stay)]
+    rc = lib().xt_emul_th_run_multi(nb, tr, Ns, Ls, D, S, ns, F, int(max_len), int(min_len), len(locerr), dp(le), C.c_double(pBL), dp(ds),
+                                    dp(Fs), dp(T), dp(p_stay), C.c_double(threshold), int(max_nb), int(chunk), int(capE), int(TT),
+                                    int(threads), int(bpc), lo, C.byref(tot))
+    if rc != 0:
+        raise RuntimeError("emul th multi rc=%d" % rc)
+    return outs, tot.value

@@ -92,3 +92,26 @@ def test_th_posteriors_body_on_golden_subset():
                               chunk=len(Cs), capE=256, threads=64, nblocks=2)
         worst = max(worst, np.abs(pr - data[pre + "preds"]).max())
     assert len(rows) >= 8 and worst < 1e-9, (len(rows), worst)
+
+
+@pytest.mark.parametrize("TT,threads", [(8, 128), (64, 256)])
+def test_th_multi_bucket_launch(TT, threads):
+    """Three buckets of different lengths (one with a single ragged chunk, one shorter than the merge horizon) served by ONE plan
+    launch and ONE apply launch through the bucket-descriptor table; isBL per bucket from the dataset's max length."""
+    E = _emul()
+    rng = np.random.default_rng(23)
+    S, ns, F, chunk = 2, 1, 5, 40
+    ds = np.array([0.012, 0.11])
+    Fs = np.array([0.45, 0.55])
+    T = np.array([[0.9, 0.1], [0.15, 0.85]])
+    buckets = []
+    for L, N in ((3, 55), (8, 100), (13, 37)):
+        buckets.append(np.cumsum(rng.normal(0, 1, (N, L, 2)) * ds[rng.integers(0, S, (N, L, 1))], 1) + rng.normal(0, 0.02, (N, L, 2)))
+    ps = p_stay_table(ds, S, ns, [0.8])
+    outs, tot = E.run_th_multi(buckets, [0.02], ds, Fs, T, 0.07, ps, ns, F, 3, 13, 0.2, 30, chunk, TT=TT, threads=threads)
+    LE = np.array([[[0.02]]])
+    for b, o in zip(buckets, outs):
+        isBL = 0 if b.shape[1] == 13 else 1
+        ref = np.concatenate([OT.proba_cs_th(b[a:a + chunk], LE, ds, Fs, T, 0.07, isBL, [0.8], ns, F, 3, 0.2, 30) for a in range(0, len(b), chunk)])
+        assert np.abs(o - ref).max() < 1e-10
+    assert abs(tot - sum(o.sum() for o in outs)) < 1e-9
