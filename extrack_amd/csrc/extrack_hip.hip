@@ -177,6 +177,7 @@ struct extrack_ctx {
     size_t th_cend_cap = 0;
     float th_plan_ms = 0.f;
     int th_force_single = 0;
+    int th_pair_lanes = 4;  // EXTRACK_TH_PAIR_LANES
     int th_plan_threads = 512;  // workgroup size of the plan kernel (EXTRACK_TH_PLAN_THREADS)
     int th_force_tt = 0, th_force_threads = 0, th_oversub = 2;  // tuning knobs (EXTRACK_TH_TT / _THREADS / _OVERSUB)
     std::string err;
@@ -247,6 +248,7 @@ extern "C" int extrack_create(int device_id, extrack_ctx** out)
         int v = atoi(ev);
         if (v >= 64 && v <= 1024 && v % 64 == 0) c->th_plan_threads = v;
     }
+    if (const char* ev = getenv("EXTRACK_TH_PAIR_LANES")) c->th_pair_lanes = atoi(ev);
     if (const char* ev = getenv("EXTRACK_TH_SINGLE")) c->th_force_single = atoi(ev) != 0;
     if (const char* ev = getenv("EXTRACK_TH_OVERSUB")) {
         int v = atoi(ev);
@@ -857,6 +859,7 @@ static int xt_th_run_group(extrack_ctx* ctx, const extrack_model* m, const std::
     a.max_nb = max_nb_states;
     a.threshold = threshold;
     a.pcap = std::min(chunk, XT_TH_PILOT);
+    a.pair_lanes_max_p = ctx->th_pair_lanes;
     a.nbuckets = nbk;
     std::vector<int32_t> chunk_end(nbk);
     int64_t total = 0;
@@ -1172,6 +1175,7 @@ extern "C" int extrack_predict_th(extrack_ctx* ctx, const extrack_model* m, int3
     a.max_nb = max_nb_states;
     a.threshold = threshold;
     a.pcap = nb_max;
+    a.pair_lanes_max_p = ctx->th_pair_lanes;
     int32_t* d_status = nullptr;
     hipError_t e = hipMalloc(&d_status, (size_t)a.nchunks * 4 * sizeof(int32_t));
     if (e != hipSuccess) {

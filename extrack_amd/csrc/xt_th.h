@@ -10,19 +10,25 @@
 // tracking.py:1043).  The result is therefore a function of (track, chunk), not of the track alone.
 //
 // How it is organised for CDNA4 (NOT the reference's data flow):
-//   * PLAN kernel (xt_th_plan_body): one workgroup per chunk walks the recursion for the <= 30 pilot tracks and runs the
-//     greedy grouping on the device; output = the "plan" of the chunk: for every step the member lists of the merge
-//     groups (CSR: members[] sorted by group, gstart[]).  The state-history bookkeeping the reference uses for its
-//     "same last frame_len states" rule (the `cat` array, averaged with np.mean at every merge, tracking.py:729) is
-//     carried in fp64 with numpy's summation order, so that argmax ties resolve as they do in the reference.
-//   * APPLY kernel (xt_th_apply_body): every track of the chunk follows the plan.  Sequence weights are linear-domain
-//     extended-range numbers (zm * 2^ze) as in xt_kernel.h.  The Gaussian integration of a position depends only on the
-//     PARENT sequence (mean, variance), not on the new state digits, so it is done once per parent (one exp, one rcp)
-//     and the expansion by the S^ns new digits is folded into the merge: a group's new weight/mean/variance is a
-//     gather over its members (parent, new digits) of table lookups and FMAs.  The expanded S^ns-fold array of the
-//     reference never exists.  State lives in LDS as [sequence][field][track] with TT tracks of ONE chunk per workgroup
-//     (same plan -> uniform control flow, conflict-free LDS rows); a workgroup is bound to one chunk and keeps the chunk's
-//     whole plan in LDS, members pre-resolved to (parent, table offset) words so the gather does no index arithmetic.
+//   * PLAN kernel (xt_th_plan_body<D,K,false>): one workgroup per chunk walks the recursion for the <= 30 pilot tracks and runs
+//     the greedy grouping on the device; output = the "plan" of the chunk: for every step the member lists of the merge groups
+//     (CSR: members[] sorted by group, gstart[]), members pre-resolved to (parent sequence, table offset) words.  All
+//     (pivot, candidate) tests of a step are evaluated in one parallel phase into a bit matrix (counts via wave ballots), the
+//     greedy scan itself is bit arithmetic.  The state-history bookkeeping the reference uses for its "same last frame_len
+//     states" rule (the `cat` array, averaged with np.mean at every merge, tracking.py:729) is carried in fp64 with numpy's
+//     summation order, so that argmax ties resolve as they do in the reference.
+//   * APPLY kernel (xt_th_apply_body<D,K,UNI,SINGLE>): every track of the chunk follows the plan.  Sequence weights are
+//     linear-domain extended-range numbers (zm * 2^ze) as in xt_kernel.h.  The Gaussian integration of a position depends only
+//     on the PARENT sequence (mean, variance), not on the new state digits, so it is done once per parent (one exp, one rcp)
+//     and the expansion by the S^ns new digits is folded into the merge: a group's new weight/mean/variance is a gather over
+//     its members (parent, new digits) of table lookups and FMAs.  The expanded S^ns-fold array of the reference never
+//     exists.  State lives in LDS as one record per (sequence, track) with TT tracks of ONE chunk per workgroup (same plan ->
+//     uniform control flow); with TT = 64 a wavefront is the 64 tracks for one sequence, every plan / table index is
+//     wave-uniform and read with scalar loads, and the merge is fused with the next integration in registers.
+//   * POSTERIORS (xt_th_plan_body<D,K,true>): predict_Bs cuts a bucket into chunks of nb_max <= 30 tracks, so every track is a
+//     pilot track and the plan kernel itself serves: forward pass with per-track histories truncated to frame_len, the merge
+//     weights recorded, then one backward pass over the merge tree reads the posteriors out.
+//   * One launch of each kernel serves all length buckets of a dataset through a table of bucket descriptors (XtThBucket).
 #pragma once
 #include "xt_kernel.h"
 
@@ -76,6 +82,7 @@ struct XtThArgs {
     double* preds_out;     // [N][L][S] state posteriors (prediction kernel)
     int32_t ws_lds;        // 1: the pilot-track state lives in LDS (capacities learned from the previous evaluation)
     int32_t wsP, wsE;      // workspace capacities: parent sequences / expanded sequences per pilot track
+    int32_t pair_lanes_max_p;  // pilot counts up to this use one lane per (pivot, candidate) pair in the grouping, more use ballots
     int32_t stP, stE;      // global workspace only: capacities of the LDS staging copy of the pilots' means / stds that the
                            // grouping reads (0: none); steps with more sequences read the workspace directly
     const XtThBucket* buckets;  // device array [nbuckets], or nullptr: the single bucket described by the fields above
@@ -208,9 +215,11 @@ XT_HD int64_t xt_th_ws_doubles(int wsP, int wsE, int D, int K, int F, int NS, in
 XT_HD int xt_th_plan_lds_doubles(int S, int G, int capE, int D, int K)
 {
     // tables | per-track scalars | wave counts | compatibility bit matrix + grouped flags | bytes: mpk u32[capE], newest[2][capE],
-    // (spare 2 x capE), mem u16[capE], gst u16[capE + 1]
-    const int bytes = 4 * capE + 4 * capE + 2 * capE + 2 * (capE + 1);
-    return ((xt_tab_doubles(S, G) + 1) & ~1) + XT_TH_PILOT * (D + K) + 8 + XT_TH_CMAT_WORDS / 2 + (capE + 63) / 64 + 1 + (bytes + 7) / 8 + 2;
+    // mem u16[capE], gst u16[capE + 1]
+    (void)D;
+    (void)K;
+    const int bytes = 4 * capE + 2 * capE + 2 * capE + 2 * (capE + 1);
+    return ((xt_tab_doubles(S, G) + 1) & ~1) + XT_TH_PILOT + 8 + XT_TH_CMAT_WORDS / 2 + (capE + 63) / 64 + 1 + (bytes + 7) / 8 + 2;
 }
 XT_HD int xt_th_apply_lds_doubles(int S, int G, int capG, int TT, int D, int K, int KS, int L, int plan_cap, bool uni, bool single = false)
 {
@@ -391,16 +400,13 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
     const double* T64 = TAB + XT_NTAB * S * G;
     const double* TD2 = TAB + 4 * S * G;
     double* pm = smem + ((ntab + 1) & ~1);
-    double* ps = pm + XT_TH_PILOT * D;
-    int* wcnt = (int*)(ps + XT_TH_PILOT * K);
+    int* wcnt = (int*)(pm + XT_TH_PILOT);  // pm: per-track totals of the final sequence weights (prediction mode)
     uint32_t* cmatL = (uint32_t*)(wcnt + 16);
     uint32_t* gbitsL = cmatL + XT_TH_CMAT_WORDS;
     uint32_t* mpk = gbitsL + 2 * ((capE + 63) / 64) + 2;
     uint8_t* newA = (uint8_t*)(mpk + capE);
     uint8_t* newB = newA + capE;
-    uint8_t* grouped = newB + capE;
-    uint8_t* sel = grouped + capE;
-    uint16_t* mem = (uint16_t*)(sel + capE);
+    uint16_t* mem = (uint16_t*)(newB + capE);
     uint16_t* gst = mem + capE;
 
     // pilot-track state: LDS when the learned capacities fit (a.ws_lds), else this workgroup's slice of the global workspace
@@ -560,7 +566,7 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
                     }
                     auto Mv = [&](int d, int x, int g) -> double { return staged ? stM[(x * stP + g) * D + d] : bA.m(d, x * wsP + g); };
                     auto Sv = [&](int k, int x, int jj) -> double { return staged ? stS[(x * stE + jj) * K + k] : sE[k * plane + x * wsE + jj]; };
-                    if (P <= 4) {
+                    if (P <= a.pair_lanes_max_p) {
                         // few pilot tracks (predict_Bs with nb_max <= 4): one lane per (pivot, candidate) pair, pilots in a loop
                         const double cntn = (double)(P * K);
                         for (int b = cx.wave_in_block(); b < nE; b += cx.waves_per_block()) {

@@ -385,6 +385,7 @@ extern "C" int xt_emul_th_run(const double* tracks, const double* sigma, long lo
         a.ws_lds = 1;
     }
     a.pcap = chunk < XT_TH_PILOT ? chunk : XT_TH_PILOT;
+    a.pair_lanes_max_p = getenv("XT_EMUL_TH_PAIR_LANES") ? atoi(getenv("XT_EMUL_TH_PAIR_LANES")) : 4;
     a.ws_stride = xt_th_ws_doubles(a.wsP, a.wsE, D, K, F, NS, S, a.pcap);
     std::vector<double> ws((size_t)a.ws_stride * plan_blocks, 0.0);
     a.ws = ws.data();
@@ -486,6 +487,7 @@ extern "C" int xt_emul_th_predict(const double* tracks, const double* sigma, lon
     a.max_nb = max_nb;
     a.threshold = threshold;
     a.pcap = chunk;
+    a.pair_lanes_max_p = 4;
     a.wsP = a.wsE = capE;
     a.ws_lds = 0;
     std::vector<int32_t> status((size_t)a.nchunks * 4, 0);
@@ -541,6 +543,7 @@ extern "C" int xt_emul_th_run_multi(int nbuckets, const double** tracks, const l
     a.max_nb = max_nb;
     a.threshold = threshold;
     a.pcap = chunk < XT_TH_PILOT ? chunk : XT_TH_PILOT;
+    a.pair_lanes_max_p = 4;
     a.wsP = a.wsE = capE;
     a.nbuckets = nbuckets;
     std::vector<XtThBucket> desc(nbuckets);

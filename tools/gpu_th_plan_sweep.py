@@ -16,8 +16,9 @@ CASES = [("C2", 1_000_000, 30, [0.0, 0.25], [[.9, .1], [.1, .9]], [.6, .4], 6, 0
 for name, N, L, Ds, Tm, Fs, F, thr, mx in CASES:
     X = synth.brownian_tracks(N, L, Ds, Tm, Fs, seed=0)
     ds = np.sqrt(2 * np.maximum(np.array(Ds), 1e-3 * 0.25) * 0.02)
-    for pt in (256, 512, 1024):
+    for pt, pl in ((512, 4), (512, 30), (256, 30), (1024, 30)):
         os.environ["EXTRACK_TH_PLAN_THREADS"] = str(pt)
+        os.environ["EXTRACK_TH_PAIR_LANES"] = str(pl)
         ts = TrackSet([X])
         model = ts.make_model(np.array([[[0.02]]]), ds, np.array(Fs), np.array(Tm), 0.1, (1.0,), 1, F)
         for _ in range(2):
@@ -26,5 +27,5 @@ for name, N, L, Ds, Tm, Fs, F, thr, mx in CASES:
         for _ in range(3):
             tot = ts.loglik_th(model, thr, mx, 2000)
         wall = (time.perf_counter() - t0) / 3
-        print("%s plan_threads=%d: wall %.2f ms total %.4f" % (name, pt, wall * 1e3, tot), flush=True)
+        print("pair_lanes<=%d " % pl, end=""); print("%s plan_threads=%d: wall %.2f ms total %.4f" % (name, pt, wall * 1e3, tot), flush=True)
         ts.close()
