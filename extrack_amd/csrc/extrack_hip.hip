@@ -178,6 +178,7 @@ struct extrack_ctx {
     float th_plan_ms = 0.f;
     int th_force_single = 0;
     int th_pair_lanes = 4;  // EXTRACK_TH_PAIR_LANES
+    int th_no_gen_single = 0;  // EXTRACK_TH_NO_GEN_SINGLE: never use the one-buffer general apply variant
     int th_plan_threads = 512;  // workgroup size of the plan kernel (EXTRACK_TH_PLAN_THREADS)
     int th_force_tt = 0, th_force_threads = 0, th_oversub = 2;  // tuning knobs (EXTRACK_TH_TT / _THREADS / _OVERSUB)
     std::string err;
@@ -248,6 +249,7 @@ extern "C" int extrack_create(int device_id, extrack_ctx** out)
         int v = atoi(ev);
         if (v >= 64 && v <= 1024 && v % 64 == 0) c->th_plan_threads = v;
     }
+    if (const char* ev = getenv("EXTRACK_TH_NO_GEN_SINGLE")) c->th_no_gen_single = atoi(ev) != 0;
     if (const char* ev = getenv("EXTRACK_TH_PAIR_LANES")) c->th_pair_lanes = atoi(ev);
     if (const char* ev = getenv("EXTRACK_TH_SINGLE")) c->th_force_single = atoi(ev) != 0;
     if (const char* ev = getenv("EXTRACK_TH_OVERSUB")) {
@@ -758,10 +760,12 @@ static hipError_t xt_th_launch_apply_v(extrack_ctx* ctx, const XtThArgs& a, int 
     return hipGetLastError();
 }
 
-// mode 0: general (fewer than 64 tracks per tile), 1: wave-uniform, two state buffers, 2: wave-uniform, one state buffer
+// mode 0: general (fewer than 64 tracks per tile), 1: wave-uniform, two state buffers, 2: wave-uniform, one state buffer,
+// 3: general with one state buffer (more than 64 live sequences)
 template <int D, int K>
 static hipError_t xt_th_launch_apply(extrack_ctx* ctx, const XtThArgs& a, int grid, int threads, size_t lds, int mode, hipStream_t stream)
 {
+    if (mode == 3) return xt_th_launch_apply_v<D, K, false, true>(ctx, a, grid, threads, lds, stream);
     if (mode == 2) return xt_th_launch_apply_v<D, K, true, true>(ctx, a, grid, threads, lds, stream);
     if (mode == 1) return xt_th_launch_apply_v<D, K, true, false>(ctx, a, grid, threads, lds, stream);
     return xt_th_launch_apply_v<D, K, false, false>(ctx, a, grid, threads, lds, stream);
@@ -1008,13 +1012,25 @@ static int xt_th_run_group(extrack_ctx* ctx, const extrack_model* m, const std::
         if (chunk >= 48 && maxG <= 16 * XT_TH_GPW && lds_of(64, true) <= 160 * 1024) {
             single_buf = 1;
         } else {
-            TT = 32;
-            while (TT > 1 && (TT > chunk * 2 || lds_of(TT) > 48 * 1024)) TT >>= 1;
+            // more live sequences than the wave-uniform variants hold: the largest tile whose single state buffer fits the
+            // LDS and whose groups fit XT_TH_GPW per thread of a 1024-thread workgroup; else the two-buffer general variant
+            TT = 0;
+            if (chunk >= 48 && !ctx->th_no_gen_single)
+                for (int tt = 32; tt >= 8; tt >>= 1)
+                    if (lds_of(tt, true) <= 150 * 1024 && maxG <= (1024 / tt) * XT_TH_GPW) {
+                        TT = tt;
+                        single_buf = 1;
+                        break;
+                    }
+            if (!TT) {
+                TT = 32;
+                while (TT > 1 && (TT > chunk * 2 || lds_of(TT) > 48 * 1024)) TT >>= 1;
+            }
         }
     }
     if (TT == 64 && ctx->th_force_single && maxG <= 16 * XT_TH_GPW) single_buf = 1;
     while (TT > 1 && lds_of(TT, single_buf) > 160 * 1024) TT >>= 1;
-    if (TT != 64) single_buf = 0;
+    if (TT != 64 && single_buf && maxG > (1024 / TT) * XT_TH_GPW) single_buf = 0;
     const bool uni = TT == 64;
     const size_t lds = lds_of(TT, single_buf);
     if (lds > 160 * 1024) return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "live state sequences do not fit the 160 KiB LDS of a CU");
@@ -1025,7 +1041,9 @@ static int xt_th_run_group(extrack_ctx* ctx, const extrack_model* m, const std::
     threads = threads > 256 ? 256 : threads;
     threads = threads < TT ? TT : threads;
     if (uni) threads = 64 * std::max(4, std::min(16, maxG));  // one wavefront per live parent sequence of the 64-track tile
+    if (!uni && single_buf) threads = 1024;
     int force_threads = ctx->th_force_threads;
+    if (!uni && single_buf) force_threads = 0;
     if (uni && single_buf && force_threads > 0 && (force_threads / 64) * XT_TH_GPW < maxG) force_threads = 0;
     if (force_threads > 0 && force_threads % TT == 0) threads = force_threads;
     const int64_t tpc = (chunk + TT - 1) / TT;
@@ -1038,7 +1056,7 @@ static int xt_th_run_group(extrack_ctx* ctx, const extrack_model* m, const std::
     const int grid = (int)(a.nchunks * bpc);
     if ((rc = xt_grow_partials(ctx, poff + (size_t)grid))) return rc;
     a.partials = ctx->d_partials + poff;
-#define XT_TH_APPLY_CALL(...) xt_th_launch_apply<__VA_ARGS__>(ctx, a, grid, threads, lds, uni ? (single_buf ? 2 : 1) : 0, ctx->stream)
+#define XT_TH_APPLY_CALL(...) xt_th_launch_apply<__VA_ARGS__>(ctx, a, grid, threads, lds, uni ? (single_buf ? 2 : 1) : (single_buf ? 3 : 0), ctx->stream)
     if (D == 1 && K == 1) e = XT_TH_APPLY_CALL(1, 1);
     else if (D == 2 && K == 1) e = XT_TH_APPLY_CALL(2, 1);
     else if (D == 2 && K == 2) e = XT_TH_APPLY_CALL(2, 2);

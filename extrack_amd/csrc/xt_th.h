@@ -965,7 +965,7 @@ XT_HD void xt_th_apply_body(const XtThArgs& a, Ctx& cx)
     const int capEl = capG * G;
     View bA, bB;
     xt_th_carve(w, bA, plane, D, K);
-    if (UNI && SINGLE)
+    if (SINGLE)
         bB = bA;  // the tail then parks its per-parent terms in the records it has just consumed
     else
         xt_th_carve(w, bB, plane, D, K);
@@ -1131,6 +1131,46 @@ XT_HD void xt_th_apply_body(const XtThArgs& a, Ctx& cx)
                 View tb = cur;
                 cur = nxt;
                 nxt = tb;
+                nPar = nG;
+            }
+        } else if (SINGLE) {
+            // many live sequences (more than 64): one state buffer, TT < 64 tracks per tile so that it fits the LDS; a thread
+            // merges its (at most XT_TH_GPW) groups into registers, barrier, integrates the next position and overwrites the
+            // buffer.  With TT = 32 a wavefront spans only two groups, so the member loops of a wavefront rarely differ much.
+            for (int t = 1; t <= L - 2; ++t) {
+                if ((t & (XT_TH_STAGE - 1)) == 0) stage(t);
+                const int nE = pstep[t * 4 + 2], nG = pstep[t * 4 + 3];
+                const uint32_t* mem = pmem + pstep[t * 4];
+                const uint16_t* gst = pgst + pstep[t * 4 + 1];
+                if (!resident) {
+                    for (int i = tid; i < nE; i += nt) pmem[i] = mpk_g[(int64_t)t * capE + i];
+                    for (int i = tid; i <= nG; i += nt) pgst[i] = gst_g[(int64_t)t * (capE + 1) + i];
+                    cx.sync();
+                }
+                const bool stay = t >= 2 && t >= a.min_len;
+                const double* TTl = TABl + (stay ? 1 : 0) * S * G;
+                double c[D], l2[K];
+                for (int d = 0; d < D; ++d) c[d] = spos[((t & (XT_TH_STAGE - 1)) * D + d) * TP + x];
+                load_l2(t, l2);
+                double Wq[XT_TH_GPW], Mq[XT_TH_GPW][D], Uq[XT_TH_GPW][K];
+                int Eq[XT_TH_GPW];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+                for (int q = 0; q < XT_TH_GPW; ++q) {
+                    const int g2 = g0 + q * gstep;
+                    if (act && g2 < nG)
+                        xt_th_gather_regs<D, K>(cur, TT, x, mem, (int)gst[g2], (int)gst[g2 + 1], TTl, TABl + 4 * S * G, Wq[q], Eq[q], Mq[q], Uq[q]);
+                }
+                cx.sync();
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+                for (int q = 0; q < XT_TH_GPW; ++q) {
+                    const int g2 = g0 + q * gstep;
+                    if (act && g2 < nG) xt_th_integrate_store<D, K>(Wq[q], Eq[q], Mq[q], Uq[q], c, l2, T64, cur, g2 * TT + x);
+                }
+                cx.sync();
                 nPar = nG;
             }
         } else {

@@ -427,16 +427,18 @@ extern "C" int xt_emul_th_run(const double* tracks, const double* sigma, long lo
     std::vector<double> partials(grid, 0.0);
     a.partials = partials.data();
     const bool uni = TT == 64;
-    const bool single_buf = uni && getenv("XT_EMUL_TH_SINGLE") && (apply_threads / 64) * XT_TH_GPW >= maxG;
+    const bool single_buf = getenv("XT_EMUL_TH_SINGLE") && (uni ? (apply_threads / 64) : (apply_threads / TT)) * XT_TH_GPW >= maxG;
     const size_t apply_lds = xt_th_apply_lds_doubles(S, G, maxG, TT, D, K, a.KS, L, a.plan_cap, uni, single_buf);
 #define TH_APPLY_SGL(DD, KK) th_emul_blocks(grid, apply_threads, apply_lds, [&](HostCtx& cx) { xt_th_apply_body<DD, KK, true, true>(a, cx); })
 #define TH_APPLY_UNI(DD, KK) th_emul_blocks(grid, apply_threads, apply_lds, [&](HostCtx& cx) { xt_th_apply_body<DD, KK, true, false>(a, cx); })
 #define TH_APPLY_GEN(DD, KK) th_emul_blocks(grid, apply_threads, apply_lds, [&](HostCtx& cx) { xt_th_apply_body<DD, KK, false, false>(a, cx); })
-#define TH_APPLY(DD, KK)                     \
-    do {                                     \
-        if (single_buf) TH_APPLY_SGL(DD, KK); \
-        else if (uni) TH_APPLY_UNI(DD, KK);  \
-        else TH_APPLY_GEN(DD, KK);           \
+#define TH_APPLY_GSG(DD, KK) th_emul_blocks(grid, apply_threads, apply_lds, [&](HostCtx& cx) { xt_th_apply_body<DD, KK, false, true>(a, cx); })
+#define TH_APPLY(DD, KK)                            \
+    do {                                            \
+        if (single_buf && uni) TH_APPLY_SGL(DD, KK); \
+        else if (single_buf) TH_APPLY_GSG(DD, KK);  \
+        else if (uni) TH_APPLY_UNI(DD, KK);         \
+        else TH_APPLY_GEN(DD, KK);                  \
     } while (0)
     if (D == 1 && K == 1) TH_APPLY(1, 1);
     else if (D == 2 && K == 1) TH_APPLY(2, 1);

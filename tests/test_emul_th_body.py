@@ -45,7 +45,7 @@ def test_th_bodies_on_golden_subset():
     assert len(rows) >= 20 and worst < 1e-10, (len(rows), worst)
 
 
-@pytest.mark.parametrize("variant", ["general", "streamed", "uniform", "uniform_single", "lds_workspace"])
+@pytest.mark.parametrize("variant", ["general", "streamed", "uniform", "uniform_single", "general_single", "general_single_streamed", "lds_workspace"])
 def test_th_apply_variants_chunked(variant, monkeypatch):
     """Two chunks (the second ragged), 3 states, per-peak errors: every apply-kernel variant and the LDS-resident plan workspace."""
     E = _emul()
@@ -67,6 +67,9 @@ def test_th_apply_variants_chunked(variant, monkeypatch):
         kw.update(TT=64, threads=256)
     elif variant == "uniform_single":
         kw.update(TT=64, threads=256)
+        monkeypatch.setenv("XT_EMUL_TH_SINGLE", "1")
+    elif variant in ("general_single", "general_single_streamed"):
+        kw.update(TT=8, threads=128, nblocks=-2 if variant.endswith("streamed") else 2)
         monkeypatch.setenv("XT_EMUL_TH_SINGLE", "1")
     elif variant == "lds_workspace":
         monkeypatch.setenv("XT_EMUL_TH_WSP", "24")
