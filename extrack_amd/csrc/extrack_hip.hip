@@ -1001,7 +1001,7 @@ static int xt_th_run_group(extrack_ctx* ctx, const extrack_model* m, const std::
     a.capG = maxG;
     a.plan_cap = (size_t)sumE * 6 + 2 * (size_t)Lmax <= 24 * 1024 ? std::max(sumE, 1) : 0;
     auto lds_of = [&](int tt, bool single = false) {
-        return (size_t)xt_th_apply_lds_doubles(S, G, maxG, tt, D, K, a.KS, Lmax, a.plan_cap, tt == 64, single) * 8;
+        return (size_t)xt_th_apply_lds_doubles(S, G, maxG, tt, D, K, a.locerr_mode ? a.KS : 0, Lmax, a.plan_cap, tt == 64, single) * 8;
     };
     // 64 tracks per tile (wave-uniform scalar path): two state buffers when two such workgroups fit a CU's LDS, one buffer
     // (merged sequences wait in registers) while at most XT_TH_GPW groups fall to a wavefront; else fewer tracks

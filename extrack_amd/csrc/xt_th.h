@@ -972,7 +972,7 @@ XT_HD void xt_th_apply_body(const XtThArgs& a, Ctx& cx)
     double* spos = w;
     w += XT_TH_STAGE * D * TP;
     double* ssig = w;
-    w += XT_TH_STAGE * KS * TP;
+    w += XT_TH_STAGE * (a.locerr_mode ? KS : 0) * TP;  // no sigma stage with a global localisation error
     double* red = w;
     w += TT;
     const bool resident = !UNI && a.plan_cap > 0;

@@ -428,7 +428,7 @@ extern "C" int xt_emul_th_run(const double* tracks, const double* sigma, long lo
     a.partials = partials.data();
     const bool uni = TT == 64;
     const bool single_buf = getenv("XT_EMUL_TH_SINGLE") && (uni ? (apply_threads / 64) : (apply_threads / TT)) * XT_TH_GPW >= maxG;
-    const size_t apply_lds = xt_th_apply_lds_doubles(S, G, maxG, TT, D, K, a.KS, L, a.plan_cap, uni, single_buf);
+    const size_t apply_lds = xt_th_apply_lds_doubles(S, G, maxG, TT, D, K, a.locerr_mode ? a.KS : 0, L, a.plan_cap, uni, single_buf);
 #define TH_APPLY_SGL(DD, KK) th_emul_blocks(grid, apply_threads, apply_lds, [&](HostCtx& cx) { xt_th_apply_body<DD, KK, true, true>(a, cx); })
 #define TH_APPLY_UNI(DD, KK) th_emul_blocks(grid, apply_threads, apply_lds, [&](HostCtx& cx) { xt_th_apply_body<DD, KK, true, false>(a, cx); })
 #define TH_APPLY_GEN(DD, KK) th_emul_blocks(grid, apply_threads, apply_lds, [&](HostCtx& cx) { xt_th_apply_body<DD, KK, false, false>(a, cx); })
@@ -600,7 +600,7 @@ extern "C" int xt_emul_th_run_multi(int nbuckets, const double** tracks, const l
     std::vector<double> partials(grid, 0.0);
     a.partials = partials.data();
     const bool uni = TT == 64;
-    const size_t lds = xt_th_apply_lds_doubles(S, G, maxG, TT, D, K, a.KS, Lmax, a.plan_cap, uni, false);
+    const size_t lds = xt_th_apply_lds_doubles(S, G, maxG, TT, D, K, 0, Lmax, a.plan_cap, uni, false);
     if (D == 2 && K == 1) {
         if (uni) th_emul_blocks(grid, threads, lds, [&](HostCtx& cx) { xt_th_apply_body<2, 1, true, false>(a, cx); });
         else th_emul_blocks(grid, threads, lds, [&](HostCtx& cx) { xt_th_apply_body<2, 1, false, false>(a, cx); });
