@@ -566,9 +566,13 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
                     }
                     auto Mv = [&](int d, int x, int g) -> double { return staged ? stM[(x * stP + g) * D + d] : bA.m(d, x * wsP + g); };
                     auto Sv = [&](int k, int x, int jj) -> double { return staged ? stS[(x * stE + jj) * K + k] : sE[k * plane + x * wsE + jj]; };
+                    // np.mean(flags) > 0.8 over the P*K flags <=> count >= cmin, with cmin found with the very same double
+                    // arithmetic (count / (P*K) > 0.8) once per step instead of two divisions per pair
+                    int cmin = P * K + 1;
+                    for (int cnt = P * K; cnt >= 0; --cnt)
+                        if ((double)cnt / (double)(P * K) > 0.8) cmin = cnt;
                     if (P <= a.pair_lanes_max_p) {
                         // few pilot tracks (predict_Bs with nb_max <= 4): one lane per (pivot, candidate) pair, pilots in a loop
-                        const double cntn = (double)(P * K);
                         for (int b = cx.wave_in_block(); b < nE; b += cx.waves_per_block()) {
                             const int gb = b / G, rb = b - gb * G;
                             for (int jj = b + S * (1 + cx.lane()); jj < nE; jj += 64 * S) {
@@ -593,7 +597,7 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
                                             cs += xt_div_lt(dsd, sj[k], thr) ? 1 : 0;
                                         }
                                     }
-                                    flag = ((double)cm / cntn > 0.8) && ((double)cs / cntn > 0.8);
+                                    flag = cm >= cmin && cs >= cmin;
                                 }
                                 const int ci = (jj - b) / S - 1;
                                 if (flag) cx.atomic_or_u32(&cmat[b * NWD + (ci >> 5)], 1u << (ci & 31));
@@ -602,18 +606,21 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
                     } else {
                         const int lane = cx.lane(), half = lane >> 5, x = lane & 31;
                         const unsigned long long hmask = half ? 0xffffffff00000000ull : 0x00000000ffffffffull;
-                        const double cntn = (double)(P * K);
                         const bool xl = x < P;
+                        const int dg = (2 * S) / G, dr = (2 * S) - dg * G;  // (parent, new digits) advance of a candidate per iteration
                         for (int b = cx.wave_in_block(); b < nE; b += cx.waves_per_block()) {
                             const int gb = b / G, rb = b - gb * G;
                             double pmv[D], psv[K];
                             for (int d = 0; d < D; ++d) pmv[d] = xl ? Mv(d, x, gb) : 0.0;
                             for (int k = 0; k < K; ++k) psv[k] = xl ? Sv(k, x, b) : 1.0;
-                            for (int j0 = b + S; j0 < nE; j0 += 2 * S) {
+                            int gj = (b + S + half * S) / G, rj = (b + S + half * S) - gj * G, ci = half;
+                            for (int j0 = b + S; j0 < nE; j0 += 2 * S, gj += dg, rj += dr, ci += 2) {
+                                if (rj >= G) {
+                                    rj -= G;
+                                    ++gj;
+                                }
                                 const int jj = j0 + half * S;
                                 const bool valid = jj < nE;
-                                const int gj = valid ? jj / G : 0;
-                                const int rj = jj - gj * G;
                                 bool same_hist = valid && useA && rj == rb;
                                 if (same_hist)  // predicting: on every pilot track (mean > 0.999, tracking.py:686)
                                     for (int xx = 0; xx < (PREDS ? P : 1); ++xx) same_hist = same_hist && kyA[xx * wsP + gj] == kyA[xx * wsP + gb];
@@ -636,8 +643,7 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
                                     cm += xt_popc64(bm & hmask);
                                     cs += xt_popc64(bs & hmask);
                                 }
-                                const bool flag = valid && (same_hist || (((double)cm / cntn > 0.8) && ((double)cs / cntn > 0.8)));
-                                const int ci = (jj - b) / S - 1;
+                                const bool flag = valid && (same_hist || (cm >= cmin && cs >= cmin));
                                 if (x == 0 && flag) cx.atomic_or_u32(&cmat[b * NWD + (ci >> 5)], 1u << (ci & 31));
                             }
                         }
