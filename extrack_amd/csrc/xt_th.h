@@ -112,6 +112,17 @@ struct XtCPtr<true, T> {
 
 XT_HD int xt_popc64(unsigned long long v) { return __builtin_popcountll(v); }
 
+// New-state entry the reference writes into a sequence's state HISTORY when sequence q (index at that expansion level) is
+// created: it takes the index from np.arange(n, dtype='int8') (tracking.py:542), i.e. wrapped to [-128, 127], modulo S.
+// Equal to q % S whenever S is a power of two or q < 128 - otherwise it differs from the sequence's actual new state, and
+// since the history decides the merge classes (and is what predict_Bs returns) the wrap is reproduced.
+XT_HD int xt_th_cat_digit(int q, int S)
+{
+    const int w = (int)(int8_t)(q & 0xff);
+    const int d = w % S;
+    return d < 0 ? d + S : d;
+}
+
 // Resolves a global chunk index to its bucket (by value) and the chunk index inside that bucket.
 XT_HD XtThBucket xt_th_bind(const XtThArgs& a, int gch, int& lc)
 {
@@ -194,7 +205,7 @@ struct XtThView {
 
 XT_HD int xt_th_hm(int F, int NS) { return F + NS; }
 XT_HD int64_t xt_th_buf_doubles(int plane, int D, int K) { return (int64_t)plane * (2 + D + K); }
-XT_HD int64_t xt_th_cmat_doubles(int wsE) { return ((int64_t)wsE * ((wsE / 2 + 32) / 32) + 1) / 2 + 1; }
+XT_HD int64_t xt_th_cmat_doubles(int wsE) { return ((int64_t)wsE * ((wsE + 32) / 32 + 1) + 1) / 2 + 1; }
 // Workspace of one workgroup of the plan kernel.  State part (LDS or global): pilot sequences, stds, histories, keys,
 // bit matrix (+ prediction mode: member / final weights, sequence masses).  History part (prediction mode, always global):
 // what the backward pass reads - members, group starts and counts of every merge step, the members' weights per track.
@@ -538,9 +549,14 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
                     // (2) the greedy scan itself (lowest ungrouped index opens a group and takes every compatible,
                     //     still ungrouped candidate) is then pure bit arithmetic, done serially by one thread.
                     const bool useA = He > F;
-                    // row b of the matrix: bit c <-> candidate b + S (c + 1); in LDS when it fits the reserved words (the serial
+                    // row b of the matrix: bit c <-> candidate b + cstep (c + 1); in LDS when it fits the reserved words (the serial
                     // scan below is latency bound), else in the workspace
-                    const int NWD = (nE / S + 32) >> 5;
+                    // candidates of pivot b = later sequences of the same history class (newest history entry).  Normally that is
+                    // b + S, b + 2S, ...; with the reference's int8 wrap (see xt_th_cat_digit) the classes are irregular beyond 127
+                    // sequences when S is not a power of two: then every later sequence is a candidate and the class is tested.
+                    const bool wrapS = (S & (S - 1)) != 0 && nE > 128;
+                    const int cstep = wrapS ? 1 : S;
+                    const int NWD = (nE / cstep + 32) >> 5;
                     const bool cml = nE * NWD <= XT_TH_CMAT_WORDS;
                     uint32_t* cmat = cml ? cmatL : cmatG;
                     uint32_t* gbits = cml ? gbitsL : gbitsG;
@@ -566,6 +582,14 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
                     }
                     auto Mv = [&](int d, int x, int g) -> double { return staged ? stM[(x * stP + g) * D + d] : bA.m(d, x * wsP + g); };
                     auto Sv = [&](int k, int x, int jj) -> double { return staged ? stS[(x * stE + jj) * K + k] : sE[k * plane + x * wsE + jj]; };
+                    // same history class / same new-state history entries of two expanded sequences
+                    auto same_class = [&](int jj, int bb) -> bool { return !wrapS || xt_th_cat_digit(jj, S) == xt_th_cat_digit(bb, S); };
+                    auto same_digits = [&](int jj, int bb, int rj, int rb) -> bool {
+                        if (!wrapS) return rj == rb;
+                        bool eq = true;
+                        for (int c = 0; c < NS; ++c) eq = eq && xt_th_cat_digit(jj / pwS[c], S) == xt_th_cat_digit(bb / pwS[c], S);
+                        return eq;
+                    };
                     // np.mean(flags) > 0.8 over the P*K flags <=> count >= cmin, with cmin found with the very same double
                     // arithmetic (count / (P*K) > 0.8) once per step instead of two divisions per pair
                     int cmin = P * K + 1;
@@ -575,9 +599,10 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
                         // few pilot tracks (predict_Bs with nb_max <= 4): one lane per (pivot, candidate) pair, pilots in a loop
                         for (int b = cx.wave_in_block(); b < nE; b += cx.waves_per_block()) {
                             const int gb = b / G, rb = b - gb * G;
-                            for (int jj = b + S * (1 + cx.lane()); jj < nE; jj += 64 * S) {
+                            for (int jj = b + cstep * (1 + cx.lane()); jj < nE; jj += 64 * cstep) {
+                                if (!same_class(jj, b)) continue;
                                 const int gj = jj / G, rj = jj - gj * G;
-                                bool same_hist = useA && rj == rb;
+                                bool same_hist = useA && same_digits(jj, b, rj, rb);
                                 if (same_hist)
                                     for (int xx = 0; xx < (PREDS ? P : 1); ++xx) same_hist = same_hist && kyA[xx * wsP + gj] == kyA[xx * wsP + gb];
                                 bool flag = same_hist;
@@ -599,7 +624,7 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
                                     }
                                     flag = cm >= cmin && cs >= cmin;
                                 }
-                                const int ci = (jj - b) / S - 1;
+                                const int ci = (jj - b) / cstep - 1;
                                 if (flag) cx.atomic_or_u32(&cmat[b * NWD + (ci >> 5)], 1u << (ci & 31));
                             }
                         }
@@ -607,21 +632,21 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
                         const int lane = cx.lane(), half = lane >> 5, x = lane & 31;
                         const unsigned long long hmask = half ? 0xffffffff00000000ull : 0x00000000ffffffffull;
                         const bool xl = x < P;
-                        const int dg = (2 * S) / G, dr = (2 * S) - dg * G;  // (parent, new digits) advance of a candidate per iteration
+                        const int dg = (2 * cstep) / G, dr = (2 * cstep) - dg * G;  // (parent, new digits) advance of a candidate per iteration
                         for (int b = cx.wave_in_block(); b < nE; b += cx.waves_per_block()) {
                             const int gb = b / G, rb = b - gb * G;
                             double pmv[D], psv[K];
                             for (int d = 0; d < D; ++d) pmv[d] = xl ? Mv(d, x, gb) : 0.0;
                             for (int k = 0; k < K; ++k) psv[k] = xl ? Sv(k, x, b) : 1.0;
-                            int gj = (b + S + half * S) / G, rj = (b + S + half * S) - gj * G, ci = half;
-                            for (int j0 = b + S; j0 < nE; j0 += 2 * S, gj += dg, rj += dr, ci += 2) {
+                            int gj = (b + cstep + half * cstep) / G, rj = (b + cstep + half * cstep) - gj * G, ci = half;
+                            for (int j0 = b + cstep; j0 < nE; j0 += 2 * cstep, gj += dg, rj += dr, ci += 2) {
                                 if (rj >= G) {
                                     rj -= G;
                                     ++gj;
                                 }
-                                const int jj = j0 + half * S;
-                                const bool valid = jj < nE;
-                                bool same_hist = valid && useA && rj == rb;
+                                const int jj = j0 + half * cstep;
+                                const bool valid = jj < nE && same_class(jj, b);
+                                bool same_hist = valid && useA && same_digits(jj, b, rj, rb);
                                 if (same_hist)  // predicting: on every pilot track (mean > 0.999, tracking.py:686)
                                     for (int xx = 0; xx < (PREDS ? P : 1); ++xx) same_hist = same_hist && kyA[xx * wsP + gj] == kyA[xx * wsP + gb];
                                 const bool live = valid && xl && !same_hist;
@@ -657,11 +682,11 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
                             gst[ng++] = (uint16_t)mpos;
                             mem[mpos++] = (uint16_t)b;  // the pivot itself
                             gbits[b >> 5] |= 1u << (b & 31);
-                            const int nc = (nE - 1 - b) / S;  // candidates b + S, ..., b + nc S
+                            const int nc = (nE - 1 - b) / cstep;  // candidates b + cstep, ..., b + nc cstep
                             for (int wd = 0; wd < ((nc + 31) >> 5); ++wd) {
                                 uint32_t bits = cmat[b * NWD + wd];
                                 while (bits) {
-                                    const int jj = b + S * ((wd << 5) + __builtin_ctz(bits) + 1);
+                                    const int jj = b + cstep * ((wd << 5) + __builtin_ctz(bits) + 1);
                                     bits &= bits - 1;
                                     if (!((gbits[jj >> 5] >> (jj & 31)) & 1u)) {
                                         gbits[jj >> 5] |= 1u << (jj & 31);
@@ -726,7 +751,8 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
                     }
                     for (int i = tid; i < nE; i += nt) {
                         const int jj = mem[i], g = jj / G;
-                        hmem[(int64_t)t * wsE + i] = ((uint32_t)g << 16) | (uint32_t)(jj - g * G);
+                        // history entry, not the state (the initial sequences, t == 1, come without the int8 index)
+                        hmem[(int64_t)t * wsE + i] = ((uint32_t)g << 16) | (uint32_t)(t == 1 ? jj % S : xt_th_cat_digit(jj, S));
                     }
                     for (int i = tid; i <= nG; i += nt) hgst[(int64_t)t * (wsE + 1) + i] = gst[i];
                     if (tid == 0) {
@@ -740,7 +766,7 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
                         const int k0 = gst[g2], k1 = gst[g2 + 1];
                         auto val = [&](int jj) -> double {
                             const int g = jj / G, r = jj - g * G;
-                            if (h < NS) return ((r / pwS[h]) % S == s2) ? 1.0 : 0.0;
+                            if (h < NS) return ((t == 1 ? (jj / pwS[h]) % S : xt_th_cat_digit(jj / pwS[h], S)) == s2) ? 1.0 : 0.0;
                             return ctA[x * cstride + (g * HM + (h - NS)) * S + s2];
                         };
                         double o;
@@ -758,7 +784,7 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
                     const int k0 = gst[g2], k1 = gst[g2 + 1];
                     auto val = [&](int j) -> double {
                         const int g = j / G, r = j - g * G;
-                        if (h < NS) return ((r / pwS[h]) % S == s) ? 1.0 : 0.0;
+                        if (h < NS) return ((t == 1 ? (j / pwS[h]) % S : xt_th_cat_digit(j / pwS[h], S)) == s) ? 1.0 : 0.0;
                         return ctA[(g * HM + (h - NS)) * S + s];
                     };
                     double o;
@@ -894,9 +920,9 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
                 const double rt = 1.0 / pm[x];
                 for (int g = 0; g < nPar; ++g) bc[g] = 0.0;
                 for (int jj = 0; jj < nE; ++jj) {
-                    const int g = jj / G, r = jj - g * G;
+                    const int g = jj / G;
                     const double om = wgt[x * wsE + jj] * rt;
-                    post[(int64_t)(L - 1) * S + r] += om;
+                    post[(int64_t)(L - 1) * S + (L == 2 ? jj % S : xt_th_cat_digit(jj, S))] += om;
                     bc[g] += om;
                 }
                 for (int t = L - 2; t >= 1; --t) {

@@ -118,3 +118,20 @@ def test_th_multi_bucket_launch(TT, threads):
         ref = np.concatenate([OT.proba_cs_th(b[a:a + chunk], LE, ds, Fs, T, 0.07, isBL, [0.8], ns, F, 3, 0.2, 30) for a in range(0, len(b), chunk)])
         assert np.abs(o - ref).max() < 1e-10
     assert abs(tot - sum(o.sum() for o in outs)) < 1e-9
+
+
+def test_th_bodies_on_extra_golden_subset():
+    """A few small cases of the second reference fixture (1-D / 3-D, per-dimension errors, nb_substeps 3, 5 states)."""
+    E = _emul()
+    meta = json.load(open(os.path.join(GOLDEN, "th_kernel_cases_extra.json")))
+    data = np.load(os.path.join(GOLDEN, "th_kernel_cases_extra.npz"))
+    rows = [r for r in meta if r["N"] <= 7 and r["L"] <= 7 and r["nB"] <= 60]
+    worst = 0.0
+    for row in rows:
+        pre = "x%04d_" % row["id"]
+        Cs, LE, ds, Fs, T = [data[pre + k] for k in ("Cs", "LE", "ds", "Fs", "T")]
+        ps = p_stay_table(ds, len(ds), row["ns"], row["cell_dims"])
+        ll, tot, plan, hdr, status = E.run_th(Cs, LE, ds, Fs, T, row["pBL"], row["isBL"], ps, row["ns"], row["F"], row["min_len"],
+                                              row["threshold"], row["max_nb_states"], chunk=len(Cs), capE=1024, TT=8, threads=64, nblocks=2)
+        worst = max(worst, np.abs(ll - data[pre + "LPC"]).max())
+    assert len(rows) >= 6 and worst < 1e-10, (len(rows), worst)
