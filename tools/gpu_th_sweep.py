@@ -13,7 +13,7 @@ N, L = 1_000_000, 30
 Ds, Tm, Fs = [0.0, 0.25], [[.9, .1], [.1, .9]], [.6, .4]
 X = synth.brownian_tracks(N, L, Ds, Tm, Fs, seed=0)
 ds = np.sqrt(2 * np.maximum(np.array(Ds), 1e-3 * 0.25) * 0.02)
-for tt, thr, ov, sg in [(0, 0, 2, 0), (64, 768, 2, 0), (64, 256, 2, 1), (64, 192, 2, 1), (64, 384, 2, 1), (64, 512, 2, 1), (64, 256, 4, 1), (64, 256, 1, 1)]:
+for tt, thr, ov, sg in [(0, 0, 2, 0), (64, 768, 2, 1), (64, 512, 2, 1), (64, 1024, 2, 1), (64, 256, 2, 1), (64, 768, 4, 1), (64, 768, 2, 0), (64, 768, 4, 0), (64, 768, 8, 0)]:
     for k, v in (("EXTRACK_TH_TT", tt), ("EXTRACK_TH_THREADS", thr), ("EXTRACK_TH_OVERSUB", ov), ("EXTRACK_TH_SINGLE", sg)):
         if v:
             os.environ[k] = str(v)
