@@ -178,6 +178,7 @@ struct extrack_ctx {
     float th_plan_ms = 0.f;
     int th_force_single = 0;
     int th_pair_lanes = 4;  // EXTRACK_TH_PAIR_LANES
+    int th_stage_in_lds_mode = 0;  // EXTRACK_TH_STAGE_LDS: LDS-typed copy of the pilot means/stds also when the state is in LDS (measured: no gain)
     int th_no_gen_single = 0;  // EXTRACK_TH_NO_GEN_SINGLE: never use the one-buffer general apply variant
     int th_plan_threads = 512;  // workgroup size of the plan kernel (EXTRACK_TH_PLAN_THREADS)
     int th_force_tt = 0, th_force_threads = 0, th_oversub = 2;  // tuning knobs (EXTRACK_TH_TT / _THREADS / _OVERSUB)
@@ -249,6 +250,7 @@ extern "C" int extrack_create(int device_id, extrack_ctx** out)
         int v = atoi(ev);
         if (v >= 64 && v <= 1024 && v % 64 == 0) c->th_plan_threads = v;
     }
+    if (const char* ev = getenv("EXTRACK_TH_STAGE_LDS")) c->th_stage_in_lds_mode = atoi(ev) != 0;
     if (const char* ev = getenv("EXTRACK_TH_NO_GEN_SINGLE")) c->th_no_gen_single = atoi(ev) != 0;
     if (const char* ev = getenv("EXTRACK_TH_PAIR_LANES")) c->th_pair_lanes = atoi(ev);
     if (const char* ev = getenv("EXTRACK_TH_SINGLE")) c->th_force_single = atoi(ev) != 0;
@@ -938,6 +940,14 @@ static int xt_th_run_group(extrack_ctx* ctx, const extrack_model* m, const std::
         }
         a.ws_lds = lds_mode ? 1 : 0;
         a.stP = a.stE = 0;
+        if (lds_mode && ctx->th_stage_in_lds_mode) {
+            const size_t st = (size_t)a.pcap * ((size_t)a.wsP * D + (size_t)a.wsE * K) * sizeof(double);
+            if (lds + st <= 80 * 1024) {
+                a.stP = a.wsP;
+                a.stE = a.wsE;
+                lds += st;
+            }
+        }
         if (!lds_mode && ctx->th_learnE > 0 && !force_global) {
             // LDS copy of what the grouping reads (pilot means, stds), sized by the previous evaluation's sequence counts
             const int sp = std::min(capE, ctx->th_learnP), se = std::min(capE, ctx->th_learnE);

@@ -33,6 +33,30 @@
 #include "xt_kernel.h"
 
 #define XT_TH_PILOT 30  // tracking.py:678-679
+// Phase timers of the plan kernel (development aid: build with -DXT_TH_PROFILE, workgroup 0 prints its cycle counts per phase)
+#if defined(XT_TH_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+#define XT_TH_TICK(i)                                   \
+    do {                                                \
+        const long long now__ = wall_clock64();         \
+        prof__[i] += now__ - last__;                    \
+        last__ = now__;                                 \
+    } while (0)
+#define XT_TH_PROF_DECL long long prof__[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last__ = wall_clock64()
+#define XT_TH_PROF_DUMP(tag)                                                                                                    \
+    if (cx.block() == 0 && tid == 0)                                                                                            \
+    printf("th plan phases (100 MHz ticks) %s: integrate %lld  stds+stage %lld  pairs %lld  greedy %lld  members %lld  merge %lld  keys %lld  other %lld\n", \
+           tag, prof__[0], prof__[1], prof__[2], prof__[3], prof__[4], prof__[5], prof__[6], prof__[7])
+#else
+#define XT_TH_TICK(i) \
+    do {              \
+    } while (0)
+#define XT_TH_PROF_DECL \
+    do {                \
+    } while (0)
+#define XT_TH_PROF_DUMP(tag) \
+    do {                     \
+    } while (0)
+#endif
 #define XT_TH_STAGE 8   // positions staged in LDS per refill (apply kernel)
 #define XT_TH_MAXCAP 8192
 #define XT_TH_CMAT_WORDS 2048  // LDS budget (32-bit words) of the pivot -> candidate compatibility bit matrix
@@ -422,8 +446,11 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
 
     // pilot-track state: LDS when the learned capacities fit (a.ws_lds), else this workgroup's slice of the global workspace
     // (then the grouping works on an LDS copy of the two arrays it reads over and over: pilots' means and stds)
-    const int wsP = a.wsP, wsE = a.wsE, stP = a.ws_lds ? 0 : a.stP, stE = a.ws_lds ? 0 : a.stE;
-    double* stM = smem + xt_th_plan_lds_doubles(S, G, capE, D, K);  // [PC][stP][D]
+    const int wsP = a.wsP, wsE = a.wsE, stP = a.stP, stE = a.stE;
+    // staging copy: after the LDS-resident state when that is in LDS too (then it only serves to give the compiler LDS-typed
+    // addresses instead of flat ones for the hot pair loop)
+    double* stM = smem + xt_th_plan_lds_doubles(S, G, capE, D, K) +
+                  (a.ws_lds ? xt_th_ws_doubles(wsP, wsE, D, K, F, NS, S, a.pcap, PREDS) : 0);  // [PC][stP][D]
     double* stS = stM + (int64_t)a.pcap * stP * D;                  // [PC][stE][K]
     double* wh = a.ws + (int64_t)cx.block() * a.ws_stride;  // history part (prediction mode), then the state part unless it is in LDS
     double* w = a.ws_lds ? smem + xt_th_plan_lds_doubles(S, G, capE, D, K) : wh + xt_th_hist_doubles(wsE, a.pcap, PREDS, L);
@@ -505,6 +532,7 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
         }
         for (int i = tid; i < S; i += nt) newA[i] = (uint8_t)i;
         int nPar = S, Hc = 1, maxE = 0, maxG = S, overflow = 0, nfuse = 0, sumE = 0;
+        XT_TH_PROF_DECL;
         double thr = a.threshold;
         uint8_t *nwA = newA, *nwB = newB;
         double *ctA = catA, *ctB = catB;
@@ -523,6 +551,7 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
                     xt_th_integrate<D, K>(bA, x * wsP + g, c, l2, T64);
                 }
                 cx.sync();
+                XT_TH_TICK(0);
             }
             const int nE = nPar * G;
             if (nE > capE || nE > wsE) {
@@ -580,6 +609,7 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
                         }
                         cx.sync();
                     }
+                    XT_TH_TICK(1);
                     auto Mv = [&](int d, int x, int g) -> double { return staged ? stM[(x * stP + g) * D + d] : bA.m(d, x * wsP + g); };
                     auto Sv = [&](int k, int x, int jj) -> double { return staged ? stS[(x * stE + jj) * K + k] : sE[k * plane + x * wsE + jj]; };
                     // same history class / same new-state history entries of two expanded sequences
@@ -674,6 +704,7 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
                         }
                     }
                     cx.sync();
+                    XT_TH_TICK(2);
                     if (tid == 0) {
                         int mpos = 0, ng = 0;
                         for (int wd = 0; wd < ((nE + 31) >> 5); ++wd) gbits[wd] = 0u;
@@ -700,6 +731,7 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
                     }
                     cx.sync();
                     nG = wcnt[0];
+                    XT_TH_TICK(3);
                 }
                 cx.sync();
                 if (nG > wsP) {
@@ -714,6 +746,7 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
                 }
                 sumE += nE;
                 cx.sync();
+                XT_TH_TICK(4);
                 // ---- merge: pilots' states, the shared state history, newest state of each group; publish the plan
                 const bool stay = t >= 2 && t >= a.min_len;
                 const double* TTl = TAB + (stay ? 1 : 0) * S * G;
@@ -814,6 +847,7 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
                     for (int i = tid; i <= nG; i += nt) gst_g[(int64_t)t * (capE + 1) + i] = gst[i];
                 }
                 cx.sync();
+                XT_TH_TICK(5);
                 // history keys of the new parents: argmax over states of the first Fk entries
                 for (int i = tid; i < (PREDS ? P : 1) * nG; i += nt) {
                     const int x = i / nG, g2 = i - x * nG;
@@ -852,6 +886,7 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
                 Hc = Hn;
                 maxG = nG > maxG ? nG : maxG;
                 cx.sync();
+                XT_TH_TICK(6);
             }
             if (tid == 0 && !PREDS) {
                 hdr_g[t * 2] = nE;
@@ -946,6 +981,7 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
             }
             cx.sync();
         }
+        XT_TH_PROF_DUMP(PREDS ? "posteriors" : "fit");
         if (tid == 0) {
             bk.status[ch * 4 + 0] = overflow;
             bk.status[ch * 4 + 1] = maxE;

@@ -389,12 +389,12 @@ extern "C" int xt_emul_th_run(const double* tracks, const double* sigma, long lo
     a.ws_stride = xt_th_ws_doubles(a.wsP, a.wsE, D, K, F, NS, S, a.pcap);
     std::vector<double> ws((size_t)a.ws_stride * plan_blocks, 0.0);
     a.ws = ws.data();
-    if (getenv("XT_EMUL_TH_STP") && !a.ws_lds) {  // exercise the LDS staging copy used with the global workspace
+    if (getenv("XT_EMUL_TH_STP")) {  // exercise the LDS staging copy used with the global workspace
         a.stP = atoi(getenv("XT_EMUL_TH_STP"));
         a.stE = atoi(getenv("XT_EMUL_TH_STE"));
     }
     const size_t plan_lds = xt_th_plan_lds_doubles(S, G, capE, D, K) +
-                            (a.ws_lds ? (size_t)a.ws_stride : (size_t)a.pcap * (a.stP * D + a.stE * K) + 8);
+                            (a.ws_lds ? (size_t)a.ws_stride : 0) + (size_t)a.pcap * (a.stP * D + a.stE * K) + 8;
     const int plan_threads = apply_threads;  // same block size for both kernels in the emulation
 #define TH_RUN(BODY, NB, NT, LDS)                                                                             \
     do {                                                                                                      \
