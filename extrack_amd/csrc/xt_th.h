@@ -625,9 +625,13 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
                     int cmin = P * K + 1;
                     for (int cnt = P * K; cnt >= 0; --cnt)
                         if ((double)cnt / (double)(P * K) > 0.8) cmin = cnt;
+                    // Rows are computed in batches of one pivot candidate per wavefront, the greedy scan advancing batch by batch:
+                    // a sequence that an earlier batch has already put into a group never becomes a pivot, so its row - more than
+                    // half of all rows - is never computed.
+                    auto compute_row = [&](const int b) {
                     if (P <= a.pair_lanes_max_p) {
                         // few pilot tracks (predict_Bs with nb_max <= 4): one lane per (pivot, candidate) pair, pilots in a loop
-                        for (int b = cx.wave_in_block(); b < nE; b += cx.waves_per_block()) {
+                        {
                             const int gb = b / G, rb = b - gb * G;
                             for (int jj = b + cstep * (1 + cx.lane()); jj < nE; jj += 64 * cstep) {
                                 if (!same_class(jj, b)) continue;
@@ -663,7 +667,7 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
                         const unsigned long long hmask = half ? 0xffffffff00000000ull : 0x00000000ffffffffull;
                         const bool xl = x < P;
                         const int dg = (2 * cstep) / G, dr = (2 * cstep) - dg * G;  // (parent, new digits) advance of a candidate per iteration
-                        for (int b = cx.wave_in_block(); b < nE; b += cx.waves_per_block()) {
+                        {
                             const int gb = b / G, rb = b - gb * G;
                             double pmv[D], psv[K];
                             for (int d = 0; d < D; ++d) pmv[d] = xl ? Mv(d, x, gb) : 0.0;
@@ -703,29 +707,41 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
                             }
                         }
                     }
+                    };
+                    int mpos = 0, ng = 0;  // used by thread 0
+                    for (int i = tid; i < ((nE + 31) >> 5); i += nt) gbits[i] = 0u;
                     cx.sync();
-                    XT_TH_TICK(2);
-                    if (tid == 0) {
-                        int mpos = 0, ng = 0;
-                        for (int wd = 0; wd < ((nE + 31) >> 5); ++wd) gbits[wd] = 0u;
-                        for (int b = 0; b < nE; ++b) {
-                            if ((gbits[b >> 5] >> (b & 31)) & 1u) continue;
-                            gst[ng++] = (uint16_t)mpos;
-                            mem[mpos++] = (uint16_t)b;  // the pivot itself
-                            gbits[b >> 5] |= 1u << (b & 31);
-                            const int nc = (nE - 1 - b) / cstep;  // candidates b + cstep, ..., b + nc cstep
-                            for (int wd = 0; wd < ((nc + 31) >> 5); ++wd) {
-                                uint32_t bits = cmat[b * NWD + wd];
-                                while (bits) {
-                                    const int jj = b + cstep * ((wd << 5) + __builtin_ctz(bits) + 1);
-                                    bits &= bits - 1;
-                                    if (!((gbits[jj >> 5] >> (jj & 31)) & 1u)) {
-                                        gbits[jj >> 5] |= 1u << (jj & 31);
-                                        mem[mpos++] = (uint16_t)jj;
+                    const int NWv = cx.waves_per_block();
+                    for (int b0 = 0; b0 < nE; b0 += NWv) {
+                        const int bw = b0 + cx.wave_in_block();
+                        if (bw < nE && !((gbits[bw >> 5] >> (bw & 31)) & 1u)) compute_row(bw);
+                        cx.sync();
+                        XT_TH_TICK(2);
+                        if (tid == 0) {
+                            const int bend = b0 + NWv < nE ? b0 + NWv : nE;
+                            for (int b = b0; b < bend; ++b) {
+                                if ((gbits[b >> 5] >> (b & 31)) & 1u) continue;
+                                gst[ng++] = (uint16_t)mpos;
+                                mem[mpos++] = (uint16_t)b;  // the pivot itself
+                                gbits[b >> 5] |= 1u << (b & 31);
+                                const int nc = (nE - 1 - b) / cstep;  // candidates b + cstep, ..., b + nc cstep
+                                for (int wd = 0; wd < ((nc + 31) >> 5); ++wd) {
+                                    uint32_t bits = cmat[b * NWD + wd];
+                                    while (bits) {
+                                        const int jj = b + cstep * ((wd << 5) + __builtin_ctz(bits) + 1);
+                                        bits &= bits - 1;
+                                        if (!((gbits[jj >> 5] >> (jj & 31)) & 1u)) {
+                                            gbits[jj >> 5] |= 1u << (jj & 31);
+                                            mem[mpos++] = (uint16_t)jj;
+                                        }
                                     }
                                 }
                             }
                         }
+                        cx.sync();
+                        XT_TH_TICK(3);
+                    }
+                    if (tid == 0) {
                         gst[ng] = (uint16_t)mpos;
                         wcnt[0] = ng;
                     }
