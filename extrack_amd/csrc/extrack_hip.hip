@@ -1226,9 +1226,15 @@ extern "C" int extrack_predict_th(extrack_ctx* ctx, const extrack_model* m, int3
         a.capE = a.wsP = a.wsE = capE;
         a.ws_lds = 0;
         a.nchunks = pass == 0 ? std::min(all_chunks, probe_chunks) : all_chunks;
+        a.cmat_words = 0;
         size_t lds = (size_t)xt_th_plan_lds_doubles(S, G, capE, D, K) * sizeof(double);
         if (pass == 1) {
             const int wp = std::min(capE, std::max(S * G, learnP)), we = std::min(capE, std::max(S * G, learnE));
+            // bit matrix: only what the probed sequence counts need (a workgroup is one wavefront here: LDS decides how many
+            // tracks a CU works on at a time)
+            const int cst = (S & (S - 1)) == 0 ? S : 1;
+            a.cmat_words = std::min(XT_TH_CMAT_WORDS, std::max(64, we * ((we / cst + 32) >> 5)));
+            lds = (size_t)xt_th_plan_lds_doubles(S, G, capE, D, K, a.cmat_words) * sizeof(double);
             const size_t need = lds + (size_t)xt_th_ws_doubles(wp, we, D, K, F, 1, S, a.pcap, true) * sizeof(double);
             if (need <= 40 * 1024) {
                 a.ws_lds = 1;
@@ -1237,6 +1243,8 @@ extern "C" int extrack_predict_th(extrack_ctx* ctx, const extrack_model* m, int3
                 lds = need;
             } else {
                 pass = 2;
+                a.cmat_words = 0;
+                lds = (size_t)xt_th_plan_lds_doubles(S, G, capE, D, K) * sizeof(double);
             }
         }
         const int threads = nb_max <= 2 ? 64 : 256;

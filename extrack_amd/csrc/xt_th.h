@@ -106,6 +106,7 @@ struct XtThArgs {
     double* preds_out;     // [N][L][S] state posteriors (prediction kernel)
     int32_t ws_lds;        // 1: the pilot-track state lives in LDS (capacities learned from the previous evaluation)
     int32_t wsP, wsE;      // workspace capacities: parent sequences / expanded sequences per pilot track
+    int32_t cmat_words;        // LDS words reserved for the compatibility bit matrix (0: XT_TH_CMAT_WORDS)
     int32_t pair_lanes_max_p;  // pilot counts up to this use one lane per (pivot, candidate) pair in the grouping, more use ballots
     int32_t stP, stE;      // global workspace only: capacities of the LDS staging copy of the pilots' means / stds that the
                            // grouping reads (0: none); steps with more sequences read the workspace directly
@@ -247,14 +248,14 @@ XT_HD int64_t xt_th_ws_doubles(int wsP, int wsE, int D, int K, int F, int NS, in
     if (preds) n += (int64_t)pcap * wsE + ((int64_t)pcap * wsE + 1) / 2 + 2 * (int64_t)pcap * wsP + 8;
     return n;
 }
-XT_HD int xt_th_plan_lds_doubles(int S, int G, int capE, int D, int K)
+XT_HD int xt_th_plan_lds_doubles(int S, int G, int capE, int D, int K, int cmat_words = XT_TH_CMAT_WORDS)
 {
     // tables | per-track scalars | wave counts | compatibility bit matrix + grouped flags | bytes: mpk u32[capE], newest[2][capE],
     // mem u16[capE], gst u16[capE + 1]
     (void)D;
     (void)K;
     const int bytes = 4 * capE + 2 * capE + 2 * capE + 2 * (capE + 1);
-    return ((xt_tab_doubles(S, G) + 1) & ~1) + XT_TH_PILOT + 8 + XT_TH_CMAT_WORDS / 2 + (capE + 63) / 64 + 1 + (bytes + 7) / 8 + 2;
+    return ((xt_tab_doubles(S, G) + 1) & ~1) + XT_TH_PILOT + 8 + (cmat_words + 1) / 2 + (capE + 63) / 64 + 1 + (bytes + 7) / 8 + 2;
 }
 XT_HD int xt_th_apply_lds_doubles(int S, int G, int capG, int TT, int D, int K, int KS, int L, int plan_cap, bool uni, bool single = false)
 {
@@ -437,7 +438,8 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
     double* pm = smem + ((ntab + 1) & ~1);
     int* wcnt = (int*)(pm + XT_TH_PILOT);  // pm: per-track totals of the final sequence weights (prediction mode)
     uint32_t* cmatL = (uint32_t*)(wcnt + 16);
-    uint32_t* gbitsL = cmatL + XT_TH_CMAT_WORDS;
+    const int cmw = a.cmat_words > 0 ? a.cmat_words : XT_TH_CMAT_WORDS;  // LDS words reserved for the bit matrix
+    uint32_t* gbitsL = cmatL + cmw + (cmw & 1);
     uint32_t* mpk = gbitsL + 2 * ((capE + 63) / 64) + 2;
     uint8_t* newA = (uint8_t*)(mpk + capE);
     uint8_t* newB = newA + capE;
@@ -449,11 +451,11 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
     const int wsP = a.wsP, wsE = a.wsE, stP = a.stP, stE = a.stE;
     // staging copy: after the LDS-resident state when that is in LDS too (then it only serves to give the compiler LDS-typed
     // addresses instead of flat ones for the hot pair loop)
-    double* stM = smem + xt_th_plan_lds_doubles(S, G, capE, D, K) +
+    double* stM = smem + xt_th_plan_lds_doubles(S, G, capE, D, K, cmw) +
                   (a.ws_lds ? xt_th_ws_doubles(wsP, wsE, D, K, F, NS, S, a.pcap, PREDS) : 0);  // [PC][stP][D]
     double* stS = stM + (int64_t)a.pcap * stP * D;                  // [PC][stE][K]
     double* wh = a.ws + (int64_t)cx.block() * a.ws_stride;  // history part (prediction mode), then the state part unless it is in LDS
-    double* w = a.ws_lds ? smem + xt_th_plan_lds_doubles(S, G, capE, D, K) : wh + xt_th_hist_doubles(wsE, a.pcap, PREDS, L);
+    double* w = a.ws_lds ? smem + xt_th_plan_lds_doubles(S, G, capE, D, K, cmw) : wh + xt_th_hist_doubles(wsE, a.pcap, PREDS, L);
     const int plane = PC * wsE;  // sE plane
     typedef XtThView<D, K, false> View;
     View A, B;
@@ -586,7 +588,7 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
                     const bool wrapS = (S & (S - 1)) != 0 && nE > 128;
                     const int cstep = wrapS ? 1 : S;
                     const int NWD = (nE / cstep + 32) >> 5;
-                    const bool cml = nE * NWD <= XT_TH_CMAT_WORDS;
+                    const bool cml = nE * NWD <= cmw;
                     uint32_t* cmat = cml ? cmatL : cmatG;
                     uint32_t* gbits = cml ? gbitsL : gbitsG;
                     for (int i = tid; i < P * nE; i += nt) {
