@@ -714,13 +714,16 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
                     for (int i = tid; i < ((nE + 31) >> 5); i += nt) gbits[i] = 0u;
                     cx.sync();
                     const int NWv = cx.waves_per_block();
-                    for (int b0 = 0; b0 < nE; b0 += NWv) {
-                        const int bw = b0 + cx.wave_in_block();
-                        if (bw < nE && !((gbits[bw >> 5] >> (bw & 31)) & 1u)) compute_row(bw);
+                    // batch size: one row per wavefront; with few sequences (<= 64) and several wavefronts everything in one batch
+                    // (the barriers of more batches would cost more than the skipped rows save)
+                    const int BS = (NWv > 1 && nE <= 64) ? nE : NWv;
+                    for (int b0 = 0; b0 < nE; b0 += BS) {
+                        for (int bw = b0 + cx.wave_in_block(); bw < b0 + BS && bw < nE; bw += NWv)
+                            if (!((gbits[bw >> 5] >> (bw & 31)) & 1u)) compute_row(bw);
                         cx.sync();
                         XT_TH_TICK(2);
                         if (tid == 0) {
-                            const int bend = b0 + NWv < nE ? b0 + NWv : nE;
+                            const int bend = b0 + BS < nE ? b0 + BS : nE;
                             for (int b = b0; b < bend; ++b) {
                                 if ((gbits[b >> 5] >> (b & 31)) & 1u) continue;
                                 gst[ng++] = (uint16_t)mpos;
