@@ -30,6 +30,8 @@
 //     weights recorded, then one backward pass over the merge tree reads the posteriors out.
 //   * One launch of each kernel serves all length buckets of a dataset through a table of bucket descriptors (XtThBucket).
 #pragma once
+#include <type_traits>
+
 #include "xt_kernel.h"
 
 #define XT_TH_PILOT 30  // tracking.py:678-679
@@ -615,9 +617,13 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
                     auto Mv = [&](int d, int x, int g) -> double { return staged ? stM[(x * stP + g) * D + d] : bA.m(d, x * wsP + g); };
                     auto Sv = [&](int k, int x, int jj) -> double { return staged ? stS[(x * stE + jj) * K + k] : sE[k * plane + x * wsE + jj]; };
                     // same history class / same new-state history entries of two expanded sequences
-                    auto same_class = [&](int jj, int bb) -> bool { return !wrapS || xt_th_cat_digit(jj, S) == xt_th_cat_digit(bb, S); };
-                    auto same_digits = [&](int jj, int bb, int rj, int rb) -> bool {
-                        if (!wrapS) return rj == rb;
+                    // (WRAP is a compile-time flag: the regular case must not pay for the wrapped-index arithmetic)
+                    auto same_class = [&](auto WRAP, int jj, int bb) -> bool {
+                        if (!decltype(WRAP)::value) return true;
+                        return xt_th_cat_digit(jj, S) == xt_th_cat_digit(bb, S);
+                    };
+                    auto same_digits = [&](auto WRAP, int jj, int bb, int rj, int rb) -> bool {
+                        if (!decltype(WRAP)::value) return rj == rb;
                         bool eq = true;
                         for (int c = 0; c < NS; ++c) eq = eq && xt_th_cat_digit(jj / pwS[c], S) == xt_th_cat_digit(bb / pwS[c], S);
                         return eq;
@@ -630,15 +636,15 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
                     // Rows are computed in batches of one pivot candidate per wavefront, the greedy scan advancing batch by batch:
                     // a sequence that an earlier batch has already put into a group never becomes a pivot, so its row - more than
                     // half of all rows - is never computed.
-                    auto compute_row = [&](const int b) {
+                    auto compute_row = [&](const int b, auto WRAP) {
                     if (P <= a.pair_lanes_max_p) {
                         // few pilot tracks (predict_Bs with nb_max <= 4): one lane per (pivot, candidate) pair, pilots in a loop
                         {
                             const int gb = b / G, rb = b - gb * G;
                             for (int jj = b + cstep * (1 + cx.lane()); jj < nE; jj += 64 * cstep) {
-                                if (!same_class(jj, b)) continue;
+                                if (!same_class(WRAP, jj, b)) continue;
                                 const int gj = jj / G, rj = jj - gj * G;
-                                bool same_hist = useA && same_digits(jj, b, rj, rb);
+                                bool same_hist = useA && same_digits(WRAP, jj, b, rj, rb);
                                 if (same_hist)
                                     for (int xx = 0; xx < (PREDS ? P : 1); ++xx) same_hist = same_hist && kyA[xx * wsP + gj] == kyA[xx * wsP + gb];
                                 bool flag = same_hist;
@@ -681,8 +687,8 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
                                     ++gj;
                                 }
                                 const int jj = j0 + half * cstep;
-                                const bool valid = jj < nE && same_class(jj, b);
-                                bool same_hist = valid && useA && same_digits(jj, b, rj, rb);
+                                const bool valid = jj < nE && same_class(WRAP, jj, b);
+                                bool same_hist = valid && useA && same_digits(WRAP, jj, b, rj, rb);
                                 if (same_hist)  // predicting: on every pilot track (mean > 0.999, tracking.py:686)
                                     for (int xx = 0; xx < (PREDS ? P : 1); ++xx) same_hist = same_hist && kyA[xx * wsP + gj] == kyA[xx * wsP + gb];
                                 const bool live = valid && xl && !same_hist;
@@ -719,7 +725,12 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
                     const int BS = (NWv > 1 && nE <= 64) ? nE : NWv;
                     for (int b0 = 0; b0 < nE; b0 += BS) {
                         for (int bw = b0 + cx.wave_in_block(); bw < b0 + BS && bw < nE; bw += NWv)
-                            if (!((gbits[bw >> 5] >> (bw & 31)) & 1u)) compute_row(bw);
+                            if (!((gbits[bw >> 5] >> (bw & 31)) & 1u)) {
+                                if (wrapS)
+                                    compute_row(bw, std::true_type());
+                                else
+                                    compute_row(bw, std::false_type());
+                            }
                         cx.sync();
                         XT_TH_TICK(2);
                         if (tid == 0) {
