@@ -44,7 +44,7 @@ def extract_params(params, dt, nb_states, nb_substeps, input_LocErr=None, Matrix
     (1,1,k) array for a global error, or one per-peak array per bucket when ``input_LocErr`` is given
     (affinely rescaled and clipped at 1e-6 if ``slope_LocErr``/``offset_LocErr`` are parameters)."""
     if isinstance(dt, (list, dict)):
-        raise NotImplementedError("per-track time steps (dt as list/dict) belong to the threshold-fusion kernel, which is not built")
+        raise NotImplementedError("per-track time steps (dt as list/dict, extrack/tracking.py:979-982) are not built: scalar dt only")
     names = np.sort(list(params.keys()))
     LocErr = [np.array([params[n].value for n in names if n.startswith("LocErr")])[None, None]]
     if input_LocErr is not None:
