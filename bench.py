@@ -1,10 +1,16 @@
 #!/usr/bin/env python3
 """Headline benchmark: log-likelihood evaluations per second on synthetic track batches.
 
-Workload at N GPUs (weak scaling): every rank holds BASELINE.json configs[1] - 1e6 tracks, 2 states, length 30,
-2-D, nb_substeps=1, frame_len=6 - resident in HBM; a "step" is one evaluation of -sum(LL) over all ranks' tracks
+Workload at N GPUs, default ``--config c2`` (weak scaling): every rank holds BASELINE.json configs[1] - 1e6 tracks, 2 states,
+length 30, 2-D, nb_substeps=1, frame_len=6 - resident in HBM; a "step" is one evaluation of -sum(LL) over all ranks' tracks
 (local kernel + one all-reduce of the fp64 scalar over RCCL).  `value` = (N x 1e6-track evaluations) / s, i.e. in
 units of "1e6-track log-likelihood evaluations per second".
+``--config c4`` (strong scaling): BASELINE.json configs[3] - 1e7 tracks of the same shape IN TOTAL, sharded by rows over the N
+ranks (1.25e6 per rank at N = 8); `value` is in the same unit (1e6-track evaluations per second = 10 x whole-dataset
+evaluations per second).
+At N = 1 with the default config, an `extra` block (outside the timed region) reports the other BASELINE configs on the same
+GPU: configs[2] (3 states, 46 length buckets) per evaluation, configs[4] (4 states, nb_substeps 3) per evaluation and its
+predict_Bs annotation, each with algorithmic bytes and the flop model of SURVEY.md section 8(d).
 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
@@ -120,12 +126,120 @@ def cpu_baseline_compiled(cores, n=400000):
             "sample": "%d tracks, %.0f tracks/s" % (n, n / wall)}
 
 
+def _flop_model(lengths_counts, S, F, ns, D):
+    """Algorithmic fp64 flops of one evaluation, SURVEY.md section 8(d): per track (L-2) * S^F * [(4D+8) + 3S + S(D+4) + 4 flops
+    + (S exp + 2 log + 2 div) at ~20 flops each] (the reference's operation count per kept sequence and step)."""
+    per_entry = (4 * D + 8) + 3 * S + S * (D + 4) + 4 + (S + 4) * 20
+    return float(sum(n * max(L - 2, 0) for L, n in lengths_counts)) * (S ** F) * per_entry
+
+
+def other_configs(device):
+    """configs[2] and configs[4] on the same GPU (N = 1 only, outside the timed region): ms per evaluation / tracks per second with
+    the HIP-event kernel time, algorithmic bytes (one read of the tracks; posteriors add their output) and the flop model."""
+    import torch
+    from extrack_amd import synth, tracking
+    from extrack_amd.lmfit_compat import Parameters
+
+    def P(vals):
+        p = Parameters()
+        for k, v in vals.items():
+            p.add(k, value=v)
+        return p
+
+    def timed(fn, n):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ks = []
+        for _ in range(n):
+            r = fn()
+            ks.append(ts.ctx.last_kernel_ms())
+        return (time.perf_counter() - t0) / n, float(np.mean(ks)), r
+
+    out = {}
+    # ---- configs[2]: 1e6 tracks, 3 states, lengths 5..50 (46 buckets, geometric sizes), one objective evaluation
+    Ds = [0.0, 0.04, 0.25]
+    Tm = np.array([[0.9, 0.07, 0.03], [0.05, 0.9, 0.05], [0.03, 0.07, 0.9]])
+    sizes = synth.bucket_sizes_geometric(N_TRACKS, list(range(5, 51)), 0.9)
+    tracks = {str(L): synth.brownian_tracks(n, L, Ds, Tm, [0.3, 0.3, 0.4], seed=1000 + L) for L, n in sizes.items() if n > 0}
+    vals = dict(D0=1e-4, D1=0.04, D2=0.25, LocErr=0.02, F0=0.3, F1=0.3, F2=0.4, p01=0.07, p02=0.03, p10=0.05, p12=0.05, p20=0.03, p21=0.07,
+                pBL=0.1)
+    _, lst, _ = tracking.engine.sort_buckets(tracks)
+    ts = tracking.TrackSet(lst, device=device)
+    lc = [(b.shape[1], len(b)) for b in lst]
+    nbytes = sum(b.nbytes for b in lst)
+    del tracks, lst
+    for F in (6, 4):
+        model = tracking._objective_model(P(vals), ts, DT, CELL, None, 3, 1, F, 1)
+        wall, kms, v = timed(lambda: ts.loglik(model), 5)
+        fl = _flop_model(lc, 3, F, 1, DIMS)
+        out["c3_loglik_F%d" % F] = {"what": "configs[2]: 1e6 tracks, 3 states, 46 buckets len 5-50, frame_len %d, one evaluation" % F,
+                                    "ms_per_eval": wall * 1e3, "kernel_ms": kms, "algorithmic_bytes": nbytes,
+                                    "hbm_gbs": nbytes / (kms * 1e-3) / 1e9, "hbm_frac": nbytes / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                    "flop_model": fl, "fp64_tflops": fl / (kms * 1e-3) / 1e12,
+                                    "fp64_frac": fl / (kms * 1e-3) / 1e12 / FP64_VALU_PEAK_TF, "neg_loglik": -v,
+                                    "launch": ts.ctx.last_launch_info()}
+    model = tracking._objective_model(P(vals), ts, DT, CELL, None, 3, 1, 6, 1)
+    wall, kms, v = timed(lambda: ts.loglik_th(model, 0.2, 120, 2000), 3)
+    out["c3_loglik_threshold"] = {"what": "configs[2] through the threshold-fusion kernels (v1.6.3 defaults, frame_len 6)", "ms_per_eval": wall * 1e3,
+                                  "kernel_ms": kms, "algorithmic_bytes": nbytes, "hbm_gbs": nbytes / (kms * 1e-3) / 1e9, "neg_loglik": -v}
+    ts.close()
+    # ---- configs[4]: 5e5 tracks x 60, 4 states, nb_substeps 3 (frame_len 4) + predict_Bs (nb_substeps 1, frame_len 5)
+    N5, L5 = 500000, 60
+    Tm = np.full((4, 4), 0.05 / 3)
+    Tm[np.arange(4), np.arange(4)] = 0.95
+    Cs = synth.brownian_tracks(N5, L5, [0.0, 0.02, 0.1, 0.5], Tm, [0.25] * 4, seed=2)
+    vals = dict(D0=1e-4, D1=0.02, D2=0.1, D3=0.5, LocErr=0.02, F0=.25, F1=.25, F2=.25, F3=.25, pBL=0.1)
+    for i in range(4):
+        for j in range(4):
+            if i != j:
+                vals["p%d%d" % (i, j)] = 0.05 / 3
+    ts = tracking.TrackSet([Cs], device=device)
+    nbytes = Cs.nbytes
+    del Cs
+    model = tracking._objective_model(P(vals), ts, DT, CELL, None, 4, 3, 4, 1)
+    wall, kms, v = timed(lambda: ts.loglik(model), 3)
+    fl = _flop_model([(L5, N5)], 4, 4, 3, DIMS)
+    out["c5_loglik_ns3_F4"] = {"what": "configs[4]: 5e5 tracks x 60, 4 states, nb_substeps 3, frame_len 4, one evaluation", "ms_per_eval": wall * 1e3,
+                               "kernel_ms": kms, "algorithmic_bytes": nbytes, "hbm_gbs": nbytes / (kms * 1e-3) / 1e9,
+                               "hbm_frac": nbytes / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, "flop_model": fl, "fp64_tflops": fl / (kms * 1e-3) / 1e12,
+                               "fp64_frac": fl / (kms * 1e-3) / 1e12 / FP64_VALU_PEAK_TF, "neg_loglik": -v, "launch": ts.ctx.last_launch_info()}
+    model = tracking._objective_model(P(vals), ts, DT, CELL, None, 4, 1, 5, 1)
+    t0 = time.perf_counter()
+    pr = ts.predict(model)
+    wall = time.perf_counter() - t0
+    kms = ts.ctx.last_kernel_ms()
+    obytes = pr[0].nbytes
+    out["c5_predict_Bs_F5"] = {"what": "configs[4] annotation: predict_Bs posteriors [5e5, 60, 4] (nb_substeps 1, frame_len 5), incl. the copy to the host",
+                               "tracks_per_s": N5 / wall, "seconds": wall, "kernel_ms": kms, "kernel_tracks_per_s": N5 / (kms * 1e-3),
+                               "algorithmic_bytes": nbytes + obytes, "hbm_gbs": (nbytes + obytes) / (kms * 1e-3) / 1e9,
+                               "rowsum_err": float(np.abs(pr[0].sum(-1) - 1).max()), "launch": ts.ctx.last_launch_info()}
+    del pr
+    ts.close()
+    # CPU side of the same configs (plain-C restatement, OpenMP, bounded samples)
+    try:
+        from oracle import oracle_c, oracle_np as O
+        cores = _one_socket_cores()
+        LocErr, ds, Fs, T, pBL = O.extract_params(vals, DT, 3, 1)
+        smp = synth.brownian_tracks(2 * cores, L5, [0.0, 0.02, 0.1, 0.5], Tm, [0.25] * 4, seed=3)
+        t0 = time.perf_counter()
+        oracle_c.run(smp, LocErr, ds, Fs, T, pBL, 0, O.p_stay_table(ds, 4, 3, CELL), 3, 4, L5, nthreads=cores)
+        dtc = time.perf_counter() - t0
+        out["c5_loglik_ns3_F4"]["cpu_port_c"] = {"tracks_per_s": len(smp) / dtc, "cores": cores, "sample": "%d tracks" % len(smp)}
+    except Exception as e:
+        out["c5_loglik_ns3_F4"]["cpu_port_c"] = {"error": str(e)}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--tracks", type=int, default=N_TRACKS, help="tracks per GPU (default = the BASELINE config)")
+    ap.add_argument("--config", choices=("c2", "c4"), default="c2",
+                    help="c2: BASELINE configs[1], 1e6 tracks per GPU (weak scaling); c4: configs[3], 1e7 tracks in total sharded over the GPUs")
+    ap.add_argument("--tracks", type=int, default=None, help="tracks per GPU (c2) / in total (c4); default = the BASELINE config")
+    ap.add_argument("--no-extra", action="store_true", help="skip the configs[2] / configs[4] measurements after the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
@@ -154,6 +268,16 @@ def main():
         comm = Comm()
 
     # synthetic data of the BASELINE shape, resident in HBM before the timed region
+    if a.config == "c4":
+        from extrack_amd.distributed import shard_plan
+        total_tracks = a.tracks if a.tracks else 10 * N_TRACKS
+        lo_, hi_ = shard_plan([total_tracks], [LEN], world)[0][rank]
+        a.tracks = hi_ - lo_   # this rank's rows of the one 1e7-track bucket
+        scaling = "strong"
+    else:
+        a.tracks = a.tracks if a.tracks else N_TRACKS
+        total_tracks = a.tracks * world
+        scaling = "weak"
     Cs = synth.brownian_tracks(a.tracks, LEN, DS_COEF, TRMAT, FS, LOCERR, DT, DIMS, seed=rank)
     ts = tracking.TrackSet([Cs], device=local, min_len=LEN, max_len=LEN)
     del Cs
@@ -189,7 +313,7 @@ def main():
     # 2000-track chunks): plan kernel + apply kernel per evaluation
     launch_info = ts.ctx.last_launch_info()
     th = None
-    if world == 1 and a.tracks == N_TRACKS:
+    if world == 1 and a.tracks == N_TRACKS and a.config == "c2":
         for _ in range(2):
             th_val = ts.loglik_th(model, 0.2, 120, 2000)
         torch.cuda.synchronize()
@@ -203,13 +327,17 @@ def main():
               "value": 1.0 / th_dt, "unit": "1e6-track LL evals/s", "ms_per_eval": th_dt * 1e3, "kernels_ms": float(np.mean(th_ms)),
               "hbm_gbs": a.tracks * LEN * DIMS * 8 / (float(np.mean(th_ms)) * 1e-3) / 1e9, "neg_loglik": -th_val,
               "launch": ts.ctx.last_launch_info()}
+    ts.close()
+    extra = None
+    if world == 1 and a.config == "c2" and a.tracks == N_TRACKS and not a.no_extra:
+        extra = other_configs(local)
     if comm is not None:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
     if rank != 0:
         return
     ms_per_step = dt_all / a.steps * 1e3
-    evals_per_s = world * (a.tracks / N_TRACKS) * a.steps / dt_all
+    evals_per_s = (total_tracks / N_TRACKS) * a.steps / dt_all
     k_ms = float(np.mean(kernel_ms))
     alg_bytes = a.tracks * LEN * DIMS * 8          # one read of the track, LL reduced in-kernel
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
@@ -228,10 +356,12 @@ def main():
     out = {
         "metric": "log-likelihood evals/sec (1e6 tracks, 2-state, len=30)", "value": evals_per_s, "unit": "1e6-track LL evals/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "BASELINE configs[1]: %d tracks/GPU, 2 states, len=30, 2-D, nb_substeps=1, frame_len=6, "
-                               "single log-likelihood eval per step" % a.tracks,
-                   "tracks_per_gpu": a.tracks, "parallelism": "dp%d" % world, "launch": launch_info},
+        "scaling": scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": ("BASELINE configs[1]: %d tracks/GPU, 2 states, len=30, 2-D, nb_substeps=1, frame_len=6, "
+                                "single log-likelihood eval per step" % a.tracks) if a.config == "c2" else
+                               ("BASELINE configs[3]: %d tracks in total, row-sharded over %d GPU(s) (%d on rank 0), 2 states, len=30, 2-D, "
+                                "nb_substeps=1, frame_len=6, single log-likelihood eval per step" % (total_tracks, world, a.tracks)),
+                   "tracks_per_gpu": a.tracks, "total_tracks": total_tracks, "parallelism": "dp%d" % world, "launch": launch_info},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes,
                      "note": "the recursion is FP64-VALU bound, not HBM bound (arithmetic intensity ~300 flop/B, DESIGN.md)",
@@ -242,6 +372,8 @@ def main():
     }
     if th is not None:
         out["threshold_fusion"] = th
+    if extra is not None:
+        out["extra"] = extra
     if not a.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline()
         out["speedup_vs_cpu_baseline"] = evals_per_s / out["cpu_baseline"]["value"]

@@ -15,7 +15,8 @@ EXPORTS = [
     "extrack_abi_version", "extrack_create", "extrack_destroy", "extrack_last_error", "extrack_set_stream",
     "extrack_upload_bucket", "extrack_attach_bucket", "extrack_clear_buckets", "extrack_bucket_count",
     "extrack_loglik", "extrack_loglik_async", "extrack_predict", "extrack_last_kernel_ms",
-    "extrack_last_launch_info", "extrack_p_stay_table", "extrack_loglik_th", "extrack_th_plan_step", "extrack_predict_th",
+    "extrack_last_launch_info", "extrack_p_stay_table", "extrack_loglik_th", "extrack_loglik_th_async", "extrack_th_plan_step",
+    "extrack_predict_th",
 ]
 
 _dp = C.POINTER(C.c_double)
@@ -89,6 +90,7 @@ def load():
     lib.extrack_last_launch_info.argtypes = [vp, C.POINTER(i32 * 6)]
     lib.extrack_p_stay_table.argtypes = [vp, i32, i32, vp, i32, vp]
     lib.extrack_loglik_th.argtypes = [vp, C.POINTER(ExtrackModel), C.c_double, i32, i32, _dp, vp]
+    lib.extrack_loglik_th_async.argtypes = [vp, C.POINTER(ExtrackModel), C.c_double, i32, i32, vp]
     lib.extrack_predict_th.argtypes = [vp, C.POINTER(ExtrackModel), i32, C.c_double, i32, i32, vp]
     lib.extrack_th_plan_step.argtypes = [vp, i32, i64, i32, C.POINTER(i32), C.POINTER(i32), vp, vp, i32]
     if lib.extrack_abi_version() != 2:
@@ -213,6 +215,10 @@ class Context:
         self._check(self._lib.extrack_loglik_th(self._h, C.byref(model.c), C.c_double(threshold), int(max_nb_states), int(chunk),
                                                 C.byref(tot), out.ctypes.data_as(C.c_void_p) if per_track else None))
         return (tot.value, out) if per_track else tot.value
+
+    def loglik_th_async(self, model, threshold, max_nb_states, chunk, d_total_ptr=None):
+        self._check(self._lib.extrack_loglik_th_async(self._h, C.byref(model.c), C.c_double(threshold), int(max_nb_states), int(chunk),
+                                                      C.c_void_p(d_total_ptr) if d_total_ptr else None))
 
     def predict_th(self, model, bucket_id, threshold=0.1, max_nb_states=200, nb_max=1):
         """Threshold-fusion posteriors of one bucket in chunks of nb_max tracks (extrack/tracking.py:792-906 semantics)."""

@@ -1,74 +1,11 @@
 // libextrack_hip.so - HIP kernels (gfx950) + C ABI for ExTrack's track-likelihood hot path.
 // See include/extrack_hip.h for the contract and xt_kernel.h for the algorithm/data layout.
-#include <hip/hip_runtime.h>
-#include <math.h>
-#include <stdio.h>
-#include <stdlib.h>
-#include <string.h>
+#include "xt_host.h"
 
-#include <algorithm>
-#include <map>
-#include <string>
-#include <vector>
-
-#include "../../include/extrack_hip.h"
 #include "xt_dispatch.h"
 #include "xt_entry.h"
 #include "xt_fast2.h"
-#include "xt_tables.h"
-#include "xt_th.h"
 
-// ------------------------------------------------------------------------------------------------
-// device side
-// ------------------------------------------------------------------------------------------------
-extern __shared__ double xt_smem[];
-
-struct DevCtx {
-    __device__ __forceinline__ int tid() const { return threadIdx.x; }
-    __device__ __forceinline__ int nthreads() const { return blockDim.x; }
-    __device__ __forceinline__ int block() const { return blockIdx.x; }
-    __device__ __forceinline__ int nblocks() const { return gridDim.x; }
-    __device__ __forceinline__ double* smem() const { return xt_smem; }
-    __device__ __forceinline__ void sync() { __syncthreads(); }
-    __device__ __forceinline__ int lane() const { return threadIdx.x & 63; }
-    // promise that v is the same in every lane of the wavefront (moves it to an SGPR: scalar loads, scalar address math)
-    __device__ __forceinline__ int uniform(int v) const { return __builtin_amdgcn_readfirstlane(v); }
-    __device__ __forceinline__ int wave_in_block() const { return threadIdx.x >> 6; }
-    __device__ __forceinline__ int waves_per_block() const { return blockDim.x >> 6; }
-    // LDS operations of one wavefront execute in order; only the compiler must be kept from moving
-    // LDS accesses across the point where other lanes' data is consumed.
-    __device__ __forceinline__ void wave_sync()
-    {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
-    __device__ __forceinline__ unsigned long long ballot(bool flag) { return __ballot(flag); }
-    // number of lanes below this one with flag set; total = lanes of the wave with flag set
-    __device__ __forceinline__ int wave_rank(bool flag, int& total)
-    {
-        const unsigned long long b = __ballot(flag);
-        total = __popcll(b);
-        return __popcll(b & ((1ull << (threadIdx.x & 63)) - 1ull));
-    }
-    __device__ __forceinline__ int shfl_xor_i32(int v, int m) { return __shfl_xor(v, m, 64); }
-    __device__ __forceinline__ double shfl_xor_f64(double v, int m) { return __shfl_xor(v, m, 64); }
-    __device__ __forceinline__ void atomic_max_i32(int* p, int v)
-    {
-        __hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-    __device__ __forceinline__ void atomic_or_u32(uint32_t* p, uint32_t v)
-    {
-        __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-    __device__ __forceinline__ void atomic_add_f64(double* p, double v)
-    {
-        __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-};
-
-// MAXT: 256 for the common one-wave-set-per-few-tracks geometry (lets the allocator use up to 256
-// VGPRs at 2 waves/SIMD if it needs them), 1024 when one track's groups need more than 256 threads.
 template <int G_, int D, int K, bool PREDS, int MAXT>
 __global__ void __launch_bounds__(MAXT, (MAXT == 256 && !PREDS && G_ != 4 ? 4 : 1)) xt_track_kernel(XtKernelArgs a)
 {
@@ -119,86 +56,9 @@ __global__ void __launch_bounds__(256) xt_reduce_partials(const double* __restri
     if (threadIdx.x == 0) *out = sh[0];
 }
 
-// ------------------------------------------------------------------------------------------------
-// host side
-// ------------------------------------------------------------------------------------------------
-struct XtBucket {
-    const double* d_tracks = nullptr;
-    const double* d_sigma = nullptr;
-    bool owned = false;
-    int64_t N = 0;
-    int L = 0, D = 0, KS = 0;
-    double* d_ll = nullptr;  // per-track output, allocated on first request
-    // threshold-fusion plan of the last extrack_loglik_th call (xt_th.h)
-    uint16_t* th_members = nullptr;
-    uint32_t* th_mpack = nullptr;
-    uint8_t* th_gnew = nullptr;
-    uint16_t* th_gstart = nullptr;
-    int32_t* th_hdr = nullptr;
-    int32_t* th_status = nullptr;
-    int th_capE = 0, th_chunk = 0;
-    int64_t th_nchunks = 0;
-};
-
-struct extrack_ctx {
-    int device = 0;
-    int n_cu = 0;
-    int oversub = 8;  // block generations per CU (EXTRACK_OVERSUB overrides; tuning knob)
-    hipStream_t own_stream = nullptr;
-    hipStream_t stream = nullptr;
-    std::vector<XtBucket> buckets;
-    XtConfig cfg;
-    int32_t* d_base_tab = nullptr;
-    int32_t* d_off_tab = nullptr;
-    double* d_blob = nullptr;
-    size_t blob_cap = 0;
-    double* h_blob = nullptr;  // pinned
-    double* d_partials = nullptr;
-    size_t partials_cap = 0;
-    double* d_total = nullptr;
-    double* h_total = nullptr;  // pinned
-    XtBucketDesc* d_desc = nullptr;  // [XT_DESC_CAP] bucket descriptors of the launches of one evaluation
-    XtBucketDesc* h_desc = nullptr;  // pinned staging
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    bool timed = false;
-    int32_t launch_info[6] = {0, 0, 0, 0, 0, 0};
-    std::map<std::pair<const void*, std::pair<int, size_t>>, int> occ_cache;
-    double* d_th_ws = nullptr;  // plan-kernel workspace
-    size_t th_ws_cap = 0;
-    int th_capE = 128;          // plan capacity (expanded sequences per step); grows on overflow
-    int th_learnP = 0, th_learnE = 0;  // live parent / expanded sequence counts seen by the last plan (+ headroom): LDS workspace sizing
-    std::vector<int32_t> th_status_host;
-    int32_t* h_th_status = nullptr;  // pinned: plan status of every chunk of a launch group
-    int32_t* d_th_status = nullptr;
-    size_t th_status_cap = 0;        // ints
-    XtThBucket* d_th_desc = nullptr;  // bucket descriptors of a launch group
-    size_t th_desc_cap = 0;
-    int32_t* d_th_cend = nullptr;     // chunk prefix of a launch group
-    size_t th_cend_cap = 0;
-    float th_plan_ms = 0.f;
-    int th_force_single = 0;
-    int th_pair_lanes = 4;  // EXTRACK_TH_PAIR_LANES
-    int th_stage_in_lds_mode = 0;  // EXTRACK_TH_STAGE_LDS: LDS-typed copy of the pilot means/stds also when the state is in LDS (measured: no gain)
-    int th_no_gen_single = 0;  // EXTRACK_TH_NO_GEN_SINGLE: never use the one-buffer general apply variant
-    int th_plan_threads = 512;  // workgroup size of the plan kernel (EXTRACK_TH_PLAN_THREADS)
-    int th_force_tt = 0, th_force_threads = 0, th_oversub = 2;  // tuning knobs (EXTRACK_TH_TT / _THREADS / _OVERSUB)
-    std::string err;
-};
-
-static const int XT_DESC_CAP = 4096;  // bucket descriptors per evaluation (buckets beyond 64 per launch group are chunked)
-
 static std::string g_create_err;
 
-#define XT_HIP(ctx, call)                                                                       \
-    do {                                                                                        \
-        hipError_t e__ = (call);                                                                \
-        if (e__ != hipSuccess) {                                                                \
-            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e__);                    \
-            return EXTRACK_E_HIP;                                                               \
-        }                                                                                       \
-    } while (0)
-
-static int xt_fail(extrack_ctx* ctx, int code, const std::string& msg)
+int xt_fail(extrack_ctx* ctx, int code, const std::string& msg)
 {
     if (ctx) ctx->err = msg;
     return code;
@@ -269,6 +129,8 @@ extern "C" int extrack_create(int device_id, extrack_ctx** out)
     c->stream = c->own_stream;
     XT_CREATE(hipEventCreate(&c->ev0));
     XT_CREATE(hipEventCreate(&c->ev1));
+    XT_CREATE(hipEventCreateWithFlags(&c->ev_blob[0], hipEventDisableTiming));
+    XT_CREATE(hipEventCreateWithFlags(&c->ev_blob[1], hipEventDisableTiming));
     XT_CREATE(hipMalloc(&c->d_total, sizeof(double)));
     XT_CREATE(hipHostMalloc(&c->h_total, sizeof(double), hipHostMallocDefault));
     XT_CREATE(hipMalloc(&c->d_desc, XT_DESC_CAP * sizeof(XtBucketDesc)));
@@ -315,8 +177,12 @@ extern "C" void extrack_destroy(extrack_ctx* ctx)
     if (ctx->d_th_status) (void)hipFree(ctx->d_th_status);
     if (ctx->d_th_desc) (void)hipFree(ctx->d_th_desc);
     if (ctx->d_th_cend) (void)hipFree(ctx->d_th_cend);
-    if (ctx->d_blob) (void)hipFree(ctx->d_blob);
-    if (ctx->h_blob) (void)hipHostFree(ctx->h_blob);
+    for (int i = 0; i < 2; ++i) {
+        if (ctx->d_blob_s[i]) (void)hipFree(ctx->d_blob_s[i]);
+        if (ctx->h_blob_s[i]) (void)hipHostFree(ctx->h_blob_s[i]);
+        if (ctx->ev_blob[i]) (void)hipEventDestroy(ctx->ev_blob[i]);
+    }
+    if (ctx->d_preds) (void)hipFree(ctx->d_preds);
     if (ctx->d_partials) (void)hipFree(ctx->d_partials);
     if (ctx->d_total) (void)hipFree(ctx->d_total);
     if (ctx->h_total) (void)hipHostFree(ctx->h_total);
@@ -401,7 +267,7 @@ extern "C" int extrack_attach_bucket(extrack_ctx* ctx, const double* d_tracks, i
     return EXTRACK_OK;
 }
 
-static int xt_validate_model(extrack_ctx* ctx, const extrack_model* m)
+int xt_validate_model(extrack_ctx* ctx, const extrack_model* m)
 {
     if (!m || !m->ds || !m->Fs || !m->TrMat || !m->p_stay) return xt_fail(ctx, EXTRACK_E_INVALID, "null model field");
     if (m->locerr_mode < 0 || m->locerr_mode > 2) return xt_fail(ctx, EXTRACK_E_INVALID, "locerr_mode must be 0, 1 or 2");
@@ -411,7 +277,7 @@ static int xt_validate_model(extrack_ctx* ctx, const extrack_model* m)
     return EXTRACK_OK;
 }
 
-static void xt_model_host(const extrack_model* m, XtModelHost& mh)
+void xt_model_host(const extrack_model* m, XtModelHost& mh)
 {
     mh.S = m->n_states;
     mh.NS = m->nb_substeps;
@@ -426,30 +292,53 @@ static void xt_model_host(const extrack_model* m, XtModelHost& mh)
     mh.p_stay = m->p_stay;
 }
 
-// Ships a model blob through the pinned staging buffer to ctx->d_blob (stream-ordered).
-static int xt_upload_blob(extrack_ctx* ctx, const std::vector<double>& blob)
+// Ships a model blob through one of the two pinned staging slots to its device slot (stream-ordered) and makes that slot
+// the current one (ctx->d_blob).  The host only waits for the copy issued two evaluations ago.
+int xt_upload_blob(extrack_ctx* ctx, const std::vector<double>& blob)
 {
     if (blob.size() > ctx->blob_cap) {
         XT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (ctx->d_blob) (void)hipFree(ctx->d_blob);
-        if (ctx->h_blob) (void)hipHostFree(ctx->h_blob);
-        ctx->d_blob = nullptr;
-        ctx->h_blob = nullptr;
+        for (int i = 0; i < 2; ++i) {
+            if (ctx->d_blob_s[i]) (void)hipFree(ctx->d_blob_s[i]);
+            if (ctx->h_blob_s[i]) (void)hipHostFree(ctx->h_blob_s[i]);
+            ctx->d_blob_s[i] = ctx->h_blob_s[i] = nullptr;
+            ctx->blob_busy[i] = false;
+        }
         ctx->blob_cap = 0;
-        XT_HIP(ctx, hipMalloc(&ctx->d_blob, blob.size() * sizeof(double)));
-        XT_HIP(ctx, hipHostMalloc(&ctx->h_blob, blob.size() * sizeof(double), hipHostMallocDefault));
+        for (int i = 0; i < 2; ++i) {
+            XT_HIP(ctx, hipMalloc(&ctx->d_blob_s[i], blob.size() * sizeof(double)));
+            XT_HIP(ctx, hipHostMalloc(&ctx->h_blob_s[i], blob.size() * sizeof(double), hipHostMallocDefault));
+        }
         ctx->blob_cap = blob.size();
-    } else {
-        // the pinned staging buffer may still be in flight from the previous evaluation
-        XT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
-    memcpy(ctx->h_blob, blob.data(), blob.size() * sizeof(double));
-    XT_HIP(ctx, hipMemcpyAsync(ctx->d_blob, ctx->h_blob, blob.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    const int slot = (int)(ctx->blob_turn++ & 1u);
+    if (ctx->blob_busy[slot]) XT_HIP(ctx, hipEventSynchronize(ctx->ev_blob[slot]));  // the slot's previous copy has left the host buffer
+    memcpy(ctx->h_blob_s[slot], blob.data(), blob.size() * sizeof(double));
+    XT_HIP(ctx, hipMemcpyAsync(ctx->d_blob_s[slot], ctx->h_blob_s[slot], blob.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    XT_HIP(ctx, hipEventRecord(ctx->ev_blob[slot], ctx->stream));
+    ctx->blob_busy[slot] = true;
+    ctx->d_blob = ctx->d_blob_s[slot];
     return EXTRACK_OK;
 }
 
-// (Re)builds the digit-slot tables when (S, ns, F) changes and uploads the model blob.
-static int xt_prepare(extrack_ctx* ctx, const extrack_model* m)
+// The bucket-descriptor staging area is used in two halves that alternate with the blob slots (same guard events).
+size_t xt_desc_base(const extrack_ctx* ctx) { return (size_t)((ctx->blob_turn - 1u) & 1u) * (XT_DESC_CAP / 2); }
+
+// Posterior output buffer of at least `bytes` bytes (kept for the next call).
+static int xt_reserve_preds(extrack_ctx* ctx, size_t bytes)
+{
+    if (bytes <= ctx->preds_cap) return EXTRACK_OK;
+    XT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->d_preds) (void)hipFree(ctx->d_preds);
+    ctx->d_preds = nullptr;
+    ctx->preds_cap = 0;
+    XT_HIP(ctx, hipMalloc(&ctx->d_preds, bytes));
+    ctx->preds_cap = bytes;
+    return EXTRACK_OK;
+}
+
+// (Re)builds the digit-slot tables when (S, ns, F) changes.
+int xt_prepare_config(extrack_ctx* ctx, const extrack_model* m)
 {
     if (ctx->cfg.S != m->n_states || ctx->cfg.NS != m->nb_substeps || ctx->cfg.F != m->frame_len || !ctx->d_base_tab) {
         XtConfig c;
@@ -465,6 +354,14 @@ static int xt_prepare(extrack_ctx* ctx, const extrack_model* m)
         XT_HIP(ctx, hipMemcpy(ctx->d_off_tab, c.off_tab.data(), c.off_tab.size() * sizeof(int32_t), hipMemcpyHostToDevice));
         ctx->cfg = c;
     }
+    return EXTRACK_OK;
+}
+
+// Digit-slot tables + model blob of one evaluation.
+static int xt_prepare(extrack_ctx* ctx, const extrack_model* m)
+{
+    int rc = xt_prepare_config(ctx, m);
+    if (rc) return rc;
     XtModelHost mh;
     xt_model_host(m, mh);
     std::vector<double> blob;
@@ -544,6 +441,9 @@ struct DevLauncher {
         memcpy(ctx->h_desc + desc_off, descs.data(), nb * sizeof(XtBucketDesc));
         herr = hipMemcpyAsync(ctx->d_desc + desc_off, ctx->h_desc + desc_off, nb * sizeof(XtBucketDesc), hipMemcpyHostToDevice, ctx->stream);
         if (herr != hipSuccess) return true;
+        // the staging half is reusable once this copy is done too: move the slot's guard event behind it
+        herr = hipEventRecord(ctx->ev_blob[(ctx->blob_turn - 1u) & 1u], ctx->stream);
+        if (herr != hipSuccess) return true;
         a.desc = ctx->d_desc + desc_off;
         a.ndesc = nb;
         hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, ctx->stream, a);
@@ -552,7 +452,7 @@ struct DevLauncher {
     }
 };
 
-static int xt_reserve_partials(extrack_ctx* ctx, size_t n)
+int xt_reserve_partials(extrack_ctx* ctx, size_t n)
 {
     if (n <= ctx->partials_cap) return EXTRACK_OK;
     XT_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -638,7 +538,7 @@ static int xt_launch_group(extrack_ctx* ctx, const extrack_model* m, const std::
 }
 
 // Upper bound of the blocks of one launch (= partial-sum slots to reserve).
-static size_t xt_max_grid(const extrack_ctx* ctx) { return (size_t)ctx->n_cu * 8 * ctx->oversub + XT_MAX_BUCKETS; }
+size_t xt_max_grid(const extrack_ctx* ctx) { return (size_t)ctx->n_cu * 8 * ctx->oversub + XT_MAX_BUCKETS; }
 
 static int xt_loglik_enqueue(extrack_ctx* ctx, const extrack_model* m, double* d_total, bool per_track)
 {
@@ -661,12 +561,12 @@ static int xt_loglik_enqueue(extrack_ctx* ctx, const extrack_model* m, double* d
             groups.emplace_back();
         groups.back().push_back(b);
     }
-    if (order.size() > (size_t)XT_DESC_CAP) return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "too many buckets");
+    if (order.size() > (size_t)XT_DESC_CAP / 2) return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "too many buckets");
     if ((rc = xt_reserve_partials(ctx, groups.size() * xt_max_grid(ctx)))) return rc;
     if (per_track)
         for (auto& b : ctx->buckets)
             if (!b.d_ll) XT_HIP(ctx, hipMalloc(&b.d_ll, (size_t)b.N * sizeof(double)));
-    size_t poff = 0, doff = 0;
+    size_t poff = 0, doff = xt_desc_base(ctx);
     XT_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     for (auto& g : groups) {
         int grid = 0;
@@ -717,12 +617,12 @@ extern "C" int extrack_predict(extrack_ctx* ctx, const extrack_model* m, int32_t
     if ((rc = xt_reserve_partials(ctx, xt_max_grid(ctx)))) return rc;
     XtBucket& b = ctx->buckets[bucket_id];
     const size_t nb = (size_t)b.N * b.L * m->n_states * sizeof(double);
-    double* d_preds = nullptr;
-    XT_HIP(ctx, hipMalloc(&d_preds, nb));
+    if ((rc = xt_reserve_preds(ctx, nb))) return rc;
+    double* d_preds = ctx->d_preds;
     int grid = 0;
     hipError_t e = hipEventRecord(ctx->ev0, ctx->stream);
     std::vector<XtBucket*> one(1, &b);
-    rc = xt_launch_group(ctx, m, one, true, false, d_preds, 0, 0, &grid);
+    rc = xt_launch_group(ctx, m, one, true, false, d_preds, 0, xt_desc_base(ctx), &grid);
     if (rc == EXTRACK_OK) {
         if (e == hipSuccess) e = hipEventRecord(ctx->ev1, ctx->stream);
         ctx->timed = true;
@@ -730,7 +630,6 @@ extern "C" int extrack_predict(extrack_ctx* ctx, const extrack_model* m, int32_t
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) rc = xt_fail(ctx, EXTRACK_E_HIP, std::string("predict: ") + hipGetErrorString(e));
     }
-    (void)hipFree(d_preds);
     return rc;
 }
 
@@ -1084,10 +983,12 @@ static int xt_th_run_group(extrack_ctx* ctx, const extrack_model* m, const std::
     return EXTRACK_OK;
 }
 
-extern "C" int extrack_loglik_th(extrack_ctx* ctx, const extrack_model* m, double threshold, int32_t max_nb_states, int32_t chunk,
-                                 double* total_ll, double* per_track)
+// Enqueues one threshold-fusion evaluation; the scalar ends up in d_total (device).  The plan kernel's status words are read back
+// between the plan and the apply launch (the apply geometry depends on the live-sequence counts), everything after that is
+// stream-ordered.
+static int xt_loglik_th_enqueue(extrack_ctx* ctx, const extrack_model* m, double threshold, int32_t max_nb_states, int32_t chunk,
+                                double* d_total, bool per_track)
 {
-    if (!ctx || !total_ll) return xt_fail(ctx, EXTRACK_E_INVALID, "null argument");
     int rc = xt_validate_model(ctx, m);
     if (rc) return rc;
     if (ctx->buckets.empty()) return xt_fail(ctx, EXTRACK_E_INVALID, "no bucket uploaded");
@@ -1119,13 +1020,29 @@ extern "C" int extrack_loglik_th(extrack_ctx* ctx, const extrack_model* m, doubl
         size_t jn = i;
         std::vector<XtBucket*> grp;
         while (jn < order.size() && order[jn]->D == order[i]->D && order[jn]->KS == order[i]->KS) grp.push_back(order[jn++]);
-        if ((rc = xt_th_run_group(ctx, m, grp, threshold, max_nb_states, chunk, G, per_track != nullptr, poff))) return rc;
+        if ((rc = xt_th_run_group(ctx, m, grp, threshold, max_nb_states, chunk, G, per_track, poff))) return rc;
         i = jn;
     }
     XT_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     ctx->timed = true;
-    hipLaunchKernelGGL(xt_reduce_partials, dim3(1), dim3(256), 0, ctx->stream, ctx->d_partials, (int)poff, ctx->d_total);
+    hipLaunchKernelGGL(xt_reduce_partials, dim3(1), dim3(256), 0, ctx->stream, ctx->d_partials, (int)poff, d_total);
     XT_HIP(ctx, hipGetLastError());
+    return EXTRACK_OK;
+}
+
+extern "C" int extrack_loglik_th_async(extrack_ctx* ctx, const extrack_model* m, double threshold, int32_t max_nb_states, int32_t chunk,
+                                       double* d_total_ll)
+{
+    if (!ctx) return EXTRACK_E_INVALID;
+    return xt_loglik_th_enqueue(ctx, m, threshold, max_nb_states, chunk, d_total_ll ? d_total_ll : ctx->d_total, false);
+}
+
+extern "C" int extrack_loglik_th(extrack_ctx* ctx, const extrack_model* m, double threshold, int32_t max_nb_states, int32_t chunk,
+                                 double* total_ll, double* per_track)
+{
+    if (!ctx || !total_ll) return xt_fail(ctx, EXTRACK_E_INVALID, "null argument");
+    int rc = xt_loglik_th_enqueue(ctx, m, threshold, max_nb_states, chunk, ctx->d_total, per_track != nullptr);
+    if (rc) return rc;
     XT_HIP(ctx, hipMemcpyAsync(ctx->h_total, ctx->d_total, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     if (per_track) {
         size_t o = 0;
@@ -1180,8 +1097,8 @@ extern "C" int extrack_predict_th(extrack_ctx* ctx, const extrack_model* m, int3
     }
     if (!((K == 1) || (K == D && D > 1))) return xt_fail(ctx, EXTRACK_E_INVALID, "locerr_dims must be 1 or the track dimensionality");
     const size_t nbytes = (size_t)b.N * b.L * S * sizeof(double);
-    double* d_preds = nullptr;
-    XT_HIP(ctx, hipMalloc(&d_preds, nbytes));
+    if ((rc = xt_reserve_preds(ctx, nbytes))) return rc;
+    double* d_preds = ctx->d_preds;
     XtThArgs a;
     memset(&a, 0, sizeof(a));
     a.tracks = b.d_tracks;
@@ -1206,10 +1123,7 @@ extern "C" int extrack_predict_th(extrack_ctx* ctx, const extrack_model* m, int3
     a.pair_lanes_max_p = ctx->th_pair_lanes;
     int32_t* d_status = nullptr;
     hipError_t e = hipMalloc(&d_status, (size_t)a.nchunks * 4 * sizeof(int32_t));
-    if (e != hipSuccess) {
-        (void)hipFree(d_preds);
-        return xt_fail(ctx, EXTRACK_E_HIP, std::string("predict_th: ") + hipGetErrorString(e));
-    }
+    if (e != hipSuccess) return xt_fail(ctx, EXTRACK_E_HIP, std::string("predict_th: ") + hipGetErrorString(e));
     a.status = d_status;
     rc = EXTRACK_OK;
     (void)hipEventRecord(ctx->ev0, ctx->stream);
@@ -1319,7 +1233,6 @@ extern "C" int extrack_predict_th(extrack_ctx* ctx, const extrack_model* m, int3
         if (e != hipSuccess) rc = xt_fail(ctx, EXTRACK_E_HIP, std::string("predict_th: ") + hipGetErrorString(e));
     }
     (void)hipFree(d_status);
-    (void)hipFree(d_preds);
     return rc;
 }
 

@@ -1,0 +1,167 @@
+// Host-side state of libextrack_hip.so shared by its translation units (extrack_hip.hip: likelihood / posterior / threshold-fusion
+// entry points; extrack_grad.hip: likelihood + gradient; extrack_hist.hip: state-duration histograms) and the device-side
+// execution context the kernel bodies are written against.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/extrack_hip.h"
+#include "xt_kernel.h"
+#include "xt_tables.h"
+#include "xt_th.h"
+
+// ------------------------------------------------------------------------------------------------
+// device side
+// ------------------------------------------------------------------------------------------------
+extern __shared__ double xt_smem[];
+
+struct DevCtx {
+    __device__ __forceinline__ int tid() const { return threadIdx.x; }
+    __device__ __forceinline__ int nthreads() const { return blockDim.x; }
+    __device__ __forceinline__ int block() const { return blockIdx.x; }
+    __device__ __forceinline__ int nblocks() const { return gridDim.x; }
+    __device__ __forceinline__ double* smem() const { return xt_smem; }
+    __device__ __forceinline__ void sync() { __syncthreads(); }
+    __device__ __forceinline__ int lane() const { return threadIdx.x & 63; }
+    // promise that v is the same in every lane of the wavefront (moves it to an SGPR: scalar loads, scalar address math)
+    __device__ __forceinline__ int uniform(int v) const { return __builtin_amdgcn_readfirstlane(v); }
+    __device__ __forceinline__ int wave_in_block() const { return threadIdx.x >> 6; }
+    __device__ __forceinline__ int waves_per_block() const { return blockDim.x >> 6; }
+    // LDS operations of one wavefront execute in order; only the compiler must be kept from moving
+    // LDS accesses across the point where other lanes' data is consumed.
+    __device__ __forceinline__ void wave_sync()
+    {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    __device__ __forceinline__ unsigned long long ballot(bool flag) { return __ballot(flag); }
+    // number of lanes below this one with flag set; total = lanes of the wave with flag set
+    __device__ __forceinline__ int wave_rank(bool flag, int& total)
+    {
+        const unsigned long long b = __ballot(flag);
+        total = __popcll(b);
+        return __popcll(b & ((1ull << (threadIdx.x & 63)) - 1ull));
+    }
+    __device__ __forceinline__ int shfl_xor_i32(int v, int m) { return __shfl_xor(v, m, 64); }
+    __device__ __forceinline__ double shfl_xor_f64(double v, int m) { return __shfl_xor(v, m, 64); }
+    __device__ __forceinline__ void atomic_max_i32(int* p, int v)
+    {
+        __hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    __device__ __forceinline__ void atomic_or_u32(uint32_t* p, uint32_t v)
+    {
+        __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    __device__ __forceinline__ void atomic_add_f64(double* p, double v)
+    {
+        __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+};
+
+// MAXT: 256 for the common one-wave-set-per-few-tracks geometry (lets the allocator use up to 256
+// VGPRs at 2 waves/SIMD if it needs them), 1024 when one track's groups need more than 256 threads.
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+struct XtBucket {
+    const double* d_tracks = nullptr;
+    const double* d_sigma = nullptr;
+    bool owned = false;
+    int64_t N = 0;
+    int L = 0, D = 0, KS = 0;
+    double* d_ll = nullptr;  // per-track output, allocated on first request
+    // threshold-fusion plan of the last extrack_loglik_th call (xt_th.h)
+    uint16_t* th_members = nullptr;
+    uint32_t* th_mpack = nullptr;
+    uint8_t* th_gnew = nullptr;
+    uint16_t* th_gstart = nullptr;
+    int32_t* th_hdr = nullptr;
+    int32_t* th_status = nullptr;
+    int th_capE = 0, th_chunk = 0;
+    int64_t th_nchunks = 0;
+};
+
+struct extrack_ctx {
+    int device = 0;
+    int n_cu = 0;
+    int oversub = 8;  // block generations per CU (EXTRACK_OVERSUB overrides; tuning knob)
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    std::vector<XtBucket> buckets;
+    XtConfig cfg;
+    int32_t* d_base_tab = nullptr;
+    int32_t* d_off_tab = nullptr;
+    // model blob: two (pinned host, device) staging slots used alternately, each guarded by an event recorded after its
+    // host->device copy, so that an evaluation never waits for the previous one (extrack_loglik_async stays asynchronous)
+    double* d_blob = nullptr;       // slot in use by the evaluation being enqueued
+    double* d_blob_s[2] = {nullptr, nullptr};
+    double* h_blob_s[2] = {nullptr, nullptr};  // pinned
+    hipEvent_t ev_blob[2] = {nullptr, nullptr};
+    bool blob_busy[2] = {false, false};
+    size_t blob_cap = 0;
+    unsigned blob_turn = 0;
+    double* d_preds = nullptr;      // posterior output buffer, kept between extrack_predict / extrack_predict_th calls
+    size_t preds_cap = 0;
+    double* d_partials = nullptr;
+    size_t partials_cap = 0;
+    double* d_total = nullptr;
+    double* h_total = nullptr;  // pinned
+    XtBucketDesc* d_desc = nullptr;  // [XT_DESC_CAP] bucket descriptors of the launches of one evaluation
+    XtBucketDesc* h_desc = nullptr;  // pinned staging
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+    int32_t launch_info[6] = {0, 0, 0, 0, 0, 0};
+    std::map<std::pair<const void*, std::pair<int, size_t>>, int> occ_cache;
+    double* d_th_ws = nullptr;  // plan-kernel workspace
+    size_t th_ws_cap = 0;
+    int th_capE = 128;          // plan capacity (expanded sequences per step); grows on overflow
+    int th_learnP = 0, th_learnE = 0;  // live parent / expanded sequence counts seen by the last plan (+ headroom): LDS workspace sizing
+    std::vector<int32_t> th_status_host;
+    int32_t* h_th_status = nullptr;  // pinned: plan status of every chunk of a launch group
+    int32_t* d_th_status = nullptr;
+    size_t th_status_cap = 0;        // ints
+    XtThBucket* d_th_desc = nullptr;  // bucket descriptors of a launch group
+    size_t th_desc_cap = 0;
+    int32_t* d_th_cend = nullptr;     // chunk prefix of a launch group
+    size_t th_cend_cap = 0;
+    float th_plan_ms = 0.f;
+    int th_force_single = 0;
+    int th_pair_lanes = 4;  // EXTRACK_TH_PAIR_LANES
+    int th_stage_in_lds_mode = 0;  // EXTRACK_TH_STAGE_LDS: LDS-typed copy of the pilot means/stds also when the state is in LDS (measured: no gain)
+    int th_no_gen_single = 0;  // EXTRACK_TH_NO_GEN_SINGLE: never use the one-buffer general apply variant
+    int th_plan_threads = 512;  // workgroup size of the plan kernel (EXTRACK_TH_PLAN_THREADS)
+    int th_force_tt = 0, th_force_threads = 0, th_oversub = 2;  // tuning knobs (EXTRACK_TH_TT / _THREADS / _OVERSUB)
+    std::string err;
+};
+
+static const int XT_DESC_CAP = 4096;  // bucket descriptors per evaluation (buckets beyond 64 per launch group are chunked)
+
+
+#define XT_HIP(ctx, call)                                                                       \
+    do {                                                                                        \
+        hipError_t e__ = (call);                                                                \
+        if (e__ != hipSuccess) {                                                                \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e__);                    \
+            return EXTRACK_E_HIP;                                                               \
+        }                                                                                       \
+    } while (0)
+
+// shared host helpers (defined in extrack_hip.hip)
+int xt_fail(extrack_ctx* ctx, int code, const std::string& msg);
+int xt_validate_model(extrack_ctx* ctx, const extrack_model* m);
+void xt_model_host(const extrack_model* m, XtModelHost& mh);
+int xt_upload_blob(extrack_ctx* ctx, const std::vector<double>& blob);   // -> ctx->d_blob (double-buffered staging)
+int xt_prepare_config(extrack_ctx* ctx, const extrack_model* m);         // digit-slot tables of (S, ns, F) -> ctx->cfg, d_base_tab, d_off_tab
+int xt_reserve_partials(extrack_ctx* ctx, size_t n);
+size_t xt_desc_base(const extrack_ctx* ctx);
+size_t xt_max_grid(const extrack_ctx* ctx);
+__global__ void xt_reduce_partials(const double* __restrict__ partials, int n, double* __restrict__ out);

@@ -12,11 +12,9 @@ import numpy as np
 
 
 def shard_range(n, rank, world, chunk=None):
-    """Contiguous rows [start, stop) of a bucket of n tracks owned by `rank` (balanced to +-1).
-
-    With ``chunk`` the unit of distribution is a whole chunk of ``chunk`` consecutive tracks: the threshold-fusion kernel
-    takes its merge decisions per chunk (extrack/tracking.py:678-679, 1043), so a shard boundary inside a chunk would change
-    the result; with chunk-aligned shards every rank evaluates exactly the chunks a single GPU would."""
+    """Contiguous rows [start, stop) of ONE bucket of n tracks owned by `rank` (balanced to +-1 row, or +-1 chunk with ``chunk``).
+    Used where every bucket is split on its own (``predict_Bs``: rank order == row order); the objective's shards come from
+    ``shard_plan``, which balances the remainders over all buckets."""
     if chunk:
         nch = -(-int(n) // int(chunk))
         a, z = shard_range(nch, rank, world)
@@ -24,6 +22,36 @@ def shard_range(n, rank, world, chunk=None):
     base, rem = divmod(int(n), int(world))
     start = rank * base + min(rank, rem)
     return start, start + base + (1 if rank < rem else 0)
+
+
+def shard_plan(sizes, lengths, world, chunk=None):
+    """Row ranges of every bucket for every rank: ``plan[b][r] = (start, stop)``, contiguous and in rank order inside a bucket.
+
+    The unit of distribution is one track, or - with ``chunk`` - a whole chunk of ``chunk`` consecutive tracks: the
+    threshold-fusion kernel takes its merge decisions per chunk (extrack/tracking.py:678-679, 1043), so a shard boundary inside a
+    chunk would change the result; with chunk-aligned shards every rank evaluates exactly the chunks a single GPU would.
+    Every bucket gives ``units // world`` units to each rank; the remaining ``units % world`` go, one each, to the ranks with
+    the least accumulated work (tracks x steps) so far.  A dataset of many small buckets (one chunk each) is thereby dealt
+    round-robin instead of piling up on rank 0, and equal buckets end up balanced to one unit overall, not one unit per bucket.
+    Deterministic: every rank computes the same plan from the same (sizes, lengths)."""
+    world = int(world)
+    load = [0.0] * world
+    plan = []
+    for n, L in zip(sizes, lengths):
+        n = int(n)
+        unit = int(chunk) if chunk else 1
+        units = -(-n // unit)
+        base, rem = divmod(units, world)
+        extra = set(sorted(range(world), key=lambda r: (load[r], r))[:rem])
+        ranges, pos = [], 0
+        for r in range(world):
+            cnt = base + (1 if r in extra else 0)
+            a, z = min(n, pos * unit), min(n, (pos + cnt) * unit)
+            ranges.append((a, z))
+            load[r] += (z - a) * max(int(L) - 1, 1)
+            pos += cnt
+        plan.append(ranges)
+    return plan
 
 
 class Comm:
@@ -54,25 +82,52 @@ class Comm:
 
     # ---- sharding -----------------------------------------------------------------------------------------
     def shard_buckets(self, tracks, sigmas=None, chunk=None):
-        """Row-shards every bucket (in whole chunks when ``chunk`` is given); buckets whose local share is empty are dropped
-        locally."""
+        """Row-shards every bucket per ``shard_plan`` (whole chunks when ``chunk`` is given); buckets whose local share is empty
+        are dropped locally (a rank may end up with no bucket at all: it then contributes 0 to the objective)."""
+        plan = shard_plan([len(b) for b in tracks], [b.shape[1] for b in tracks], self.world, chunk)
         t_out, s_out = [], ([] if sigmas is not None else None)
         for i, b in enumerate(tracks):
-            a, z = shard_range(len(b), self.rank, self.world, chunk)
+            a, z = plan[i][self.rank]
             if z > a:
                 t_out.append(b[a:z])
                 if sigmas is not None:
                     s_out.append(sigmas[i][a:z])
         return t_out, s_out
 
-    def shard_trackset(self, tracks, sigmas=None, device=0, chunk=None):
+    def agree(self, ok, what="an operation"):
+        """Collective error agreement: every rank passes its local success flag; if ANY rank failed, all ranks raise here, so that
+        no rank walks on into a collective its peers will never join."""
+        if self.allreduce_scalar(1.0 if ok else 0.0, "min") < 0.5:
+            raise RuntimeError("%s failed on at least one rank%s" % (what, "" if ok else " (this one: rank %d)" % self.rank))
+
+    def local_device(self):
+        """GPU index this rank's kernels run on: the device of the communicator (nccl), else 0."""
+        d = str(self.device)
+        return int(d.split(":")[1]) if d.startswith("cuda:") else 0
+
+    def shard_trackset(self, tracks, sigmas=None, device=None, chunk=None):
+        """Uploads this rank's shard of ``tracks`` (the WHOLE dataset, same list on every rank) to its GPU.  ``min_len`` /
+        ``max_len`` are the dataset-global ones.  A rank left without tracks gets an empty TrackSet (objective 0.0)."""
         from .engine import TrackSet
-        lo, hi = self.global_min_max_len([b.shape[1] for b in tracks if len(b)])
-        t_loc, s_loc = self.shard_buckets(tracks, sigmas, chunk)
-        if not t_loc:
-            raise ValueError("rank %d received no tracks: fewer tracks%s than ranks" % (self.rank, " (chunks)" if chunk else ""))
-        ts = TrackSet(t_loc, s_loc, device=device, min_len=lo, max_len=hi)
-        ts.shard_chunk = chunk  # chunk alignment of the shard boundaries (None: row-balanced)
+        lens = [b.shape[1] for b in tracks if len(b)]
+        lo, hi = self.global_min_max_len(lens)
+        if device is None:
+            device = self.local_device()
+        ts, err = None, None
+        try:
+            if not lens:
+                raise ValueError("No track could be detected. The loaded tracks seem empty. Errors often come from wrong input paths.")
+            t_loc, s_loc = self.shard_buckets(tracks, sigmas, chunk)
+            ts = TrackSet(t_loc, s_loc, device=device, min_len=lo, max_len=hi, allow_empty=True)
+            ts.shard_chunk = chunk  # chunk alignment of the shard boundaries (None: row-balanced)
+        except Exception as e:  # agree before raising: a lone raising rank would leave the others blocked in the next collective
+            err = e
+        try:
+            self.agree(err is None, "sharding the dataset")
+        except RuntimeError:
+            if ts is not None:
+                ts.close()
+            raise err if err is not None else RuntimeError("sharding the dataset failed on another rank")
         return ts
 
     # ---- posteriors: no collective in the data path, only an ordered gather of the per-rank row blocks ------------
@@ -90,18 +145,37 @@ class Comm:
         if getattr(ts, "shard_chunk", None) != chunk:
             raise ValueError("fusion='threshold' needs shards aligned to the %d-track chunks (Comm.shard_trackset(..., chunk=%d))"
                              % (chunk, chunk))
+        if ts.n_tracks == 0:
+            return self.allreduce_scalar(0.0, "sum")
+        if self.backend == "nccl":
+            buf = self._device_buffer(ts)
+            ts.ctx.loglik_th_async(model, threshold, max_nb_states, chunk, buf.data_ptr())  # stream-ordered, no host round trip
+            self.dist.all_reduce(buf, op=self.dist.ReduceOp.SUM, group=self.group)
+            return float(buf.item())
         return self.allreduce_scalar(ts.loglik_th(model, threshold, max_nb_states, chunk), "sum")
+
+    def _device_buffer(self, ts):
+        """fp64 scalar on this rank's GPU + the context bound to torch's current stream (kernels and the collective are ordered
+        on one stream)."""
+        torch = self.torch
+        if self._buf is None:
+            self._buf = torch.zeros(1, dtype=torch.float64, device=self.device)
+        if ts.n_tracks and self._buf.device.index != ts.ctx.device:
+            raise RuntimeError("the TrackSet lives on GPU %d but the communicator reduces on %s: pass device=%d (LOCAL_RANK) when "
+                               "building it" % (ts.ctx.device, self._buf.device, self._buf.device.index))
+        if ts.n_tracks:
+            ts.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        return self._buf
 
     # ---- the per-evaluation collective ----------------------------------------------------------------------
     def allreduce_loglik(self, ts, model):
         """Local sum of log-likelihoods on this rank's GPU -> all-reduce(sum) -> python float."""
         if self.backend == "nccl":
-            torch = self.torch
-            if self._buf is None:
-                self._buf = torch.zeros(1, dtype=torch.float64, device=self.device)
-            stream = torch.cuda.current_stream()
-            ts.ctx.set_stream(stream.cuda_stream)  # kernels and the collective are ordered on one stream
-            ts.ctx.loglik_async(model, self._buf.data_ptr())
-            self.dist.all_reduce(self._buf, op=self.dist.ReduceOp.SUM, group=self.group)
-            return float(self._buf.item())
-        return self.allreduce_scalar(ts.loglik(model), "sum")
+            buf = self._device_buffer(ts)
+            if ts.n_tracks:
+                ts.ctx.loglik_async(model, buf.data_ptr())
+            else:
+                buf.zero_()
+            self.dist.all_reduce(buf, op=self.dist.ReduceOp.SUM, group=self.group)
+            return float(buf.item())
+        return self.allreduce_scalar(ts.loglik(model) if ts.n_tracks else 0.0, "sum")

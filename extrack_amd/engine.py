@@ -69,8 +69,10 @@ class TrackSet:
     dataset must be given the global ones (extrack/tracking.py:1009-1010 uses the whole list).
     """
 
-    def __init__(self, buckets, sigmas=None, device=0, min_len=None, max_len=None):
-        if len(buckets) < 1:
+    def __init__(self, buckets, sigmas=None, device=0, min_len=None, max_len=None, allow_empty=False):
+        """allow_empty: a shard of a distributed dataset may hold no track at all (its objective is 0.0, its posteriors are
+        empty); the dataset-global ``min_len`` / ``max_len`` must then be given."""
+        if len(buckets) < 1 and not allow_empty:
             raise ValueError("No track could be detected. The loaded tracks seem empty. Errors often come from wrong input paths.")
         self.ctx = _lib.Context(device)
         self.shapes = []
@@ -86,14 +88,15 @@ class TrackSet:
             if len(b):
                 self.ctx.upload_bucket(b, s)
                 self.shapes.append(b.shape)
-        if not self.shapes:
+        if not self.shapes and not (allow_empty and min_len is not None and max_len is not None):
+            self.ctx.close()
             raise ValueError("No track could be detected. The loaded tracks seem empty. Errors often come from wrong input paths.")
         lens = [s[1] for s in self.shapes]
         self.min_len = int(min(lens) if min_len is None else min_len)
         self.max_len = int(max(lens) if max_len is None else max_len)
         self.has_sigma = sigmas is not None
         self.n_tracks = int(sum(s[0] for s in self.shapes))
-        self.dims = int(self.shapes[0][2])
+        self.dims = int(self.shapes[0][2]) if self.shapes else 0
 
     # ---- model handle -------------------------------------------------------------------------------------
     def make_model(self, LocErr, ds, Fs, TrMat, pBL, cell_dims, nb_substeps, frame_len, slope_offset=None):
@@ -109,7 +112,7 @@ class TrackSet:
             slope, offset = slope_offset if slope_offset is not None else (0.0, 0.0)
         else:
             le = np.asarray(LocErr, float).reshape(-1)
-            if len(le) not in (1, self.dims):
+            if len(le) not in (1, self.dims) and self.shapes:
                 raise ValueError("Localization error is not specified correctly, in case of unique localization error specify a float "
                                  "number; if one localization error per dimension, specify one value per dimension")
             mode, slope, offset = 0, 0.0, 0.0
@@ -117,9 +120,13 @@ class TrackSet:
                                 locerr_mode=mode, slope=slope, offset=offset)
 
     def loglik(self, model, per_track=False):
+        if not self.shapes:
+            return (0.0, np.empty(0)) if per_track else 0.0
         return self.ctx.loglik(model, per_track=per_track)
 
     def loglik_th(self, model, threshold=0.2, max_nb_states=120, chunk=2000, per_track=False):
+        if not self.shapes:
+            return (0.0, np.empty(0)) if per_track else 0.0
         return self.ctx.loglik_th(model, threshold, max_nb_states, chunk, per_track=per_track)
 
     def predict_th(self, model, threshold=0.1, max_nb_states=200, nb_max=1):

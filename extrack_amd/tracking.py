@@ -23,6 +23,8 @@ keyword ``fusion``:
                                  tracks (tracking.py:856-868; nb_max <= 30).
 ``workers`` is accepted and ignored: the tracks are sharded over GPUs instead (extrack_amd.distributed).
 """
+import os
+
 import numpy as np
 from scipy import linalg
 
@@ -177,6 +179,8 @@ def get_params(nb_states=2, steady_state=False, vary_params=_GP_VARY, estimated_
 
 
 def _check_fusion(fusion):
+    if fusion is None:
+        fusion = default_fusion()
     if fusion not in ("window", "threshold"):
         raise ValueError("fusion must be 'window' or 'threshold'")
     return fusion == "threshold"
@@ -243,22 +247,32 @@ def P_Cs_inter_bound_stats(Cs, LocErr, ds, Fs, TrMat, pBL=0.1, isBL=1, cell_dims
 # ------------------------------------------------------------------------------------------------------------
 # objective
 # ------------------------------------------------------------------------------------------------------------
-_TRACKSET_CACHE = {}
+def default_fusion():
+    """Kernel used when a call does not pass ``fusion=``: "window" (the fixed-window kernel BASELINE.json names) unless the
+    environment variable ``EXTRACK_FUSION=threshold`` selects the kernel extrack.tracking runs in v1.6.3 for the whole process."""
+    return os.environ.get("EXTRACK_FUSION", "window").strip().lower() or "window"
 
 
-def _as_trackset(all_tracks, input_LocErr, device=0):
-    """The reference hands the objective a list of arrays at every call; keep ONE device copy per list."""
+def _resolve_device(device, comm):
+    """GPU index: explicit, else the communicator's device (LOCAL_RANK under torchrun), else 0."""
+    if device is not None:
+        return int(device)
+    return comm.local_device() if comm is not None else 0
+
+
+def _as_trackset(all_tracks, input_LocErr, device=None, comm=None):
+    """(TrackSet, owned).  A ``TrackSet`` is used as is.  A list of bucket arrays (what the reference's objective receives at
+    every call) is uploaded for THIS call only and released afterwards (``owned``): device copies are never cached behind the
+    caller's back, so edited or re-allocated arrays can not be confused with earlier ones.  Keep a ``TrackSet`` (or use
+    ``param_fitting``) to pay the upload once.  With ``comm`` the list is this rank's shard and the dataset-global
+    min / max length are agreed over the ranks (collective)."""
     if isinstance(all_tracks, TrackSet):
-        return all_tracks
-    key = (tuple((id(a), a.shape, a.__array_interface__["data"][0]) for a in all_tracks),
-           None if input_LocErr is None else tuple(id(a) for a in input_LocErr), device)
-    ts = _TRACKSET_CACHE.get(key)
-    if ts is None:
-        while len(_TRACKSET_CACHE) >= 2:
-            _TRACKSET_CACHE.pop(next(iter(_TRACKSET_CACHE))).close()
-        ts = TrackSet(list(all_tracks), input_LocErr, device=device)
-        _TRACKSET_CACHE[key] = ts
-    return ts
+        return all_tracks, False
+    dev = _resolve_device(device, comm)
+    if comm is None:
+        return TrackSet(list(all_tracks), input_LocErr, device=dev), True
+    lo, hi = comm.global_min_max_len([np.shape(b)[1] for b in all_tracks if len(b)])
+    return TrackSet(list(all_tracks), input_LocErr, device=dev, min_len=lo, max_len=hi, allow_empty=True), True
 
 
 def _objective_model(params, ts, dt, cell_dims, input_LocErr, nb_states, nb_substeps, frame_len, Matrix_type):
@@ -273,24 +287,33 @@ def _objective_model(params, ts, dt, cell_dims, input_LocErr, nb_states, nb_subs
 
 
 def cum_Proba_Cs(params, all_tracks, dt, cell_dims, input_LocErr, nb_states, nb_substeps, frame_len, verbose=1, workers=1,
-                 Matrix_type=1, threshold=0.2, max_nb_states=120, max_number_of_tracks_per_matrix=2000, comm=None, fusion="window"):
+                 Matrix_type=1, threshold=0.2, max_nb_states=120, max_number_of_tracks_per_matrix=2000, comm=None, fusion=None,
+                 device=None):
     """-sum of per-track log-likelihoods, or +inf for invalid parameters / NaN (extrack/tracking.py:991-1088).
 
-    ``all_tracks``: list of bucket arrays sorted short->long (as the reference passes it) or a ``TrackSet``.
-    ``comm``: optional extrack_amd.distributed.Comm; when given, ``all_tracks`` is this rank's shard and the
-    scalar is all-reduced over the ranks.  ``fusion="threshold"``: the v1.6.3 kernel with ``threshold``, ``max_nb_states`` and
-    chunks of ``max_number_of_tracks_per_matrix`` tracks (the chunking is part of the result: with ``comm`` the shards must be
-    whole chunks, ``Comm.shard_trackset(..., chunk=...)``)."""
+    ``all_tracks``: a ``TrackSet`` (device-resident, reused between calls) or the list of bucket arrays sorted short->long that
+    the reference passes (uploaded for this call only).  ``comm``: optional extrack_amd.distributed.Comm; ``all_tracks`` is
+    then this rank's shard - preferably the ``TrackSet`` made by ``comm.shard_trackset`` - and the scalar is all-reduced over
+    the ranks.  ``fusion="threshold"``: the v1.6.3 kernel with ``threshold``, ``max_nb_states`` and chunks of
+    ``max_number_of_tracks_per_matrix`` tracks (the chunking is part of the result: with ``comm`` the shards must be whole chunks,
+    ``Comm.shard_trackset(..., chunk=...)``).  ``fusion=None``: the process default (``EXTRACK_FUSION``, else "window")."""
     th = _check_fusion(fusion)
-    ts = _as_trackset(all_tracks, input_LocErr)
-    model = _objective_model(params, ts, dt, cell_dims, input_LocErr, nb_states, nb_substeps, frame_len, Matrix_type)
+    if th and comm is not None and not isinstance(all_tracks, TrackSet):
+        raise ValueError("fusion='threshold' with comm needs chunk-aligned shards: pass the TrackSet of comm.shard_trackset(..., chunk=...)")
+    ts, owned = _as_trackset(all_tracks, input_LocErr, device, comm)
+    try:
+        model = _objective_model(params, ts, dt, cell_dims, input_LocErr, nb_states, nb_substeps, frame_len, Matrix_type)
+        if model is not None:
+            if th and comm is not None:  # shards are whole chunks, so the chunking is that of the unsharded dataset
+                Cum_P = comm.allreduce_loglik_th(ts, model, threshold, max_nb_states, max_number_of_tracks_per_matrix)
+            elif th:
+                Cum_P = ts.loglik_th(model, threshold, max_nb_states, max_number_of_tracks_per_matrix)
+            else:
+                Cum_P = ts.loglik(model) if comm is None else comm.allreduce_loglik(ts, model)
+    finally:
+        if owned:
+            ts.close()
     if model is not None:
-        if th and comm is not None:  # shards are whole chunks, so the chunking is that of the unsharded dataset
-            Cum_P = comm.allreduce_loglik_th(ts, model, threshold, max_nb_states, max_number_of_tracks_per_matrix)
-        elif th:
-            Cum_P = ts.loglik_th(model, threshold, max_nb_states, max_number_of_tracks_per_matrix)
-        else:
-            Cum_P = ts.loglik(model) if comm is None else comm.allreduce_loglik(ts, model)
         if verbose == 1:
             q = [p + " = " + str(np.round(params[p].value, 6)) for p in params]
             print(Cum_P, q)
@@ -313,13 +336,15 @@ def cum_Proba_Cs(params, all_tracks, dt, cell_dims, input_LocErr, nb_states, nb_
 # ------------------------------------------------------------------------------------------------------------
 def param_fitting(all_tracks, dt, params=None, nb_states=2, nb_substeps=1, frame_len=6, verbose=1, workers=1, Matrix_type=1,
                   method="bfgs", steady_state=False, cell_dims=[1], input_LocErr=None, threshold=0.2, max_nb_states=120,
-                  device=0, comm=None, fusion="window"):
+                  device=None, comm=None, fusion=None):
     """Fit the model parameters to a length-bucketed track dict (extrack/tracking.py:1299-1386).
 
     all_tracks: {str(len): ndarray[n_tracks, len, dims]}.  Returns the lmfit (or lmfit_compat) MinimizerResult:
-    ``.params[name].value``, ``.residual[0] == -log-likelihood``.  Extra keywords: ``device`` (GPU index) and
-    ``comm`` (distributed shard communicator), ``fusion`` ("window" | "threshold", see the module docstring)."""
-    _check_fusion(fusion)
+    ``.params[name].value``, ``.residual[0] == -log-likelihood``.  Extra keywords: ``device`` (GPU index; default: the
+    communicator's device, else 0), ``comm`` (distributed shard communicator: every rank passes the WHOLE dataset and keeps its
+    shard), ``fusion`` ("window" | "threshold" | None = process default, see the module docstring)."""
+    fusion = "threshold" if _check_fusion(fusion) else "window"
+    device = _resolve_device(device, comm)
     if params is None:
         params = generate_params(nb_states=nb_states, LocErr_type=1, LocErr_bounds=[0.005, 0.1], D_max=3,
                                  Fractions_bounds=[0.001, 0.99], estimated_transition_rates=0.1)
@@ -347,7 +372,7 @@ def param_fitting(all_tracks, dt, params=None, nb_states=2, nb_substeps=1, frame
 
 
 def predict_Bs(all_tracks, dt, params, cell_dims=[1], nb_states=4, frame_len=5, max_nb_states=200, threshold=0.1, workers=1,
-               input_LocErr=None, verbose=0, nb_max=1, device=0, comm=None, fusion="window"):
+               input_LocErr=None, verbose=0, nb_max=1, device=None, comm=None, fusion=None):
     """Probability of each localisation to be in each state (extrack/tracking.py:792-906).
 
     Returns {str(len): ndarray[n_tracks, len, nb_states]} keyed by every input key (empty arrays for empty
@@ -355,6 +380,8 @@ def predict_Bs(all_tracks, dt, params, cell_dims=[1], nb_states=4, frame_len=5, 
     come from ALL keys (:853-854).  With ``comm`` (extrack_amd.distributed.Comm) every rank annotates its row range of
     every bucket on its own GPU and rank 0 gets the row-ordered result (other ranks get None); no collective is needed in
     the data path."""
+    fusion = "threshold" if _check_fusion(fusion) else "window"
+    device = _resolve_device(device, comm)
     if comm is not None:
         from .distributed import shard_range
         loc_tracks = {k: np.asarray(v)[slice(*shard_range(len(v), comm.rank, comm.world))] for k, v in all_tracks.items()}

@@ -119,6 +119,10 @@ int extrack_predict(extrack_ctx* ctx, const extrack_model* model, int32_t bucket
  * total_ll / per_track as in extrack_loglik. */
 int extrack_loglik_th(extrack_ctx* ctx, const extrack_model* model, double threshold, int32_t max_nb_states, int32_t chunk,
                       double* total_ll, double* per_track);
+/* Same evaluation, the scalar left in device memory (d_total_ll, 8 bytes) for a following RCCL all-reduce on the context's
+ * stream; nothing is copied back to the host at the end (counterpart of extrack_loglik_async for the threshold-fusion kernel). */
+int extrack_loglik_th_async(extrack_ctx* ctx, const extrack_model* model, double threshold, int32_t max_nb_states, int32_t chunk,
+                            double* d_total_ll);
 /* Threshold-fusion state posteriors of one bucket (P_Cs_inter_bound_stats_th(..., do_preds=1), extrack/tracking.py:427-650,
  * driven as predict_Bs drives it, tracking.py:792-906): preds host [n][len][S].  The bucket is cut into chunks of nb_max
  * consecutive tracks (predict_Bs default: 1, i.e. every track decides its own merges); nb_max <= 30, so that every track of a

@@ -1,6 +1,10 @@
-"""The N>1 path on CPU: world_size-2 gloo process group.  Sharding, the dataset-global min/max length agreement
-and the scalar all-reduce of extrack_amd.distributed are exercised for real; the per-rank likelihood comes from the
-oracle here (no GPU in this container) - on the GPU box the same Comm drives the HIP path over RCCL (bench.py)."""
+"""The N>1 path on CPU: world_size-2 gloo process group driving the PRODUCT call path -
+``Comm.shard_trackset`` -> ``cum_Proba_Cs(comm=...)`` / ``param_fitting(comm=...)`` / ``predict_Bs(comm=...)`` - with ONE
+substitution made in this test only: ``extrack_amd._lib.Context`` (the ctypes front of the HIP library; there is no GPU in
+this container) is replaced by a stand-in that keeps the uploaded buckets on the host and evaluates them with the oracle.
+Everything above the C ABI (sharding plan, dataset-global min/max length, empty-rank handling, chunk-aligned shards of the
+threshold-fusion objective, the scalar all-reduce, the ordered gather of posterior rows, collective error agreement) is the
+code that runs over RCCL on the GPU box."""
 import os
 import socket
 import sys
@@ -9,6 +13,7 @@ import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CELL = [1.0]
 
 
 def _free_port():
@@ -19,74 +24,174 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
-    sys.path.insert(0, ROOT)
-    import torch.distributed as dist
+class OracleContext:
+    """Test-only stand-in for extrack_amd._lib.Context: same methods, likelihoods from oracle/ (CPU)."""
+
+    def __init__(self, device=0):
+        self.device = int(device)
+        self.buckets, self.data = [], []
+
+    def upload_bucket(self, tracks, sigma=None):
+        assert sigma is None
+        self.buckets.append(tracks.shape + (0,))
+        self.data.append(np.array(tracks, float))
+        return len(self.data) - 1
+
+    def n_tracks(self):
+        return sum(b[0] for b in self.buckets)
+
+    def close(self):
+        pass
+
+    def set_stream(self, ptr):
+        pass
+
+    def _model(self, model):
+        c = model.c
+        le = np.array([c.locerr[i] for i in range(c.locerr_dims)])[None, None]
+        return le, model.ds, model.Fs, model.TrMat, c.pBL, c.nb_substeps, c.frame_len, c.min_len, c.max_len
+
+    def loglik(self, model, per_track=False):
+        from oracle import oracle_np as O
+        le, ds, Fs, T, pBL, ns, F, lo, hi = self._model(model)
+        per = [O.proba_cs(b, le, ds, Fs, T, pBL, 0 if b.shape[1] == hi else 1, CELL, ns, F, lo) for b in self.data]
+        per = np.concatenate(per) if per else np.empty(0)
+        return (per.sum(), per) if per_track else per.sum()
+
+    def loglik_th(self, model, threshold=0.2, max_nb_states=120, chunk=2000, per_track=False):
+        from oracle import oracle_th as OT
+        le, ds, Fs, T, pBL, ns, F, lo, hi = self._model(model)
+        tot = 0.0
+        for b in self.data:
+            for a0 in range(0, len(b), chunk):
+                tot += OT.proba_cs_th(b[a0:a0 + chunk], le, ds, Fs, T, pBL, 0 if b.shape[1] == hi else 1, CELL, ns, F, lo, threshold,
+                                      max_nb_states).sum()
+        return tot
+
+    def predict(self, model, bucket_id):
+        from oracle import oracle_np as O
+        le, ds, Fs, T, pBL, ns, F, lo, hi = self._model(model)
+        b = self.data[bucket_id]
+        return O.p_cs_inter_bound_stats(b, le, ds, Fs, T, pBL, 0 if b.shape[1] == hi else 1, CELL, 1, F, 1, lo)[1]
+
+
+def _dataset():
     from extrack_amd import synth
-    from extrack_amd.distributed import Comm, shard_range
-    from oracle import oracle_np as O
+    # the longest bucket has ONE track (one rank owns none of it); 6 small buckets of one 16-track chunk each
+    lens = {5: 41, 9: 30, 12: 1, 6: 16, 7: 16, 8: 16, 10: 16, 11: 16}
+    return {str(L): synth.brownian_tracks(n, L, [0.0, 0.25], [[.9, .1], [.1, .9]], [.6, .4], seed=L) for L, n in lens.items()}
+
+
+def _worker(rank, world, port, q, scenario):
+    sys.path.insert(0, ROOT)
+    import contextlib
+    import io
+    import torch.distributed as dist
+    from extrack_amd import _lib, tracking as T
+    from extrack_amd.distributed import Comm, shard_plan, shard_range
+    from extrack_amd.lmfit_compat import Parameters
+    from oracle import oracle_np as O, oracle_th as OT
+    _lib.Context = OracleContext  # the ONE substitution: no GPU here
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     try:
         comm = Comm()
-        assert comm.backend == "gloo" and comm.world == world
+        assert comm.backend == "gloo" and comm.world == world and comm.local_device() == 0
         vals = dict(D0=1e-3, D1=0.25, LocErr=0.02, F0=0.6, F1=0.4, p01=0.1, p10=0.1, pBL=0.1)
-        lens = {5: 41, 9: 30, 12: 1}  # the longest bucket has ONE track: rank 1 owns none of it
-        tracks = {str(L): synth.brownian_tracks(n, L, [0.0, 0.25], [[.9, .1], [.1, .9]], [.6, .4], seed=L) for L, n in lens.items()}
-        lst = [tracks[k] for k in ("5", "9", "12")]
-        t_loc, _ = comm.shard_buckets(lst)
-        lo, hi = comm.global_min_max_len([b.shape[1] for b in t_loc])
-        assert (lo, hi) == (5, 12)
-        if rank == 1:
-            assert 12 not in [b.shape[1] for b in t_loc]  # local max length differs from the global one
-        # local objective with the GLOBAL min/max length (isBL of each bucket must not depend on the shard)
-        LocErr, ds, Fs, T, pBL = O.extract_params(vals, 0.02, 1, 1)
-        local = 0.0
-        for b in t_loc:
-            local += O.proba_cs(b, LocErr, ds, Fs, T, pBL, 0 if b.shape[1] == hi else 1, [1], 1, 6, lo).sum()
-        total = comm.allreduce_scalar(local, "sum")
-        ref = -O.cum_proba_cs(vals, tracks, 0.02, [1], None, 1, 6)
-        covered = comm.allreduce_scalar(sum(len(b) for b in t_loc), "sum")
-        # ordered gather of per-rank row blocks (what predict_Bs(comm=...) uses): rank 0 must get the rows in input order
-        local = {k: v[slice(*shard_range(len(v), rank, world))] for k, v in tracks.items()}
-        full = comm.gather_rows(local)
-        if rank == 0:
-            assert all(np.array_equal(full[k], tracks[k]) for k in tracks)
-        else:
-            assert full is None
-        # threshold-fusion objective: shards are whole chunks, so every chunk keeps the pilot tracks it has on one GPU
-        from oracle import oracle_th as OT
-        chunk = 16
-        th_loc = 0.0
-        t_th, _ = comm.shard_buckets(lst, chunk=chunk)
-        for b in t_th:
-            for a0 in range(0, len(b), chunk):
-                th_loc += OT.proba_cs_th(b[a0:a0 + chunk], LocErr, ds, Fs, T, pBL, 0 if b.shape[1] == hi else 1, [1], 1, 6, lo, 0.2, 120).sum()
-        th_total = comm.allreduce_scalar(th_loc, "sum")
-        th_ref = -OT.cum_proba_cs_th(vals, tracks, 0.02, [1], None, 1, 6, 1, 0.2, 120, chunk=chunk)
-        assert abs(th_total - th_ref) < 1e-12 * abs(th_ref), (th_total, th_ref)
-        assert [shard_range(41, r, world, chunk) for r in range(world)] == [(0, 32), (32, 41)]
-        q.put((rank, total, ref, covered, [shard_range(41, r, world) for r in range(world)]))
+        p = Parameters()
+        for k, v in vals.items():
+            p.add(k, value=v)
+        tracks = _dataset()
+        keys, lst, _ = T.engine.sort_buckets(tracks)
+        out = {"rank": rank}
+        if scenario == "objective":
+            # fixed-window objective through the product path
+            ts = comm.shard_trackset(lst)
+            assert (ts.min_len, ts.max_len) == (5, 12)
+            out["has12"] = 12 in [s[1] for s in ts.shapes]  # one rank's local max length differs from the global one
+            with contextlib.redirect_stdout(io.StringIO()):
+                got = T.cum_Proba_Cs(p, ts, 0.02, CELL, None, 2, 1, 6, verbose=0, comm=comm)
+                # a plain list is this rank's shard: the global min/max must still be agreed on (ADVICE r1)
+                loc, _ = comm.shard_buckets(lst)
+                got_list = T.cum_Proba_Cs(p, loc, 0.02, CELL, None, 2, 1, 6, verbose=0, comm=comm)
+            ts.close()
+            out.update(got=got, got_list=got_list, ref=O.cum_proba_cs(vals, tracks, 0.02, CELL, None, 1, 6),
+                       covered=comm.allreduce_scalar(ts.n_tracks, "sum"))
+            # threshold-fusion objective: chunk-aligned shards -> the unsharded value
+            chunk = 16
+            ts = comm.shard_trackset(lst, chunk=chunk)
+            with contextlib.redirect_stdout(io.StringIO()):
+                th = T.cum_Proba_Cs(p, ts, 0.02, CELL, None, 2, 1, 6, verbose=0, threshold=0.2, max_nb_states=120,
+                                    max_number_of_tracks_per_matrix=chunk, comm=comm, fusion="threshold")
+            out.update(th=th, th_ref=OT.cum_proba_cs_th(vals, tracks, 0.02, CELL, None, 1, 6, 1, 0.2, 120, chunk=chunk), th_n=ts.n_tracks)
+            ts.close()
+            # posteriors: per-rank row ranges, ordered gather on rank 0
+            pr = T.predict_Bs(tracks, 0.02, p, cell_dims=CELL, nb_states=2, frame_len=5, comm=comm)
+            if rank == 0:
+                ref = O.predict_bs(vals, tracks, 0.02, CELL, 5)
+                out["pred_err"] = max(np.abs(pr[k] - ref[k]).max() for k in tracks)
+                out["pred_keys"] = sorted(pr.keys(), key=int)
+            else:
+                assert pr is None
+        elif scenario == "empty_rank":
+            # fewer chunks than ranks: rank 1 holds nothing, contributes 0.0 and must not dead-lock the others
+            small = {"9": tracks["9"][:10]}
+            _, l2, _ = T.engine.sort_buckets(small)
+            ts = comm.shard_trackset(l2, chunk=16)
+            assert ts.n_tracks == (10 if rank == 0 else 0)
+            with contextlib.redirect_stdout(io.StringIO()):
+                th = T.cum_Proba_Cs(p, ts, 0.02, CELL, None, 2, 1, 6, verbose=0, max_number_of_tracks_per_matrix=16, comm=comm,
+                                    fusion="threshold")
+            ts.close()
+            out.update(th=th, th_ref=OT.cum_proba_cs_th(vals, small, 0.02, CELL, None, 1, 6, 1, 0.2, 120, chunk=16))
+            # collective error agreement: an empty dataset raises on EVERY rank, nobody is left waiting in a collective
+            try:
+                comm.shard_trackset([np.zeros((0, 5, 2))])
+                out["raised"] = False
+            except ValueError:
+                out["raised"] = True
+        out["plan"] = shard_plan([41, 30, 1], [5, 9, 12], world)
+        out["ranges"] = [shard_range(41, r, world) for r in range(world)]
+        out["ranges_chunk"] = [shard_range(41, r, world, 16) for r in range(world)]
+        q.put(out)
     finally:
         dist.destroy_process_group()
 
 
-def test_two_rank_sharded_objective_matches_unsharded():
+def _run(scenario):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, scenario)) for r in range(2)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=120) for _ in procs]
+    res = [q.get(timeout=300) for _ in procs]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for rank, total, ref, covered, ranges in res:
-        assert covered == 72
-        assert abs(total - ref) < 1e-12 * abs(ref), (rank, total, ref)
-        assert ranges == [(0, 21), (21, 41)]
-    assert res[0][1] == res[1][1]  # every rank sees the same reduced scalar
+    return sorted(res, key=lambda r: r["rank"])
+
+
+def test_two_rank_product_path_matches_unsharded():
+    res = _run("objective")
+    for r in res:
+        assert r["covered"] == 152
+        assert abs(r["got"] - r["ref"]) < 1e-12 * abs(r["ref"]), r
+        assert abs(r["got_list"] - r["ref"]) < 1e-12 * abs(r["ref"]), r
+        assert abs(r["th"] - r["th_ref"]) < 1e-12 * abs(r["th_ref"]), r
+        assert r["ranges"] == [(0, 21), (21, 41)] and r["ranges_chunk"] == [(0, 32), (32, 41)]
+    assert res[0]["got"] == res[1]["got"] and res[0]["th"] == res[1]["th"]  # every rank sees the same reduced scalar
+    assert sorted(r["has12"] for r in res) == [False, True]
+    assert res[0]["pred_err"] < 1e-12 and res[0]["pred_keys"] == ["5", "6", "7", "8", "9", "10", "11", "12"]
+    # chunk-aligned shards are balanced over ALL buckets (one-chunk buckets are dealt round-robin, not piled on rank 0)
+    assert abs(res[0]["th_n"] - res[1]["th_n"]) <= 32 and min(res[0]["th_n"], res[1]["th_n"]) > 40
+
+
+def test_rank_without_tracks_and_collective_failure():
+    res = _run("empty_rank")
+    for r in res:
+        assert abs(r["th"] - r["th_ref"]) < 1e-12 * abs(r["th_ref"]), r
+        assert r["raised"] is True
 
 
 def test_shard_range_partitions_exactly():
@@ -98,3 +203,74 @@ def test_shard_range_partitions_exactly():
             assert all(parts[i][1] == parts[i + 1][0] for i in range(w - 1))
             sizes = [b - a for a, b in parts]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_shard_plan_balances_many_small_buckets():
+    """46 buckets of fewer than one 2000-track chunk each used to land on rank 0 entirely; equal buckets used to be
+    ~2x unbalanced.  The plan must partition every bucket exactly, keep chunk alignment, and balance the work."""
+    from extrack_amd.distributed import shard_plan
+    lengths = list(range(5, 51))
+    rng = np.random.default_rng(0)
+    sizes = [int(x) for x in rng.integers(200, 1900, len(lengths))]
+    plan = shard_plan(sizes, lengths, 8, chunk=2000)
+    per_rank = [sum(z - a for a, z in (b[r] for b in plan)) for r in range(8)]
+    assert sum(per_rank) == sum(sizes) and min(per_rank) > 0
+    for n, b in zip(sizes, plan):
+        assert b[0][0] == 0 and b[-1][1] == n and all(b[i][1] == b[i + 1][0] for i in range(7))
+        assert all(a % 2000 == 0 for a, z in b if z > a)
+    work = [sum((z - a) * (L - 1) for (a, z), L in zip((b[r] for b in plan), lengths)) for r in range(8)]
+    assert max(work) < 1.6 * (sum(work) / 8)
+    # 1e6 tracks in 46 equal buckets, 2000-track chunks: balanced to a chunk overall
+    sizes = [21740] * 46
+    plan = shard_plan(sizes, lengths, 8, chunk=2000)
+    per_rank = [sum(z - a for a, z in (b[r] for b in plan)) for r in range(8)]
+    assert max(per_rank) - min(per_rank) <= 3 * 2000, per_rank
+    # row-balanced mode: every bucket to +-1 row, totals to +-1 row as well (remainders rotate)
+    plan = shard_plan([10, 10, 10, 10], [5, 5, 5, 5], 4)
+    per_rank = [sum(z - a for a, z in (b[r] for b in plan)) for r in range(4)]
+    assert per_rank == [10, 10, 10, 10]
+
+
+def test_list_input_is_never_cached(monkeypatch):
+    """the objective used to key a device-copy cache on id()/address of the caller's arrays, so an in-place
+    edit (or a re-allocated array at the same address) silently evaluated stale device data.  List input is now uploaded per
+    call: an edit must be seen, and nothing may stay alive behind the caller's back."""
+    sys.path.insert(0, ROOT)
+    from extrack_amd import _lib, synth, tracking as T
+    from extrack_amd.lmfit_compat import Parameters
+    from oracle import oracle_np as O
+    created = []
+
+    class Ctx(OracleContext):
+        def __init__(self, device=0):
+            super().__init__(device)
+            created.append(self)
+            self.closed = False
+
+        def close(self):
+            self.closed = True
+
+    monkeypatch.setattr(_lib, "Context", Ctx)
+    vals = dict(D0=1e-3, D1=0.25, LocErr=0.02, F0=0.6, F1=0.4, p01=0.1, p10=0.1, pBL=0.1)
+    p = Parameters()
+    for k, v in vals.items():
+        p.add(k, value=v)
+    a = synth.brownian_tracks(20, 7, [0.0, 0.25], [[.9, .1], [.1, .9]], [.6, .4], seed=1)
+    v1 = T.cum_Proba_Cs(p, [a], 0.02, CELL, None, 2, 1, 4, verbose=0)
+    a[3, 2, 0] += 0.5  # in-place edit: same id, same address, same shape
+    v2 = T.cum_Proba_Cs(p, [a], 0.02, CELL, None, 2, 1, 4, verbose=0)
+    assert v1 != v2
+    assert abs(v2 - O.cum_proba_cs(vals, {"7": a}, 0.02, CELL, None, 1, 4)) < 1e-12 * abs(v2)
+    assert len(created) == 2 and all(c.closed for c in created)
+    assert not hasattr(T, "_TRACKSET_CACHE")
+
+
+def test_default_fusion_env_switch(monkeypatch):
+    from extrack_amd import tracking as T
+    monkeypatch.delenv("EXTRACK_FUSION", raising=False)
+    assert T.default_fusion() == "window" and T._check_fusion(None) is False
+    monkeypatch.setenv("EXTRACK_FUSION", "threshold")
+    assert T._check_fusion(None) is True and T._check_fusion("window") is False
+    monkeypatch.setenv("EXTRACK_FUSION", "bogus")
+    with pytest.raises(ValueError):
+        T._check_fusion(None)
