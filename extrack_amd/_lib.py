@@ -16,7 +16,7 @@ EXPORTS = [
     "extrack_upload_bucket", "extrack_attach_bucket", "extrack_clear_buckets", "extrack_bucket_count",
     "extrack_loglik", "extrack_loglik_async", "extrack_predict", "extrack_last_kernel_ms",
     "extrack_last_launch_info", "extrack_p_stay_table", "extrack_loglik_th", "extrack_loglik_th_async", "extrack_th_plan_step",
-    "extrack_predict_th",
+    "extrack_predict_th", "extrack_loglik_grad", "extrack_last_grad_ms",
 ]
 
 _dp = C.POINTER(C.c_double)
@@ -29,6 +29,14 @@ class ExtrackModel(C.Structure):
         ("max_len", C.c_int32), ("locerr_mode", C.c_int32), ("locerr_dims", C.c_int32), ("reserved", C.c_int32),
         ("locerr", C.c_double * 3), ("slope", C.c_double), ("offset", C.c_double), ("pBL", C.c_double),
         ("ds", _dp), ("Fs", _dp), ("TrMat", _dp), ("p_stay", _dp),
+    ]
+
+
+class ExtrackModelTangent(C.Structure):
+    """Mirror of ``struct extrack_model_tangent`` (include/extrack_hip.h)."""
+    _fields_ = [
+        ("locerr", C.c_double * 3), ("slope", C.c_double), ("offset", C.c_double), ("pBL", C.c_double),
+        ("ds2", _dp), ("Fs", _dp), ("TrMat", _dp), ("p_stay", _dp),
     ]
 
 
@@ -93,7 +101,9 @@ def load():
     lib.extrack_loglik_th_async.argtypes = [vp, C.POINTER(ExtrackModel), C.c_double, i32, i32, vp]
     lib.extrack_predict_th.argtypes = [vp, C.POINTER(ExtrackModel), i32, C.c_double, i32, i32, vp]
     lib.extrack_th_plan_step.argtypes = [vp, i32, i64, i32, C.POINTER(i32), C.POINTER(i32), vp, vp, i32]
-    if lib.extrack_abi_version() != 2:
+    lib.extrack_loglik_grad.argtypes = [vp, C.POINTER(ExtrackModel), i32, C.POINTER(ExtrackModelTangent), _dp, vp]
+    lib.extrack_last_grad_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    if lib.extrack_abi_version() != 3:
         raise ImportError("libextrack_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -207,6 +217,34 @@ class Context:
         out = np.empty(self.n_tracks()) if per_track else None
         self._check(self._lib.extrack_loglik(self._h, C.byref(model.c), C.byref(tot), out.ctypes.data_as(C.c_void_p) if per_track else None))
         return (tot.value, out) if per_track else tot.value
+
+    def loglik_grad(self, model, tangents):
+        """(sum LL, d sum LL / d theta_i) for the model directions ``tangents``: list of dicts with the keys ds2 [S], Fs [S],
+        TrMat [S, S], p_stay [S**ns] and optionally locerr (<= 3 values), slope, offset, pBL."""
+        n = len(tangents)
+        arr = (ExtrackModelTangent * max(n, 1))()
+        keep = []
+        for i, t in enumerate(tangents):
+            e = arr[i]
+            le = np.zeros(3)
+            v = np.atleast_1d(np.asarray(t.get("locerr", 0.0), float)).ravel()
+            le[:len(v)] = v
+            e.locerr = (C.c_double * 3)(*le)
+            e.slope, e.offset, e.pBL = float(t.get("slope", 0.0)), float(t.get("offset", 0.0)), float(t.get("pBL", 0.0))
+            S = model.c.n_states
+            a4 = [_f64(np.broadcast_to(np.asarray(t.get(k, 0.0), float), shp)) for k, shp in
+                  (("ds2", (S,)), ("Fs", (S,)), ("TrMat", (S, S)), ("p_stay", model.p_stay.shape))]
+            keep.append(a4)
+            e.ds2, e.Fs, e.TrMat, e.p_stay = [x.ctypes.data_as(_dp) for x in a4]
+        tot = C.c_double(0.0)
+        g = np.zeros(max(n, 1))
+        self._check(self._lib.extrack_loglik_grad(self._h, C.byref(model.c), n, arr, C.byref(tot), g.ctypes.data_as(C.c_void_p)))
+        return tot.value, g[:n]
+
+    def last_grad_ms(self):
+        ms = C.c_float(0)
+        self._check(self._lib.extrack_last_grad_ms(self._h, C.byref(ms)))
+        return ms.value
 
     def loglik_th(self, model, threshold=0.2, max_nb_states=120, chunk=2000, per_track=False):
         """Threshold-fusion log-likelihood (extrack/tracking.py:427-743 semantics, see include/extrack_hip.h)."""

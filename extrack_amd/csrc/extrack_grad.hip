@@ -1,0 +1,262 @@
+// libextrack_hip.so, translation unit 2: log-likelihood + exact gradient (xt_grad.h) behind extrack_loglik_grad.
+// Replaces the finite-difference loop that lmfit's BFGS runs around cum_Proba_Cs (extrack/tracking.py:1371).
+#include "xt_host.h"
+
+#include "xt_grad.h"
+#include "xt_grad_host.h"
+
+template <int G_, int D, int K, int MAXT>
+__global__ void __launch_bounds__(MAXT) xt_grad_kernel(XtKernelArgs a, XtGradArgs ga)
+{
+    DevCtx cx;
+    xt_grad_body<G_, D, K>(a, ga, cx);
+}
+
+// Column sums of the per-block partials [nrows][ncol] in a fixed order: one workgroup per column.
+__global__ void __launch_bounds__(256) xt_grad_reduce(const double* __restrict__ partials, int nrows, int ncol, double* __restrict__ out)
+{
+    __shared__ double sh[256];
+    const int col = blockIdx.x;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nrows; i += 256) s += partials[(int64_t)i * ncol + col];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[col] = sh[0];
+}
+
+struct GradLauncher {
+    extrack_ctx* ctx;
+    XtKernelArgs a;
+    XtGradArgs ga;
+    int threads = 0;
+    size_t lds = 0;
+    int grid = 0;
+    hipError_t herr = hipSuccess;
+
+    template <int G_, int D, int K>
+    bool run()
+    {
+        if (threads <= 256) return launch(xt_grad_kernel<G_, D, K, 256>);
+        return launch(xt_grad_kernel<G_, D, K, 1024>);
+    }
+    template <class KernT>
+    bool launch(KernT kern)
+    {
+        if (lds > 64 * 1024) {
+            herr = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (herr != hipSuccess) return true;
+        }
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, ctx->stream, a, ga);
+        herr = hipGetLastError();
+        return true;
+    }
+};
+
+template <int GG, class L>
+static bool xt_grad_dispatch_dk(int D, int K, L& l)
+{
+    if (D == 1 && K == 1) return l.template run<GG, 1, 1>();
+    if (D == 2 && K == 1) return l.template run<GG, 2, 1>();
+    if (D == 2 && K == 2) return l.template run<GG, 2, 2>();
+    if (D == 3 && K == 1) return l.template run<GG, 3, 1>();
+    if (D == 3 && K == 3) return l.template run<GG, 3, 3>();
+    return false;
+}
+
+template <class L>
+static bool xt_grad_dispatch(int G, int D, int K, L& l)
+{
+    if (G == 2) return xt_grad_dispatch_dk<2>(D, K, l);
+    if (G == 3) return xt_grad_dispatch_dk<3>(D, K, l);
+    if (G == 4) return xt_grad_dispatch_dk<4>(D, K, l);
+    return xt_grad_dispatch_dk<0>(D, K, l);
+}
+
+// LDS bytes of a block of tpb tracks with NP directions
+static size_t xt_grad_lds_bytes(const XtConfig& c, int D, int K, int NP, int tpb, bool tan_lds)
+{
+    size_t d = (size_t)((xt_tab_doubles(c.S, c.G) + 1) & ~1);
+    if (tan_lds) d += (size_t)((NP * xt_grad_tb_doubles(c.S, c.G) + 1) & ~1);
+    d += (size_t)tpb * ((size_t)xt_grad_region_doubles(c.EP, D, K, NP) + xt_grad_acc_doubles(NP, c.NG) + xt_stage_doubles(D));
+    return d * sizeof(double);
+}
+
+static int xt_grad_reserve(extrack_ctx* ctx, double** buf, size_t* cap, size_t n)
+{
+    if (n <= *cap) return EXTRACK_OK;
+    XT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (*buf) (void)hipFree(*buf);
+    *buf = nullptr;
+    *cap = 0;
+    XT_HIP(ctx, hipMalloc(buf, n * sizeof(double)));
+    *cap = n;
+    return EXTRACK_OK;
+}
+
+extern "C" int extrack_loglik_grad(extrack_ctx* ctx, const extrack_model* m, int32_t n_dir, const extrack_model_tangent* tangents,
+                                   double* total_ll, double* grad)
+{
+    if (!ctx || !total_ll || n_dir < 0 || (n_dir > 0 && (!tangents || !grad))) return xt_fail(ctx, EXTRACK_E_INVALID, "null argument");
+    int rc = xt_validate_model(ctx, m);
+    if (rc) return rc;
+    if (ctx->buckets.empty()) return xt_fail(ctx, EXTRACK_E_INVALID, "no bucket uploaded");
+    for (int i = 0; i < n_dir; ++i)
+        if (!tangents[i].ds2 || !tangents[i].Fs || !tangents[i].TrMat || !tangents[i].p_stay)
+            return xt_fail(ctx, EXTRACK_E_INVALID, "null tangent field");
+    XT_HIP(ctx, hipSetDevice(ctx->device));
+    if ((rc = xt_prepare_config(ctx, m))) return rc;
+    const XtConfig& c = ctx->cfg;
+    XtModelHost mh;
+    xt_model_host(m, mh);
+    std::vector<double> blob;
+    xt_build_blob(mh, c, blob);
+    if ((rc = xt_upload_blob(ctx, blob))) return rc;
+    const int TB = xt_grad_tb_doubles(c.S, c.G);
+    std::vector<double> dblob((size_t)std::max(n_dir, 1) * TB, 0.0);
+    for (int i = 0; i < n_dir; ++i) xt_build_tangent_block(mh, tangents[i], c, m->locerr_mode, dblob.data() + (size_t)i * TB);
+    if ((rc = xt_grad_reserve(ctx, &ctx->d_dblob, &ctx->dblob_cap, dblob.size()))) return rc;
+    XT_HIP(ctx, hipMemcpyAsync(ctx->d_dblob, dblob.data(), dblob.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+
+    // launch groups: buckets with the same (dims, sigma dims), longest first
+    std::vector<XtBucket*> order;
+    for (auto& b : ctx->buckets) order.push_back(&b);
+    std::stable_sort(order.begin(), order.end(), [](const XtBucket* x, const XtBucket* y) {
+        if (x->D != y->D) return x->D < y->D;
+        if (x->KS != y->KS) return x->KS < y->KS;
+        return x->L > y->L;
+    });
+    std::vector<std::vector<XtBucket*>> groups;
+    for (XtBucket* b : order) {
+        if (groups.empty() || groups.back().size() >= XT_MAX_BUCKETS || groups.back()[0]->D != b->D || groups.back()[0]->KS != b->KS)
+            groups.emplace_back();
+        groups.back().push_back(b);
+    }
+    if (order.size() > (size_t)XT_DESC_CAP / 2) return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "too many buckets");
+
+    *total_ll = 0.0;
+    for (int i = 0; i < n_dir; ++i) grad[i] = 0.0;
+    std::vector<double> host_out;
+    size_t doff = xt_desc_base(ctx);
+    float ms_total = 0.f;
+    for (auto& g : groups) {
+        const XtBucket& b0 = *g[0];
+        const int D = b0.D;
+        int K;
+        if (m->locerr_mode == 0) {
+            K = m->locerr_dims;
+            if (K != 1 && K != D) return xt_fail(ctx, EXTRACK_E_INVALID, "locerr_dims must be 1 or the track dimensionality");
+        } else {
+            if (!b0.d_sigma) return xt_fail(ctx, EXTRACK_E_INVALID, "per-peak localisation error mode but the bucket has no sigma");
+            K = b0.KS;
+        }
+        // directions per pass: as many as keep one track's state within the LDS of a CU (all of them for the usual models)
+        int npass_dir = std::max(n_dir, 1);
+        while (npass_dir > 1 && xt_grad_lds_bytes(c, D, K, npass_dir, 1, false) > 150 * 1024) npass_dir = (npass_dir + 1) / 2;
+        if (xt_grad_lds_bytes(c, D, K, std::min(npass_dir, std::max(n_dir, 0)), 1, false) > 160 * 1024)
+            return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "sequence state with one tangent direction does not fit the 160 KiB LDS of a CU");
+        // bucket descriptors of this group (shared by its passes)
+        std::vector<XtBucketDesc> descs;
+        for (XtBucket* b : g) {
+            XtBucketDesc d;
+            d.tracks = b->d_tracks;
+            d.sigma = m->locerr_mode ? b->d_sigma : nullptr;
+            d.ll_out = nullptr;
+            d.preds_out = nullptr;
+            d.N = b->N;
+            d.L = b->L;
+            d.isBL = (b->L != m->max_len) ? 1 : 0;  // tracking.py:1037-1040
+            d.ll_const = -(double)(b->L - 1) * D * 0.5 * XT_LOG2PI;
+            descs.push_back(d);
+        }
+        memcpy(ctx->h_desc + doff, descs.data(), descs.size() * sizeof(XtBucketDesc));
+        XT_HIP(ctx, hipMemcpyAsync(ctx->d_desc + doff, ctx->h_desc + doff, descs.size() * sizeof(XtBucketDesc), hipMemcpyHostToDevice, ctx->stream));
+        XT_HIP(ctx, hipEventRecord(ctx->ev_blob[(ctx->blob_turn - 1u) & 1u], ctx->stream));
+        for (int p0 = 0; p0 < std::max(n_dir, 1); p0 += npass_dir) {
+            const int NP = n_dir == 0 ? 0 : std::min(npass_dir, n_dir - p0);
+            GradLauncher l;
+            l.ctx = ctx;
+            memset(&l.a, 0, sizeof(l.a));
+            xt_fill_args_from_config(c, l.a);
+            const bool tan_lds = (size_t)NP * TB * 8 <= 16 * 1024;
+            const size_t per_track = xt_grad_lds_bytes(c, D, K, NP, 1, tan_lds) - xt_grad_lds_bytes(c, D, K, NP, 0, tan_lds);
+            const size_t fixed = xt_grad_lds_bytes(c, D, K, NP, 0, tan_lds);
+            const size_t budget = 64 * 1024;
+            const int by_threads = c.NG >= 256 ? 1 : 256 / c.NG;
+            const int by_lds = budget > fixed + per_track ? (int)((budget - fixed) / per_track) : 1;
+            int tpb = std::max(1, std::min(by_threads, by_lds));
+            const int threads = (tpb * c.NG + 63) / 64 * 64;
+            if (threads > 1024) return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "n_states^(frame_len-nb_substeps) > 1024 groups per track is not built");
+            l.threads = threads;
+            l.lds = xt_grad_lds_bytes(c, D, K, NP, tpb, tan_lds);
+            if (l.lds > 160 * 1024) return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "sequence state does not fit the 160 KiB LDS of a CU");
+            // grid: blocks per bucket in proportion to its work, CUs oversubscribed (as the likelihood launcher does)
+            const int occ = std::max(1, std::min((int)((160 * 1024) / l.lds), 2048 / threads));
+            const double target = (double)occ * ctx->n_cu * 4;
+            double wsum = 0.0;
+            std::vector<int64_t> nbatch(descs.size());
+            for (size_t i = 0; i < descs.size(); ++i) {
+                nbatch[i] = (descs[i].N + tpb - 1) / tpb;
+                wsum += (double)nbatch[i] * (descs[i].L - 1);
+            }
+            int64_t acc = 0;
+            for (size_t i = 0; i < descs.size(); ++i) {
+                int64_t n = (int64_t)ceil(target * ((double)nbatch[i] * (descs[i].L - 1)) / wsum);
+                n = n < 1 ? 1 : (n > nbatch[i] ? nbatch[i] : n);
+                acc += n;
+                l.a.blk_end[i] = (int32_t)acc;
+            }
+            l.grid = (int)acc;
+            if ((rc = xt_grad_reserve(ctx, &ctx->d_gpartials, &ctx->gpartials_cap, (size_t)l.grid * (NP + 1) + (size_t)(NP + 1)))) return rc;
+            l.a.desc = ctx->d_desc + doff;
+            l.a.ndesc = (int32_t)descs.size();
+            l.a.blob = ctx->d_blob;
+            l.a.base_tab = ctx->d_base_tab;
+            l.a.off_tab = ctx->d_off_tab;
+            l.a.TPB = tpb;
+            l.a.min_len = m->min_len;
+            l.a.locerr_mode = m->locerr_mode;
+            l.a.KS = b0.KS ? b0.KS : 1;
+            l.ga.dblob = ctx->d_dblob + (size_t)p0 * TB;
+            l.ga.gpartials = ctx->d_gpartials;
+            l.ga.NP = NP;
+            l.ga.TB = TB;
+            l.ga.tan_lds = tan_lds ? 1 : 0;
+            XT_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+            if (!xt_grad_dispatch(c.G, D, K, l)) return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "gradient kernel variant not built");
+            if (l.herr != hipSuccess) return xt_fail(ctx, EXTRACK_E_HIP, std::string("gradient kernel launch: ") + hipGetErrorString(l.herr));
+            XT_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+            double* d_out = ctx->d_gpartials + (size_t)l.grid * (NP + 1);
+            hipLaunchKernelGGL(xt_grad_reduce, dim3(NP + 1), dim3(256), 0, ctx->stream, ctx->d_gpartials, l.grid, NP + 1, d_out);
+            XT_HIP(ctx, hipGetLastError());
+            host_out.assign((size_t)NP + 1, 0.0);
+            XT_HIP(ctx, hipMemcpyAsync(host_out.data(), d_out, (size_t)(NP + 1) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+            XT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            float ms = 0.f;
+            XT_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+            ms_total += ms;
+            if (p0 == 0) *total_ll += host_out[0];
+            for (int i = 0; i < NP; ++i) grad[p0 + i] += host_out[1 + i];
+            ctx->launch_info[0] = l.grid;
+            ctx->launch_info[1] = threads;
+            ctx->launch_info[2] = (int32_t)l.lds;
+            ctx->launch_info[3] = tpb;
+            ctx->launch_info[4] = occ;
+            ctx->launch_info[5] = ctx->n_cu;
+        }
+        doff += g.size();
+    }
+    ctx->grad_ms = ms_total;
+    ctx->timed = false;
+    return EXTRACK_OK;
+}
+
+extern "C" int extrack_last_grad_ms(extrack_ctx* ctx, float* ms)
+{
+    if (!ctx || !ms) return EXTRACK_E_INVALID;
+    *ms = ctx->grad_ms;
+    return EXTRACK_OK;
+}

@@ -183,6 +183,8 @@ extern "C" void extrack_destroy(extrack_ctx* ctx)
         if (ctx->ev_blob[i]) (void)hipEventDestroy(ctx->ev_blob[i]);
     }
     if (ctx->d_preds) (void)hipFree(ctx->d_preds);
+    if (ctx->d_dblob) (void)hipFree(ctx->d_dblob);
+    if (ctx->d_gpartials) (void)hipFree(ctx->d_gpartials);
     if (ctx->d_partials) (void)hipFree(ctx->d_partials);
     if (ctx->d_total) (void)hipFree(ctx->d_total);
     if (ctx->h_total) (void)hipHostFree(ctx->h_total);
@@ -330,6 +332,8 @@ static int xt_reserve_preds(extrack_ctx* ctx, size_t bytes)
     if (bytes <= ctx->preds_cap) return EXTRACK_OK;
     XT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->d_preds) (void)hipFree(ctx->d_preds);
+    if (ctx->d_dblob) (void)hipFree(ctx->d_dblob);
+    if (ctx->d_gpartials) (void)hipFree(ctx->d_gpartials);
     ctx->d_preds = nullptr;
     ctx->preds_cap = 0;
     XT_HIP(ctx, hipMalloc(&ctx->d_preds, bytes));

@@ -40,9 +40,10 @@ struct XtGradArgs {
 //   [0..2] d l2 (global localisation error),  [3] d slope,  [4] d offset,  [8 + s] d log Fs[s]
 //   XT_BLOB_HDR + (v * S + prev) * G + q :  v = 0..3  d log of table v (T, T*stay, T*Eend, T*stay*Eend);  v = 4  d d2 (absolute)
 XT_HD int xt_grad_tb_doubles(int S, int G) { return XT_BLOB_HDR + XT_NTAB * S * G; }
-// LDS doubles per track: primal region + NP tangent planes (+ nothing else: the final reduction reuses the tangent planes)
+// LDS doubles per track: primal region + NP tangent planes
 XT_HD int xt_grad_region_doubles(int EP, int D, int K, int NP) { return xt_region_doubles(EP, D, K) + NP * EP * (1 + D + K); }
-XT_HD int xt_grad_acc_doubles(int NP) { return NP + 2; }  // per track slot: block accumulators [LL, g_0 .. g_NP-1] (+ pad)
+// per track slot: block accumulators bacc[NP + 1], column sums csum[NP + 1], per-thread partials gth[NP + 1][NG]
+XT_HD int xt_grad_acc_doubles(int NP, int NG) { return 2 * (NP + 2) + (NP + 1) * NG; }
 
 template <int G_, int D, int K, class Ctx>
 XT_HD void xt_grad_body(const XtKernelArgs& a, const XtGradArgs& ga, Ctx& cx)
@@ -79,8 +80,11 @@ XT_HD void xt_grad_body(const XtKernelArgs& a, const XtGradArgs& ga, Ctx& cx)
     int* red_e = ze + ((EP + 1) & ~1);  // [0] final-reduce exponent, [1] NaN-input flag
     double* tan = reg + xt_region_doubles(EP, D, K);  // [NP][(1 + D + K)][EP]: rz, dm[D], du[K]
     const int tstride = (1 + D + K) * EP;
-    double* bacc = smem + reg0 + a.TPB * rdoubles + (tvalid ? slot : 0) * xt_grad_acc_doubles(NP);  // [1 + NP]
-    double* spos = smem + reg0 + a.TPB * (rdoubles + xt_grad_acc_doubles(NP)) + (tvalid ? slot : 0) * xt_stage_doubles(D);
+    const int adoubles = xt_grad_acc_doubles(NP, NG);
+    double* bacc = smem + reg0 + a.TPB * rdoubles + (tvalid ? slot : 0) * adoubles;  // [NP + 1] (+ pad)
+    double* csum = bacc + NP + 2;                                                     // [NP + 1] (+ pad)
+    double* gth = csum + NP + 2;                                                      // [NP + 1][NG]
+    double* spos = smem + reg0 + a.TPB * (rdoubles + adoubles) + (tvalid ? slot : 0) * xt_stage_doubles(D);
     double* ssig = spos + XT_STAGE * D;
 
     const int prev = g / a.prev_div;
@@ -345,161 +349,122 @@ XT_HD void xt_grad_body(const XtKernelArgs& a, const XtGradArgs& ga, Ctx& cx)
             cx.sync();
         }
 
-        // ---- last position (+ leaving/bleaching term): pass 1 = extended-range total, pass 2 = gradient weights on its scale
+        // ---- last position (+ leaving/bleaching term).  Pass 1: extended-range total of every thread -> common exponent fe.
+        // Pass 2: the same weights on the 2^fe scale (plain doubles) and, per direction, sum w * d log w.
         if (((L - 1) & (XT_STAGE - 1)) == 0) stage(L - 1);
         const int tl = L - 1;
         const int phl = (tl - 1) % a.P;
         const int vfin = (b.isBL ? 2 : 0) + (tl >= stay_from ? 1 : 0);
+        const double* TF = TAB + (vfin * S + prev) * G;
+        const int tvf = vfin * SG + toff;
         double cl[D], l2l[K], scl[K], srl[K];
+        for (int d = 0; d < D; ++d) cl[d] = 0.0;
+        // weight of (old member Q, new digits q) as mantissa/exponent; rel != nullptr: also d log w for direction (dtb, tp)
+        auto pair_term = [&](int idx, int q, const double* dq, double dsq, double zq, int eq, double& wm, int& we, const double* dtb,
+                             const double* dl2, double rzQ, const double* dmQ, const double* duQ, double& rel) {
+            double quad, gf;
+            if (K == 1) {
+                const double r = xt_rcp(TD2[q] + uu[idx] + l2l[0]);
+                quad = 0.5 * dsq * r;
+                gf = xt_pow_half<D>(r);
+                if (dtb) {
+                    const double dden = dtb[4 * SG + toff + q] + duQ[0] + dl2[0];
+                    double ddsq = 0.0;
+                    for (int d = 0; d < D; ++d) ddsq = xt_fma(-2.0 * dq[d], dmQ[d], ddsq);
+                    rel = rzQ + dtb[tvf + q] - 0.5 * r * (D * dden + ddsq - dsq * r * dden);
+                }
+            } else {
+                quad = 0.0;
+                gf = 1.0;
+                if (dtb) rel = rzQ + dtb[tvf + q];
+                for (int d = 0; d < D; ++d) {
+                    const double r = xt_rcp(TD2[q] + uu[d * EP + idx] + l2l[d]);
+                    quad = xt_fma(0.5 * dq[d] * dq[d], r, quad);
+                    gf *= r;
+                    if (dtb) {
+                        const double dden = dtb[4 * SG + toff + q] + duQ[d] + dl2[d];
+                        rel -= 0.5 * r * (dden - 2.0 * dq[d] * dmQ[d] - dq[d] * dq[d] * r * dden);
+                    }
+                }
+                gf = sqrt(gf);
+            }
+            double pp;
+            int j, n;
+            xt_exp_tab(-quad, pp, j, n);
+            wm = zq * TF[q] * (gf * T64[j]) * pp;
+            we = eq + n;
+        };
         XtAcc tot;
         tot.clear();
         if (act) {
             const int base = a.base_tab[phl * NG + g];
             const int32_t* off = a.off_tab + phl * G;
-            const double* TF = TAB + (vfin * S + prev) * G;
             for (int d = 0; d < D; ++d) cl[d] = spos[(tl & (XT_STAGE - 1)) * D + d];
             load_l2(tl, l2l, scl, srl);
             for (int Q = 0; Q < G; ++Q) {
                 const int idx = xt_skew(base + off[Q], a.skew);
                 const double zq = zm[idx];
                 if (zq == 0.0) continue;
-                const int eq = ze[idx];
                 double dq[D], dsq = 0.0;
                 for (int d = 0; d < D; ++d) {
                     dq[d] = cl[d] - mm[d * EP + idx];
                     dsq = xt_fma(dq[d], dq[d], dsq);
                 }
                 for (int q = 0; q < G; ++q) {
-                    double quad, gf;
-                    if (K == 1) {
-                        const double r = xt_rcp(TD2[q] + uu[idx] + l2l[0]);
-                        quad = 0.5 * dsq * r;
-                        gf = xt_pow_half<D>(r);
-                    } else {
-                        quad = 0.0;
-                        gf = 1.0;
-                        for (int d = 0; d < D; ++d) {
-                            const double r = xt_rcp(TD2[q] + uu[d * EP + idx] + l2l[d]);
-                            quad = xt_fma(0.5 * dq[d] * dq[d], r, quad);
-                            gf *= r;
-                        }
-                        gf = sqrt(gf);
-                    }
-                    double pp;
-                    int j, n;
-                    xt_exp_tab(-quad, pp, j, n);
-                    tot.add(zq * TF[q] * (gf * T64[j]) * pp, eq + n);
+                    double wm, rel;
+                    int we;
+                    pair_term(idx, q, dq, dsq, zq, ze[idx], wm, we, nullptr, nullptr, 0.0, nullptr, nullptr, rel);
+                    tot.add(wm, we);
                 }
             }
             if (tot.m != 0.0) cx.atomic_max_i32(&red_e[0], tot.e);
         }
         cx.sync();
-        double gsum[1];  // (unused placeholder keeps the structure of pass 2 below readable)
-        (void)gsum;
         if (act) {
             const int fe = red_e[0];
             const int base = a.base_tab[phl * NG + g];
             const int32_t* off = a.off_tab + phl * G;
-            const double* TF = TAB + (vfin * S + prev) * G;
-            const int tvf = vfin * SG + toff;
-            // per-thread partial sums: w (total weight on the 2^fe scale) and, per direction, sum w * d log w.  They go to LDS
-            // after the loop; until then the directions' sums are accumulated in the (no longer needed) NEW-digit tangent slots
-            // is not possible (still read below), so they are accumulated per (Q, p) in registers and added to LDS scratch.
-            double wsum = 0.0;
-            // scratch: gth[p][g] lives in the primal arrays' tail?  No: the primal state is still read here.  Use a two-step
-            // scheme: first compute and stash this thread's G*G weights (compile-time G) or recompute them (runtime G).
-            for (int p = -1; p < NP; ++p) {
-                // p == -1: weight pass (wsum); p >= 0: direction p
-                const double* dtb = p >= 0 ? DT + p * TB : nullptr;
-                const double* tp = p >= 0 ? tan + p * tstride : nullptr;
+            gth[g] = tot.m != 0.0 ? xt_ldexp(tot.m, tot.e - fe) : 0.0;  // column 0: weight total of this thread
+            for (int p = 0; p < NP; ++p) {
+                const double* dtb = DT + p * TB;
+                const double* tp = tan + p * tstride;
                 double dl2[K];
-                if (p >= 0) dl2_of(dtb, scl, srl, dl2);
+                dl2_of(dtb, scl, srl, dl2);
                 double acc = 0.0;
                 for (int Q = 0; Q < G; ++Q) {
                     const int idx = xt_skew(base + off[Q], a.skew);
                     const double zq = zm[idx];
                     if (zq == 0.0) continue;
-                    const int eq = ze[idx];
-                    double dq[D], dsq = 0.0;
+                    double dq[D], dsq = 0.0, dmQ[D], duQ[K];
                     for (int d = 0; d < D; ++d) {
                         dq[d] = cl[d] - mm[d * EP + idx];
                         dsq = xt_fma(dq[d], dq[d], dsq);
+                        dmQ[d] = tp[(1 + d) * EP + idx];
                     }
-                    double rzQ = 0.0, dmQ[D], duQ[K];
-                    if (p >= 0) {
-                        rzQ = tp[idx];
-                        for (int d = 0; d < D; ++d) dmQ[d] = tp[(1 + d) * EP + idx];
-                        for (int k = 0; k < K; ++k) duQ[k] = tp[(1 + D + k) * EP + idx];
-                    }
+                    for (int k = 0; k < K; ++k) duQ[k] = tp[(1 + D + k) * EP + idx];
+                    const double rzQ = tp[idx];
                     for (int q = 0; q < G; ++q) {
-                        double quad, gf, rel = 0.0;
-                        if (K == 1) {
-                            const double r = xt_rcp(TD2[q] + uu[idx] + l2l[0]);
-                            quad = 0.5 * dsq * r;
-                            gf = xt_pow_half<D>(r);
-                            if (p >= 0) {
-                                const double dden = dtb[4 * SG + toff + q] + duQ[0] + dl2[0];
-                                double ddsq = 0.0;
-                                for (int d = 0; d < D; ++d) ddsq = xt_fma(-2.0 * dq[d], dmQ[d], ddsq);
-                                rel = rzQ + dtb[tvf + q] - 0.5 * r * (D * dden + ddsq - dsq * r * dden);
-                            }
-                        } else {
-                            quad = 0.0;
-                            gf = 1.0;
-                            if (p >= 0) rel = rzQ + dtb[tvf + q];
-                            for (int d = 0; d < D; ++d) {
-                                const double r = xt_rcp(TD2[q] + uu[d * EP + idx] + l2l[d]);
-                                quad = xt_fma(0.5 * dq[d] * dq[d], r, quad);
-                                gf *= r;
-                                if (p >= 0) {
-                                    const double dden = dtb[4 * SG + toff + q] + duQ[d] + dl2[d];
-                                    rel -= 0.5 * r * (dden - 2.0 * dq[d] * dmQ[d] - dq[d] * dq[d] * r * dden);
-                                }
-                            }
-                            gf = sqrt(gf);
-                        }
-                        double pp;
-                        int j, n;
-                        xt_exp_tab(-quad, pp, j, n);
-                        const double w = xt_ldexp(zq * TF[q] * (gf * T64[j]) * pp, eq + n - fe);
-                        acc = p >= 0 ? xt_fma(w, rel, acc) : acc + w;
+                        double wm, rel = 0.0;
+                        int we;
+                        pair_term(idx, q, dq, dsq, zq, ze[idx], wm, we, dtb, dl2, rzQ, dmQ, duQ, rel);
+                        acc = xt_fma(xt_ldexp(wm, we - fe), rel, acc);
                     }
                 }
-                if (p < 0)
-                    wsum = acc;
-                else
-                    gsum[0] = acc;
-                // direction p's sum of this thread is parked in direction p's rz plane at entry g AFTER all threads of the track
-                // have finished reading that plane: the plane of direction p is only read in iteration p, and a sync separates
-                // the iterations (all threads of the block run the same trip count NP + 1).
-                cx.sync();
-                if (p >= 0) (tan + p * tstride)[g] = acc;
+                gth[(p + 1) * NG + g] = acc;
             }
-            (void)wsum;
-            zm_dummy_guard:;
-            // the weight total of this thread goes to the primal zm array (the state is not read any more after the loop)
-            cx.sync();
-            zm[g] = wsum;
-        } else {
-            for (int p = -1; p < NP; ++p) cx.sync();
-            cx.sync();
         }
         cx.sync();
-        const bool poisoned = act && red_e[1] != 0;
-        // fixed-order sums over the track's NG threads: thread i of the slot owns column i (0: weight total, 1 + p: direction p)
-        if (act) {
+        // fixed-order sums over the track's NG threads, one column per thread (0: weight total, 1 + p: direction p)
+        if (act)
             for (int col = g; col < NP + 1; col += NG) {
-                const double* src = col == 0 ? zm : tan + (col - 1) * tstride;
-                double s = 0.0;
-                for (int i = 0; i < NG; ++i) s += src[i];
-                src = nullptr;
-                // park the column sums in the u array (free now): uu[col]
-                uu[col % EP + (col / EP) * 0] = s;  // NP + 1 <= EP is checked on the host
+                double s2 = 0.0;
+                for (int i = 0; i < NG; ++i) s2 += gth[col * NG + i];
+                csum[col] = s2;
             }
-        }
         cx.sync();
         if (act) {
-            const double sw = uu[0];
+            const bool poisoned = red_e[1] != 0;
+            const double sw = csum[0];
             const int fe = red_e[0];
             for (int col = g; col < NP + 1; col += NG) {
                 if (col == 0) {
@@ -507,7 +472,7 @@ XT_HD void xt_grad_body(const XtKernelArgs& a, const XtGradArgs& ga, Ctx& cx)
                     if (b.ll_out) b.ll_out[trk] = ll;
                     bacc[0] += ll;
                 } else {
-                    bacc[col] += poisoned ? NAN : uu[col] / sw;
+                    bacc[col] += poisoned ? NAN : csum[col] / sw;
                 }
             }
         }
@@ -520,7 +485,7 @@ XT_HD void xt_grad_body(const XtKernelArgs& a, const XtGradArgs& ga, Ctx& cx)
     double* bacc0 = smem + reg0 + a.TPB * rdoubles;
     for (int col = tid; col < NP + 1; col += cx.nthreads()) {
         double s = 0.0;
-        for (int i = 0; i < a.TPB; ++i) s += bacc0[i * xt_grad_acc_doubles(NP) + col];
+        for (int i = 0; i < a.TPB; ++i) s += bacc0[i * adoubles + col];
         ga.gpartials[(int64_t)cx.block() * (NP + 1) + col] = s;
     }
 }

@@ -1,0 +1,82 @@
+// Host-side table construction for the gradient kernels (plain C++, no HIP): the tangent of every model table of
+// xt_build_blob (xt_tables.h), obtained by running the same construction in dual numbers.
+#pragma once
+#include <vector>
+
+#include "../../include/extrack_hip.h"
+#include "xt_grad.h"
+#include "xt_tables.h"
+
+struct XtDual {
+    double v, d;
+    XtDual(double v_ = 0.0, double d_ = 0.0) : v(v_), d(d_) {}
+};
+static inline XtDual operator+(XtDual a, XtDual b) { return XtDual(a.v + b.v, a.d + b.d); }
+static inline XtDual operator-(XtDual a, XtDual b) { return XtDual(a.v - b.v, a.d - b.d); }
+static inline XtDual operator*(XtDual a, XtDual b) { return XtDual(a.v * b.v, a.d * b.v + a.v * b.d); }
+static inline XtDual operator/(XtDual a, double s) { return XtDual(a.v / s, a.d / s); }
+static inline double xt_dlog(XtDual a) { return a.v != 0.0 ? a.d / a.v : 0.0; }
+
+// One direction's tangent block (layout: xt_grad.h).  `m` is the primal model, `t` its tangent.
+static void xt_build_tangent_block(const XtModelHost& m, const extrack_model_tangent& t, const XtConfig& c, int locerr_mode, double* tb)
+{
+    const int S = c.S, NS = c.NS, G = c.G;
+    const int TBn = xt_grad_tb_doubles(S, G);
+    for (int i = 0; i < TBn; ++i) tb[i] = 0.0;
+    if (locerr_mode == 0)
+        for (int k = 0; k < 3; ++k) {
+            const int kk = k < m.locerr_dims ? k : 0;
+            tb[k] = 2.0 * m.locerr[kk] * t.locerr[kk];
+        }
+    tb[3] = t.slope;
+    tb[4] = t.offset;
+    for (int s = 0; s < S; ++s) tb[8 + s] = m.Fs[s] != 0.0 ? t.Fs[s] / m.Fs[s] : 0.0;
+    const XtDual pBL(m.pBL, t.pBL), one(1.0, 0.0);
+    std::vector<XtDual> T((size_t)S * S), ds2(S), pst(G);
+    for (int i = 0; i < S * S; ++i) T[i] = XtDual(m.TrMat[i], t.TrMat[i]);
+    for (int s = 0; s < S; ++s) ds2[s] = XtDual(m.ds[s] * m.ds[s], t.ds2[s]);
+    for (int r = 0; r < G; ++r) pst[r] = XtDual(m.p_stay[r], t.p_stay[r]);
+    // Eend = T^NS qq,  qq[s] = pBL + (1 - p_stay[s]) - pBL (1 - p_stay[s])   (p_stay indexed by the raw state: tracking.py:297)
+    std::vector<XtDual> v(S), w(S);
+    for (int s = 0; s < S; ++s) {
+        const XtDual q1 = one - pst[s];
+        v[s] = pBL + q1 - pBL * q1;
+    }
+    for (int it = 0; it < NS; ++it) {
+        for (int i = 0; i < S; ++i) {
+            XtDual acc;
+            for (int j = 0; j < S; ++j) acc = acc + T[i * S + j] * v[j];
+            w[i] = acc;
+        }
+        v = w;
+    }
+    double* TAB = tb + XT_BLOB_HDR;
+    const size_t SG = (size_t)S * G;
+    for (int prev = 0; prev < S; ++prev)
+        for (int q = 0; q < G; ++q) {
+            int chain[8];
+            chain[0] = prev;
+            int r = q;
+            for (int j = 1; j <= NS; ++j) {
+                chain[j] = r % S;
+                r /= S;
+            }
+            XtDual tp = one, d2;
+            for (int j = 0; j < NS; ++j) {
+                tp = tp * T[chain[j] * S + chain[j + 1]];
+                d2 = d2 + (ds2[chain[j]] + ds2[chain[j + 1]]) / 2.0;
+            }
+            d2 = d2 / (double)NS;
+            int rref = 0;
+            for (int cc = 0; cc < NS; ++cc) rref += chain[NS - cc] * c.pw[cc];
+            const XtDual stay = pst[rref] * (one - pBL);
+            const XtDual ee = v[chain[NS]];
+            const size_t o = (size_t)prev * G + q;
+            TAB[0 * SG + o] = xt_dlog(tp);
+            TAB[1 * SG + o] = xt_dlog(tp * stay);
+            TAB[2 * SG + o] = xt_dlog(tp * ee);
+            TAB[3 * SG + o] = xt_dlog(tp * stay * ee);
+            TAB[4 * SG + o] = d2.d;
+        }
+}
+

@@ -111,6 +111,11 @@ struct extrack_ctx {
     unsigned blob_turn = 0;
     double* d_preds = nullptr;      // posterior output buffer, kept between extrack_predict / extrack_predict_th calls
     size_t preds_cap = 0;
+    double* d_dblob = nullptr;      // gradient path: tangent tables [n_dir][TB]
+    size_t dblob_cap = 0;           // doubles
+    double* d_gpartials = nullptr;  // gradient path: per-block partial sums [grid][NP + 1] + the reduced row
+    size_t gpartials_cap = 0;       // doubles
+    float grad_ms = 0.f;            // device time of the gradient kernels of the last extrack_loglik_grad call
     double* d_partials = nullptr;
     size_t partials_cap = 0;
     double* d_total = nullptr;

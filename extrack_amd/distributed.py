@@ -75,6 +75,12 @@ class Comm:
         self.dist.all_reduce(t, op=ops[op], group=self.group)
         return float(t.item())
 
+    def allreduce_vector(self, v):
+        """Sum of a small fp64 vector over the ranks (objective + gradient: 1 + nvar doubles per evaluation)."""
+        t = self.torch.as_tensor(np.asarray(v, dtype=np.float64), device=self.device).clone()
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        return t.cpu().numpy()
+
     def global_min_max_len(self, lengths):
         lo = min(lengths) if len(lengths) else 1 << 30
         hi = max(lengths) if len(lengths) else 0

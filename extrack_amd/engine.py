@@ -46,6 +46,35 @@ def _p_stay_table(ds, nb_states, nb_substeps, cell_dims):
     return out
 
 
+def p_stay_table_grad(ds, nb_states, nb_substeps, cell_dims):
+    """(p_stay [G], d p_stay / d(ds^2) [G, S]) for the gradient path: the table of ``_p_stay_table`` and its analytic derivative
+    with respect to the SQUARED diffusion lengths (finite at ds = 0, where the table is flat).
+    With sigma_r = sqrt(mean_c ds^2[g_c(r)]) and one cell dimension c: p = mean_x [Phi((c - x)/sigma) - Phi(-x/sigma)],
+    dp/dsigma = -mean_x [phi((c - x)/sigma) (c - x) + phi(x/sigma) x] / sigma^2, d sigma / d ds^2[s] = count_s(r) / (2 ns sigma)."""
+    S, ns = int(nb_states), int(nb_substeps)
+    ds2 = np.asarray(ds, float) ** 2
+    r = np.arange(S ** ns)
+    cnt = np.zeros((len(r), S))
+    for c in range(ns):
+        cnt[r, (r // S ** c) % S] += 1
+    sig = np.sqrt(cnt @ ds2 / ns)
+    p = np.ones(len(r))
+    dlogp = np.zeros(len(r))  # d log p / d sigma, summed over the cell dimensions
+    with np.errstate(divide="ignore", invalid="ignore", over="ignore", under="ignore"):
+        for cell_len in cell_dims:
+            xs = np.linspace(0 + cell_len / 2000, cell_len - cell_len / 2000, 1000)[:, None]
+            a, b = (cell_len - xs) / (sig + 1e-200), xs / (sig + 1e-200)
+            cur = np.mean(ndtr(a) - ndtr(-b), 0)
+            phi = lambda z: np.exp(-0.5 * z * z) / np.sqrt(2 * np.pi)
+            num = np.mean(phi(a) * a + phi(b) * b, 0)  # = mean[phi(.)(c-x) + phi(.)x] / sigma
+            dcur = np.where(num > 0, -num / (sig + 1e-200), 0.0)
+            p = p * cur
+            dlogp = dlogp + np.where(cur > 0, dcur / np.where(cur > 0, cur, 1.0), 0.0)
+        dsig = np.where(sig[:, None] > 0, cnt / (2 * ns * np.where(sig > 0, sig, 1.0)[:, None]), 0.0)
+    dp = np.nan_to_num((p * dlogp)[:, None] * dsig, nan=0.0, posinf=0.0, neginf=0.0)
+    return p, dp
+
+
 def sort_buckets(all_tracks, input_LocErr=None):
     """Numeric sort of the length keys, dropping empty buckets (extrack/tracking.py:1346-1367).
 

@@ -32,33 +32,25 @@ from . import engine
 from .engine import TrackSet
 from .lmfit_compat import Parameters, is_parameters, minimize
 
-__all__ = ["param_fitting", "predict_Bs", "cum_Proba_Cs", "Proba_Cs", "P_Cs_inter_bound_stats", "extract_params",
+__all__ = ["param_fitting", "predict_Bs", "cum_Proba_Cs", "cum_Proba_Cs_grad", "Proba_Cs", "P_Cs_inter_bound_stats", "extract_params",
            "generate_params", "get_params", "TrackSet"]
 
 
 # ------------------------------------------------------------------------------------------------------------
 # parameter plumbing
 # ------------------------------------------------------------------------------------------------------------
-def extract_params(params, dt, nb_states, nb_substeps, input_LocErr=None, Matrix_type=1):
-    """Parameters -> (LocErr, ds, Fs, TrMat, pBL); mirrors extrack/tracking.py:913-986.
-
-    ``nb_states`` is accepted and unused, exactly like the reference.  ``LocErr`` is a list: one
-    (1,1,k) array for a global error, or one per-peak array per bucket when ``input_LocErr`` is given
-    (affinely rescaled and clipped at 1e-6 if ``slope_LocErr``/``offset_LocErr`` are parameters)."""
-    if isinstance(dt, (list, dict)):
-        raise NotImplementedError("per-track time steps (dt as list/dict, extrack/tracking.py:979-982) are not built: scalar dt only")
+def _extract_arrays(params, dt, nb_substeps, Matrix_type=1):
+    """The arithmetic of extract_params on any mapping ``{name: object with .value}`` - real or COMPLEX values (the gradient path
+    differentiates it by the complex-step method, extrack_amd/gradient.py).  Returns (global LocErr [k], Ds [S], Fs [S],
+    TrMat [S, S], pBL, (slope, offset) or None)."""
     names = np.sort(list(params.keys()))
-    LocErr = [np.array([params[n].value for n in names if n.startswith("LocErr")])[None, None]]
-    if input_LocErr is not None:
-        if "slope_LocErr" in params:
-            sl, of = params["slope_LocErr"].value, params["offset_LocErr"].value
-            LocErr = [np.clip(le * sl + of, 0.000001, np.inf) for le in input_LocErr]
-        else:
-            LocErr = input_LocErr
+    le = np.array([params[n].value for n in names if n.startswith("LocErr")])
+    so = (params["slope_LocErr"].value, params["offset_LocErr"].value) if "slope_LocErr" in params else None
     Ds = np.array([params[n].value for n in names if n.startswith("D") and len(n) < 3])
     Fs = np.array([params[n].value for n in names if n.startswith("F")])
     S = len(Ds)
-    TrMat = np.zeros((S, S))
+    cplx = any(isinstance(params[n].value, complex) for n in params)
+    TrMat = np.zeros((S, S), dtype=complex if cplx else float)
     pBL = None
     for n in params:
         if n == "pBL":
@@ -82,6 +74,24 @@ def extract_params(params, dt, nb_states, nb_substeps, input_LocErr=None, Matrix
         G[diag, diag] = -np.sum(G, 1)
         TrMatG = linalg.expm(G)
         TrMat = np.mean([TrMat, TrMatG], axis=0) if Matrix_type == 3 else (TrMat * TrMatG) ** 0.5
+    return le, Ds, Fs, TrMat, pBL, so
+
+
+def extract_params(params, dt, nb_states, nb_substeps, input_LocErr=None, Matrix_type=1):
+    """Parameters -> (LocErr, ds, Fs, TrMat, pBL); mirrors extrack/tracking.py:913-986.
+
+    ``nb_states`` is accepted and unused, exactly like the reference.  ``LocErr`` is a list: one
+    (1,1,k) array for a global error, or one per-peak array per bucket when ``input_LocErr`` is given
+    (affinely rescaled and clipped at 1e-6 if ``slope_LocErr``/``offset_LocErr`` are parameters)."""
+    if isinstance(dt, (list, dict)):
+        raise NotImplementedError("per-track time steps (dt as list/dict, extrack/tracking.py:979-982) are not built: scalar dt only")
+    le, Ds, Fs, TrMat, pBL, so = _extract_arrays(params, dt, nb_substeps, Matrix_type)
+    LocErr = [le[None, None]]
+    if input_LocErr is not None:
+        if so is not None:
+            LocErr = [np.clip(x * so[0] + so[1], 0.000001, np.inf) for x in input_LocErr]
+        else:
+            LocErr = input_LocErr
     ds = np.sqrt(2 * Ds * dt)
     return LocErr, ds, Fs, TrMat, pBL
 
@@ -331,18 +341,54 @@ def cum_Proba_Cs(params, all_tracks, dt, cell_dims, input_LocErr, nb_states, nb_
     return out
 
 
+def cum_Proba_Cs_grad(params, names, all_tracks, dt, cell_dims, input_LocErr, nb_states, nb_substeps, frame_len, verbose=1, workers=1,
+                      Matrix_type=1, threshold=0.2, max_nb_states=120, max_number_of_tracks_per_matrix=2000, comm=None, fusion=None,
+                      device=None):
+    """(objective, gradient): ``cum_Proba_Cs`` (fixed-window kernel) and its exact derivative with respect to the VALUES of the free
+    parameters ``names``, from ONE pass of the gradient kernel (extrack_loglik_grad) instead of the nvar + 1 evaluations the
+    reference's optimiser spends on finite differences (extrack/tracking.py:1371).  Same argument list as ``cum_Proba_Cs`` after
+    ``names``; same prints; (+inf, zeros) for invalid parameters or NaN."""
+    from . import gradient
+    if _check_fusion(fusion):
+        raise ValueError("the analytic gradient exists for the fixed-window kernel only (the threshold-fusion objective is only "
+                         "piecewise smooth in the parameters)")
+    ts, owned = _as_trackset(all_tracks, input_LocErr, device, comm)
+    try:
+        out, g = gradient.objective_and_gradient(params, ts, dt, cell_dims, nb_states, nb_substeps, frame_len, Matrix_type, comm, names)
+    finally:
+        if owned:
+            ts.close()
+    if np.isfinite(out):
+        if verbose == 1:
+            q = [p + " = " + str(np.round(params[p].value, 6)) for p in params]
+            print(-out, q)
+        else:
+            print(".", end="")
+    elif np.isnan(out):
+        out, g = np.inf, np.zeros(len(g))
+        print("input parameters give nans, you may want to pick more suitable parameter initial values")
+    else:
+        print("x", end="")
+        if verbose == 1:
+            print([p + " = " + str(np.round(params[p].value, 4)) for p in params])
+    return out, g
+
+
 # ------------------------------------------------------------------------------------------------------------
 # public API
 # ------------------------------------------------------------------------------------------------------------
 def param_fitting(all_tracks, dt, params=None, nb_states=2, nb_substeps=1, frame_len=6, verbose=1, workers=1, Matrix_type=1,
                   method="bfgs", steady_state=False, cell_dims=[1], input_LocErr=None, threshold=0.2, max_nb_states=120,
-                  device=None, comm=None, fusion=None):
+                  device=None, comm=None, fusion=None, gradient=None):
     """Fit the model parameters to a length-bucketed track dict (extrack/tracking.py:1299-1386).
 
     all_tracks: {str(len): ndarray[n_tracks, len, dims]}.  Returns the lmfit (or lmfit_compat) MinimizerResult:
     ``.params[name].value``, ``.residual[0] == -log-likelihood``.  Extra keywords: ``device`` (GPU index; default: the
     communicator's device, else 0), ``comm`` (distributed shard communicator: every rank passes the WHOLE dataset and keeps its
-    shard), ``fusion`` ("window" | "threshold" | None = process default, see the module docstring)."""
+    shard), ``fusion`` ("window" | "threshold" | None = process default, see the module docstring), ``gradient``
+    ("analytic": the optimiser gets the exact gradient from the GPU, one evaluation per iteration; "fd": it differences the
+    objective like the reference's; None: analytic where it exists - fixed-window kernel, gradient-based method, the built-in
+    lmfit-compatible minimiser - else fd)."""
     fusion = "threshold" if _check_fusion(fusion) else "window"
     device = _resolve_device(device, comm)
     if params is None:
@@ -359,11 +405,18 @@ def param_fitting(all_tracks, dt, params=None, nb_states=2, nb_substeps=1, frame
         ts = comm.shard_trackset(tracks, sigmas, device=device, chunk=2000 if fusion == "threshold" else None)
     else:
         ts = TrackSet(tracks, sigmas, device=device)
+    from . import lmfit_compat
+    can_grad = fusion == "window" and not lmfit_compat.HAVE_LMFIT and str(method).lower() in lmfit_compat._GRADIENT_METHODS
+    if gradient not in (None, "analytic", "fd"):
+        raise ValueError("gradient must be None, 'analytic' or 'fd'")
+    if gradient == "analytic" and not can_grad:
+        raise ValueError("gradient='analytic' needs fusion='window', a gradient-based method and the built-in minimiser")
+    extra = dict(fcn_grad=cum_Proba_Cs_grad) if can_grad and gradient != "fd" else {}
     try:
         fit = minimize(cum_Proba_Cs, params,
                        args=(ts, dt, cell_dims, sigmas, nb_states, nb_substeps, frame_len, verbose, workers, Matrix_type, threshold,
                              max_nb_states, 2000, comm, fusion),
-                       method=method, nan_policy="propagate")
+                       method=method, nan_policy="propagate", **extra)
     finally:
         ts.close()
     if verbose == 0:

@@ -26,6 +26,10 @@
  *       the merge groups fuse_tracks_th decided for one chunk and step (tracking.py:681-701) - diagnostic.
  *   extrack_p_stay_table
  *       the field-of-view survival table, extrack/tracking.py:182-191.
+ *   extrack_loglik_grad
+ *       extrack_loglik AND its exact gradient in one pass.  It replaces the finite-difference loop that the reference's
+ *       optimiser runs around cum_Proba_Cs (lmfit.minimize at extrack/tracking.py:1371: BFGS evaluates the objective
+ *       nvar + 1 times per iteration to difference it numerically).
  *
  * Conventions: plain C, no exceptions cross the boundary.  Every function returns 0 on success or a
  * negative EXTRACK_E_* code; extrack_last_error() gives the message.  The caller owns every host
@@ -41,7 +45,7 @@
 extern "C" {
 #endif
 
-#define EXTRACK_ABI_VERSION 2
+#define EXTRACK_ABI_VERSION 3
 
 #define EXTRACK_OK 0
 #define EXTRACK_E_INVALID (-1)     /* bad argument / unsupported configuration */
@@ -108,6 +112,29 @@ int extrack_loglik_async(extrack_ctx* ctx, const extrack_model* model, double* d
 /* State posteriors of one bucket: preds host [n][len][S].  model->nb_substeps must be 1
  * (predict_Bs forces it, extrack/tracking.py:839). */
 int extrack_predict(extrack_ctx* ctx, const extrack_model* model, int32_t bucket_id, double* preds);
+
+/* Tangent of a model along one direction theta: d(field)/d(theta) for every differentiable field of extrack_model.
+ * The diffusion lengths enter as the derivative of their SQUARES (ds^2 = 2 D dt is what the recursion uses, and it keeps the
+ * derivative finite at D = 0).  p_stay is a function of ds and cell_dims computed by the caller (extrack_p_stay_table), so its
+ * tangent comes from the caller too. */
+typedef struct extrack_model_tangent {
+    double locerr[3];     /* d locerr (std), mode 0 */
+    double slope, offset; /* mode 2 */
+    double pBL;
+    const double* ds2;    /* [S]    d (ds^2) */
+    const double* Fs;     /* [S] */
+    const double* TrMat;  /* [S*S] */
+    const double* p_stay; /* [S^ns] */
+} extrack_model_tangent;
+
+/* One evaluation of the fixed-window log-likelihood (as extrack_loglik) together with its derivative along n_dir model
+ * directions, by forward-mode differentiation inside the recursion (window fusion included: it is the exact gradient of the
+ * value extrack_loglik returns, not an approximation).  total_ll: sum of per-track log-likelihoods; grad[i] = d total_ll /
+ * d theta_i (host, n_dir entries).  n_dir may be 0 (then it is extrack_loglik through the gradient kernel). */
+int extrack_loglik_grad(extrack_ctx* ctx, const extrack_model* model, int32_t n_dir, const extrack_model_tangent* tangents,
+                        double* total_ll, double* grad);
+/* Device time (ms) of the gradient kernels of the last extrack_loglik_grad call. */
+int extrack_last_grad_ms(extrack_ctx* ctx, float* ms);
 
 /* Threshold-fusion log-likelihood (the kernel extrack.tracking.param_fitting / cum_Proba_Cs call in v1.6.3,
  * extrack/tracking.py:427-743).  Which state sequences are merged at a step is decided from the first 30 tracks

@@ -12,6 +12,8 @@
 #include "../../extrack_amd/csrc/xt_dispatch.h"
 #include "../../extrack_amd/csrc/xt_entry.h"
 #include "../../extrack_amd/csrc/xt_fast2.h"
+#include "../../extrack_amd/csrc/xt_grad.h"
+#include "../../extrack_amd/csrc/xt_grad_host.h"
 #include "../../extrack_amd/csrc/xt_tables.h"
 #include "../../extrack_amd/csrc/xt_th.h"
 
@@ -611,5 +613,118 @@ extern "C" int xt_emul_th_run_multi(int nbuckets, const double** tracks, const l
     double sacc = 0.0;
     for (double p : partials) sacc += p;
     if (total) *total = sacc;
+    return 0;
+}
+
+
+// ---- likelihood + gradient body (xt_grad.h): one bucket, all directions in one pass ------------------------------------------
+struct EmulGradLauncher {
+    XtKernelArgs a;
+    XtGradArgs ga;
+    int threads, nblocks;
+    size_t lds_doubles;
+    template <int G_, int D, int K>
+    bool run()
+    {
+        for (int b = 0; b < nblocks; ++b) {
+            std::vector<double> smem(lds_doubles + 16, 0.0);
+            pthread_barrier_t bar;
+            pthread_barrier_init(&bar, nullptr, threads);
+            std::vector<std::thread> th;
+            for (int t = 0; t < threads; ++t)
+                th.emplace_back([&, t]() {
+                    HostCtx cx{t, threads, b, nblocks, smem.data(), &bar};
+                    xt_grad_body<G_, D, K>(a, ga, cx);
+                });
+            for (auto& x : th) x.join();
+            pthread_barrier_destroy(&bar);
+        }
+        return true;
+    }
+};
+
+template <int GG, class L>
+static bool emul_grad_dispatch_dk(int D, int K, L& l)
+{
+    if (D == 1 && K == 1) return l.template run<GG, 1, 1>();
+    if (D == 2 && K == 1) return l.template run<GG, 2, 1>();
+    if (D == 2 && K == 2) return l.template run<GG, 2, 2>();
+    if (D == 3 && K == 1) return l.template run<GG, 3, 1>();
+    if (D == 3 && K == 3) return l.template run<GG, 3, 3>();
+    return false;
+}
+
+// tangents: n_dir rows of [locerr(3), slope, offset, pBL, ds2(S), Fs(S), TrMat(S*S), p_stay(G)]
+extern "C" int xt_emul_grad(const double* tracks, const double* sigma, long long N, int L, int D, int KS, int S, int NS, int F, int isBL,
+                            int min_len, int locerr_mode, int locerr_dims, const double* locerr, double slope, double offset, double pBL,
+                            const double* ds, const double* Fs, const double* TrMat, const double* p_stay, int n_dir, const double* tangents,
+                            int nblocks, int tpb, int tan_lds, int generic_g, double* ll_out, double* out /* [1 + n_dir] */)
+{
+    XtConfig cfg;
+    if (!xt_build_config(S, NS, F, cfg).empty()) return -1;
+    XtModelHost m{S, NS, locerr_dims, {0, 0, 0}, slope, offset, pBL, ds, Fs, TrMat, p_stay};
+    for (int k = 0; k < 3; ++k) m.locerr[k] = locerr ? locerr[k < locerr_dims ? k : 0] : 0.0;
+    std::vector<double> blob;
+    xt_build_blob(m, cfg, blob);
+    const int K = locerr_mode == 0 ? locerr_dims : KS;
+    const int TB = xt_grad_tb_doubles(S, cfg.G);
+    const int row = 6 + 2 * S + S * S + cfg.G;
+    std::vector<double> dblob((size_t)(n_dir > 0 ? n_dir : 1) * TB, 0.0);
+    for (int i = 0; i < n_dir; ++i) {
+        const double* r = tangents + (size_t)i * row;
+        extrack_model_tangent t;
+        for (int k = 0; k < 3; ++k) t.locerr[k] = r[k];
+        t.slope = r[3];
+        t.offset = r[4];
+        t.pBL = r[5];
+        t.ds2 = r + 6;
+        t.Fs = r + 6 + S;
+        t.TrMat = r + 6 + 2 * S;
+        t.p_stay = r + 6 + 2 * S + S * S;
+        xt_build_tangent_block(m, t, cfg, locerr_mode, dblob.data() + (size_t)i * TB);
+    }
+    EmulGradLauncher l;
+    memset(&l.a, 0, sizeof(l.a));
+    xt_fill_args_from_config(cfg, l.a);
+    const int threads = (tpb * cfg.NG + 63) / 64 * 64;
+    if (threads > 1024) return -2;
+    std::vector<double> gp((size_t)nblocks * (n_dir + 1), 0.0);
+    l.a.tracks = tracks;
+    l.a.sigma = locerr_mode ? sigma : nullptr;
+    l.a.blob = blob.data();
+    l.a.base_tab = cfg.base_tab.data();
+    l.a.off_tab = cfg.off_tab.data();
+    l.a.ll_out = ll_out;
+    l.a.N = N;
+    l.a.L = L;
+    l.a.TPB = tpb;
+    l.a.isBL = isBL;
+    l.a.min_len = min_len;
+    l.a.locerr_mode = locerr_mode;
+    l.a.KS = KS;
+    l.a.ll_const = -(double)(L - 1) * D * 0.5 * XT_LOG2PI;
+    if (generic_g) l.a.G = cfg.G;
+    l.ga.dblob = dblob.data();
+    l.ga.gpartials = gp.data();
+    l.ga.NP = n_dir;
+    l.ga.TB = TB;
+    l.ga.tan_lds = tan_lds;
+    l.threads = threads;
+    l.nblocks = nblocks;
+    size_t d = (size_t)((xt_tab_doubles(S, cfg.G) + 1) & ~1);
+    if (tan_lds) d += (size_t)((n_dir * TB + 1) & ~1);
+    d += (size_t)tpb * ((size_t)xt_grad_region_doubles(cfg.EP, D, K, n_dir) + xt_grad_acc_doubles(n_dir, cfg.NG) + xt_stage_doubles(D));
+    l.lds_doubles = d;
+    bool ok;
+    if (generic_g || cfg.G > 4) ok = emul_grad_dispatch_dk<0>(D, K, l);
+    else if (cfg.G == 2) ok = emul_grad_dispatch_dk<2>(D, K, l);
+    else if (cfg.G == 3) ok = emul_grad_dispatch_dk<3>(D, K, l);
+    else ok = emul_grad_dispatch_dk<4>(D, K, l);
+    if (!ok) return -3;
+    for (int c = 0; c < n_dir + 1; ++c) {
+        double s2 = 0.0;
+        for (int b = 0; b < nblocks; ++b) s2 += gp[(size_t)b * (n_dir + 1) + c];
+        out[c] = s2;
+    }
     return 0;
 }

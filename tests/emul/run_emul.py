@@ -13,7 +13,8 @@ def lib():
     if _lib is None:
         so = os.path.join(HERE, "libxt_emul.so")
         src = os.path.join(HERE, "emul.cpp")
-        hdrs = [os.path.join(HERE, "..", "..", "extrack_amd", "csrc", h) for h in ("xt_kernel.h", "xt_math.h", "xt_tables.h", "xt_dispatch.h", "xt_th.h", "xt_entry.h", "xt_fast2.h")]
+        hdrs = [os.path.join(HERE, "..", "..", "extrack_amd", "csrc", h) for h in ("xt_kernel.h", "xt_math.h", "xt_tables.h", "xt_dispatch.h", "xt_th.h", "xt_entry.h", "xt_fast2.h", "xt_grad.h",
+                                                                                             "xt_grad_host.h")]
         if not os.path.exists(so) or any(os.path.getmtime(f) > os.path.getmtime(so) for f in [src] + hdrs):
             import subprocess
             subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-pthread", "-o", so, src])
@@ -168,3 +169,41 @@ def run_th_multi(buckets, locerr, ds, Fs, T, pBL, p_stay, ns, F, min_len, max_le
     if rc != 0:
         raise RuntimeError("emul th multi rc=%d" % rc)
     return outs, tot.value
+
+
+def run_grad(Cs, LE, ds, Fs, T, pBL, isBL, p_stay, ns, F, min_len, tangents, nblocks=2, tpb=2, tan_lds=1, generic_g=0, slope=None, offset=None):
+    """Likelihood + gradient body on CPU threads.  tangents: list of dicts (keys ds2, Fs, TrMat, p_stay, locerr, slope, offset, pBL).
+    Returns (per-track LL, total LL, gradient[n_dir])."""
+    Cs = np.ascontiguousarray(Cs, float)
+    N, L, D = Cs.shape
+    S = len(ds)
+    G = S ** ns
+    LE = np.ascontiguousarray(LE, float)
+    if LE.shape[1] == 1 and L != 1:
+        mode, K, KS = 0, LE.shape[2], 1
+        locerr = np.zeros(3)
+        locerr[:K] = LE[0, 0]
+        sigma = None
+    else:
+        mode, KS = (2 if slope is not None else 1), LE.shape[2]
+        K, locerr, sigma = KS, np.zeros(3), LE
+    rows = []
+    for t in tangents:
+        le = np.zeros(3)
+        v = np.atleast_1d(np.asarray(t.get("locerr", 0.0), float)).ravel()
+        le[:len(v)] = v
+        rows.append(np.concatenate([le, [t.get("slope", 0.0), t.get("offset", 0.0), t.get("pBL", 0.0)],
+                                    np.broadcast_to(np.asarray(t.get("ds2", 0.0), float), (S,)),
+                                    np.broadcast_to(np.asarray(t.get("Fs", 0.0), float), (S,)),
+                                    np.broadcast_to(np.asarray(t.get("TrMat", 0.0), float), (S, S)).ravel(),
+                                    np.broadcast_to(np.asarray(t.get("p_stay", 0.0), float), (G,))]))
+    tan = np.ascontiguousarray(np.array(rows, float)) if rows else np.zeros((1, 1))
+    ll = np.zeros(N)
+    out = np.zeros(len(tangents) + 1)
+    ds, Fs, T, p_stay = [np.ascontiguousarray(x, float) for x in (ds, Fs, T, p_stay)]
+    rc = lib().xt_emul_grad(dp(Cs), dp(sigma), C.c_longlong(N), L, D, KS, S, ns, F, int(isBL), int(min_len), mode, K, dp(locerr),
+                            C.c_double(slope or 0.0), C.c_double(offset or 0.0), C.c_double(pBL), dp(ds), dp(Fs), dp(T), dp(p_stay),
+                            len(tangents), dp(tan), nblocks, tpb, tan_lds, generic_g, dp(ll), dp(out))
+    if rc != 0:
+        raise RuntimeError("emul grad rc=%d" % rc)
+    return ll, out[0], out[1:]
