@@ -179,6 +179,16 @@ def other_configs(device):
                                     "flop_model": fl, "fp64_tflops": fl / (kms * 1e-3) / 1e12,
                                     "fp64_frac": fl / (kms * 1e-3) / 1e12 / FP64_VALU_PEAK_TF, "neg_loglik": -v,
                                     "launch": ts.ctx.last_launch_info()}
+    # likelihood + exact gradient in one pass (13 free parameters) vs the 14 evaluations a finite-difference gradient costs
+    from extrack_amd import gradient
+    pg = tracking.generate_params(nb_states=3, LocErr_type=1, estimated_Ds=[1e-4, 0.04, 0.25], estimated_LocErr=[0.02], estimated_Fs=[0.3, 0.3],
+                                  estimated_transition_rates=0.06)
+    names = gradient.free_names(pg)
+    for _ in range(2):
+        gv, gg = gradient.objective_and_gradient(pg, ts, DT, CELL, 3, 1, 4, names=names)
+    out["c3_loglik_grad_F4"] = {"what": "configs[2], frame_len 4: -sum(LL) AND its exact gradient (13 free parameters) in one pass", "kernel_ms": ts.ctx.last_grad_ms(),
+                                "n_directions": len(names), "fd_equivalent_ms": (len(names) + 1) * out["c3_loglik_F4"]["kernel_ms"],
+                                "grad_inf_norm": float(np.abs(gg).max())}
     model = tracking._objective_model(P(vals), ts, DT, CELL, None, 3, 1, 6, 1)
     wall, kms, v = timed(lambda: ts.loglik_th(model, 0.2, 120, 2000), 3)
     out["c3_loglik_threshold"] = {"what": "configs[2] through the threshold-fusion kernels (v1.6.3 defaults, frame_len 6)", "ms_per_eval": wall * 1e3,
@@ -313,6 +323,17 @@ def main():
     # 2000-track chunks): plan kernel + apply kernel per evaluation
     launch_info = ts.ctx.last_launch_info()
     th = None
+    grad_info = None
+    if world == 1 and a.tracks == N_TRACKS and a.config == "c2":
+        from extrack_amd import gradient
+        pg = tracking.generate_params(nb_states=2, LocErr_type=1, estimated_Ds=[1e-3, DS_COEF[1]], estimated_LocErr=[LOCERR], estimated_Fs=[FS[0]],
+                                      estimated_transition_rates=0.1)
+        gnames = gradient.free_names(pg)
+        for _ in range(2):
+            gv, gg = gradient.objective_and_gradient(pg, ts, DT, CELL, S, NS, FRAME, names=gnames)
+        grad_info = {"what": "BASELINE configs[1] data: -sum(LL) AND its exact gradient (7 free parameters) in one pass of the gradient kernel "
+                             "(extrack_loglik_grad), the evaluation an analytic-gradient BFGS iteration costs",
+                     "kernel_ms": ts.ctx.last_grad_ms(), "n_directions": len(gnames), "grad_inf_norm": float(np.abs(gg).max())}
     if world == 1 and a.tracks == N_TRACKS and a.config == "c2":
         for _ in range(2):
             th_val = ts.loglik_th(model, 0.2, 120, 2000)
@@ -372,6 +393,9 @@ def main():
     }
     if th is not None:
         out["threshold_fusion"] = th
+    if grad_info is not None:
+        grad_info["fd_equivalent_ms"] = (grad_info["n_directions"] + 1) * k_ms
+        out["loglik_gradient"] = grad_info
     if extra is not None:
         out["extra"] = extra
     if not a.no_cpu_baseline and world == 1:

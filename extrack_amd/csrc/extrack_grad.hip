@@ -5,8 +5,13 @@
 #include "xt_grad.h"
 #include "xt_grad_host.h"
 
+// Waves per SIMD the register allocator is asked to allow.  Measured on C2 (1e6 x 30, 7 directions, PJ = 4): 2 -> 63 ms,
+// 3 -> 53 ms (168 VGPRs, 108 B of scratch per lane), 4 -> 60 ms (128 VGPRs, 272 B of scratch).
+#ifndef XT_GRAD_WAVES
+#define XT_GRAD_WAVES 3
+#endif
 template <int G_, int D, int K, int MAXT>
-__global__ void __launch_bounds__(MAXT) xt_grad_kernel(XtKernelArgs a, XtGradArgs ga)
+__global__ void __launch_bounds__(MAXT, (MAXT == 256 ? XT_GRAD_WAVES : 1)) xt_grad_kernel(XtKernelArgs a, XtGradArgs ga)
 {
     DevCtx cx;
     xt_grad_body<G_, D, K>(a, ga, cx);
@@ -185,10 +190,18 @@ extern "C" int extrack_loglik_grad(extrack_ctx* ctx, const extrack_model* m, int
             const size_t per_track = xt_grad_lds_bytes(c, D, K, NP, 1, tan_lds) - xt_grad_lds_bytes(c, D, K, NP, 0, tan_lds);
             const size_t fixed = xt_grad_lds_bytes(c, D, K, NP, 0, tan_lds);
             const size_t budget = 64 * 1024;
-            const int by_threads = c.NG >= 256 ? 1 : 256 / c.NG;
+            // PJ lanes per group: about two directions per lane, as long as a track's threads fit a workgroup
+            int PJ = 1;
+            while (PJ < 8 && PJ * 2 <= NP && NP > 2 * PJ - 1 && c.NG * PJ * 2 <= 1024) PJ *= 2;
+            if (const char* ev = getenv("EXTRACK_GRAD_PJ")) {
+                const int v = atoi(ev);
+                if ((v == 1 || v == 2 || v == 4 || v == 8) && c.NG * v <= 1024) PJ = v;
+            }
+            const int NT = c.NG * PJ;
+            const int by_threads = NT >= 256 ? 1 : 256 / NT;
             const int by_lds = budget > fixed + per_track ? (int)((budget - fixed) / per_track) : 1;
             int tpb = std::max(1, std::min(by_threads, by_lds));
-            const int threads = (tpb * c.NG + 63) / 64 * 64;
+            const int threads = (tpb * NT + 63) / 64 * 64;
             if (threads > 1024) return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "n_states^(frame_len-nb_substeps) > 1024 groups per track is not built");
             l.threads = threads;
             l.lds = xt_grad_lds_bytes(c, D, K, NP, tpb, tan_lds);
@@ -225,6 +238,7 @@ extern "C" int extrack_loglik_grad(extrack_ctx* ctx, const extrack_model* m, int
             l.ga.NP = NP;
             l.ga.TB = TB;
             l.ga.tan_lds = tan_lds ? 1 : 0;
+            l.ga.PJ = PJ;
             XT_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
             if (!xt_grad_dispatch(c.G, D, K, l)) return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "gradient kernel variant not built");
             if (l.herr != hipSuccess) return xt_fail(ctx, EXTRACK_E_HIP, std::string("gradient kernel launch: ") + hipGetErrorString(l.herr));

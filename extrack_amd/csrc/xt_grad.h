@@ -21,9 +21,11 @@
 //     dm'  = d m_bar (1 - tt) + (c - m_bar) d tt,       du' = d l2 tt + l2 d tt
 // last position: LL = log sum_{Q,q} w_Qq,  dLL = sum w_Qq (rz_Q + dlogTF[q] - (D/2) r d den - d quad) / sum w_Qq.
 //
-// Mapping: one thread per group as in xt_track_body; the tangents of a track's sequences live in LDS next to the primal
-// state ((1 + D + K) doubles per sequence and direction) and are updated in place, direction by direction, before the primal
-// values of the step are overwritten.  Per-track and per-block sums are taken in a fixed order (no floating-point atomics):
+// Mapping: PJ threads per group (adjacent lanes of one wavefront); the tangents of a track's sequences live in LDS next to the
+// primal state ((1 + D + K) doubles per sequence and direction) - that, not the arithmetic, limits how many tracks a CU holds, so
+// the directions of a group are dealt over PJ lanes: every lane repeats the (cheap) primal merge of its group from broadcast LDS
+// reads, carries the directions j, j + PJ, ..., and lane j == 0 stores the new primal state after the tangents of the step have
+// been updated in place.  Per-track and per-block sums are taken in a fixed order (no floating-point atomics):
 // the result is bit-reproducible for a given launch geometry.
 #pragma once
 #include "xt_kernel.h"
@@ -34,14 +36,15 @@ struct XtGradArgs {
     int32_t NP;            // directions
     int32_t TB;            // doubles per direction: XT_BLOB_HDR + XT_NTAB * S * G
     int32_t tan_lds;       // 1: the tangent tables are copied to LDS (small models), 0: read from global memory
-    int32_t reserved;
+    int32_t PJ;            // threads per group: thread (g, j) carries the directions j, j + PJ, ... (power of two, adjacent lanes)
 };
 // Tangent table block of one direction (TB doubles):
 //   [0..2] d l2 (global localisation error),  [3] d slope,  [4] d offset,  [8 + s] d log Fs[s]
 //   XT_BLOB_HDR + (v * S + prev) * G + q :  v = 0..3  d log of table v (T, T*stay, T*Eend, T*stay*Eend);  v = 4  d d2 (absolute)
 XT_HD int xt_grad_tb_doubles(int S, int G) { return XT_BLOB_HDR + XT_NTAB * S * G; }
-// LDS doubles per track: primal region + NP tangent planes
-XT_HD int xt_grad_region_doubles(int EP, int D, int K, int NP) { return xt_region_doubles(EP, D, K) + NP * EP * (1 + D + K); }
+// LDS doubles per track: two primal regions (read / write, swapped every step: no lane ever overwrites state that a lane of
+// another direction still reads) + NP tangent planes
+XT_HD int xt_grad_region_doubles(int EP, int D, int K, int NP) { return 2 * xt_region_doubles(EP, D, K) + NP * EP * (1 + D + K); }
 // per track slot: block accumulators bacc[NP + 1], column sums csum[NP + 1], per-thread partials gth[NP + 1][NG]
 XT_HD int xt_grad_acc_doubles(int NP, int NG) { return 2 * (NP + 2) + (NP + 1) * NG; }
 
@@ -68,17 +71,17 @@ XT_HD void xt_grad_body(const XtKernelArgs& a, const XtGradArgs& ga, Ctx& cx)
     const double* DT = ga.tan_lds ? smem + tan0 : ga.dblob;  // [NP][TB]
     const int reg0 = tan0 + (ga.tan_lds ? ((NP * TB + 1) & ~1) : 0);
 
-    const int slot = tid / NG;
-    const int g = tid - slot * NG;
+    const int PJ = ga.PJ, NT = NG * PJ;  // threads per track
+    const int slot = tid / NT;
+    const int rr_ = tid - slot * NT;      // thread index inside the track
+    const int g = rr_ / PJ;
+    const int j = rr_ - g * PJ;
     const bool tvalid = slot < a.TPB;
     const int rdoubles = xt_grad_region_doubles(EP, D, K, NP);
     double* reg = smem + reg0 + (tvalid ? slot : 0) * rdoubles;
-    double* zm = reg;
-    double* mm = zm + EP;
-    double* uu = mm + D * EP;
-    int* ze = (int*)(uu + K * EP);
-    int* red_e = ze + ((EP + 1) & ~1);  // [0] final-reduce exponent, [1] NaN-input flag
-    double* tan = reg + xt_region_doubles(EP, D, K);  // [NP][(1 + D + K)][EP]: rz, dm[D], du[K]
+    const int pdoubles = xt_region_doubles(EP, D, K);
+    int* red_e = (int*)(reg + EP * (1 + D + K)) + ((EP + 1) & ~1);  // [0] final-reduce exponent, [1] NaN-input flag (in region 0)
+    double* tan = reg + 2 * pdoubles;  // [NP][(1 + D + K)][EP]: rz, dm[D], du[K]
     const int tstride = (1 + D + K) * EP;
     const int adoubles = xt_grad_acc_doubles(NP, NG);
     double* bacc = smem + reg0 + a.TPB * rdoubles + (tvalid ? slot : 0) * adoubles;  // [NP + 1] (+ pad)
@@ -96,8 +99,8 @@ XT_HD void xt_grad_body(const XtKernelArgs& a, const XtGradArgs& ga, Ctx& cx)
     const int SG = S * G;
 
     if (tvalid)
-        for (int i = g; i < NP + 1; i += NG) bacc[i] = 0.0;
-    if (tvalid && g == 0) red_e[1] = 0;
+        for (int i = rr_; i < NP + 1; i += NT) bacc[i] = 0.0;
+    if (tvalid && rr_ == 0) red_e[1] = 0;
     cx.sync();
 
     const int64_t nbatch = (b.N + a.TPB - 1) / a.TPB;
@@ -109,14 +112,14 @@ XT_HD void xt_grad_body(const XtKernelArgs& a, const XtGradArgs& ga, Ctx& cx)
 
         auto stage = [&](int p0) {
             if (act) {
-                for (int i = g; i < XT_STAGE * D; i += NG)
+                for (int i = rr_; i < XT_STAGE * D; i += NT)
                     if (p0 + i / D < L) {
                         const double v = c[p0 * D + i];
                         spos[i] = v;
                         if (v != v) red_e[1] = 1;
                     }
                 if (sg)
-                    for (int i = g; i < XT_STAGE * a.KS; i += NG)
+                    for (int i = rr_; i < XT_STAGE * a.KS; i += NT)
                         if (p0 + i / a.KS < L) {
                             const double v = sg[p0 * a.KS + i];
                             ssig[i] = v;
@@ -155,13 +158,22 @@ XT_HD void xt_grad_body(const XtKernelArgs& a, const XtGradArgs& ga, Ctx& cx)
                 for (int k = 0; k < K; ++k) dl2[k] = sc[k] * xt_fma(sraw[k], dtb[3], dtb[4]);
         };
 
+        // primal state: read from (zm, mm, uu, ze), the step writes (zmN, mmN, uuN, zeN); swapped after every step
+        double* zm = reg;
+        double* mm = zm + EP;
+        double* uu = mm + D * EP;
+        int* ze = (int*)(uu + K * EP);
+        double* zmN = reg + pdoubles;
+        double* mmN = zmN + EP;
+        double* uuN = mmN + D * EP;
+        int* zeN = (int*)(uuN + K * EP);
         stage(0);
         // ---- position 0
         if (act) {
             double l20[K], sc0[K], sr0[K], c0[D];
             load_l2(0, l20, sc0, sr0);
             for (int d = 0; d < D; ++d) c0[d] = spos[d];
-            for (int il = g; il < E; il += NG) {
+            for (int il = rr_; il < E; il += NT) {
                 const bool live = il < S;
                 const int i = xt_skew(il, a.skew);
                 zm[i] = live ? hdr[8 + il] : 0.0;
@@ -178,7 +190,7 @@ XT_HD void xt_grad_body(const XtKernelArgs& a, const XtGradArgs& ga, Ctx& cx)
                     for (int k = 0; k < K; ++k) tp[(1 + D + k) * EP + i] = dl2[k];
                 }
             }
-            if (g == 0) red_e[0] = XT_EMIN;
+            if (rr_ == 0) red_e[0] = XT_EMIN;
         }
         cx.sync();
 
@@ -245,8 +257,8 @@ XT_HD void xt_grad_body(const XtKernelArgs& a, const XtGradArgs& ga, Ctx& cx)
                 if (G_)
                     for (int q = 0; q < GM; ++q) light(q, rq[q], tq[q]);
 
-                // tangents, direction by direction (reads the OLD primal members, writes the new tangents in place)
-                for (int p = 0; p < NP; ++p) {
+                // tangents of this lane's directions (reads the OLD primal members, writes the new tangents in place)
+                for (int p = j; p < NP; p += PJ) {
                     const double* dtb = DT + p * TB;
                     double* tp = tan + p * tstride;
                     double R = 0.0, dmb[D], dub[K];
@@ -309,10 +321,10 @@ XT_HD void xt_grad_body(const XtKernelArgs& a, const XtGradArgs& ga, Ctx& cx)
                     }
                 }
 
-                // primal update (as xt_track_body)
+                // primal update (as xt_track_body), by lane j == 0 of the group
                 const double Wm = xt_frexp_mant(W);
                 const int We = W > 0.0 ? emax + xt_frexp_exp(W) : XT_EMIN;
-                for (int q = 0; q < G; ++q) {
+                for (int q = 0; q < (j == 0 ? G : 0); ++q) {
                     const int idx = xt_skew(base + off[q], a.skew);
                     double rl[K], tl[K];
                     const double* r = rl;
@@ -337,16 +349,22 @@ XT_HD void xt_grad_body(const XtKernelArgs& a, const XtGradArgs& ga, Ctx& cx)
                         gf = sqrt(gf);
                     }
                     double pp;
-                    int j, n;
-                    xt_exp_tab(-quad, pp, j, n);
+                    int jt, n;
+                    xt_exp_tab(-quad, pp, jt, n);
                     const int en = We + n;
-                    zm[idx] = (Wm * TTl[q]) * (gf * T64[j]) * pp;
-                    ze[idx] = en > XT_EMIN ? en : XT_EMIN;
-                    for (int d = 0; d < D; ++d) mm[d * EP + idx] = xt_fma(dm[d], tt[K == 1 ? 0 : d], mb[d]);
-                    for (int k = 0; k < K; ++k) uu[k * EP + idx] = l2t[k] * tt[k];
+                    zmN[idx] = (Wm * TTl[q]) * (gf * T64[jt]) * pp;
+                    zeN[idx] = en > XT_EMIN ? en : XT_EMIN;
+                    for (int d = 0; d < D; ++d) mmN[d * EP + idx] = xt_fma(dm[d], tt[K == 1 ? 0 : d], mb[d]);
+                    for (int k = 0; k < K; ++k) uuN[k * EP + idx] = l2t[k] * tt[k];
                 }
             }
             cx.sync();
+            {
+                double* t0 = zm; zm = zmN; zmN = t0;
+                t0 = mm; mm = mmN; mmN = t0;
+                t0 = uu; uu = uuN; uuN = t0;
+                int* t1 = ze; ze = zeN; zeN = t1;
+            }
         }
 
         // ---- last position (+ leaving/bleaching term).  Pass 1: extended-range total of every thread -> common exponent fe.
@@ -417,15 +435,15 @@ XT_HD void xt_grad_body(const XtKernelArgs& a, const XtGradArgs& ga, Ctx& cx)
                     tot.add(wm, we);
                 }
             }
-            if (tot.m != 0.0) cx.atomic_max_i32(&red_e[0], tot.e);
+            if (tot.m != 0.0 && j == 0) cx.atomic_max_i32(&red_e[0], tot.e);
         }
         cx.sync();
         if (act) {
             const int fe = red_e[0];
             const int base = a.base_tab[phl * NG + g];
             const int32_t* off = a.off_tab + phl * G;
-            gth[g] = tot.m != 0.0 ? xt_ldexp(tot.m, tot.e - fe) : 0.0;  // column 0: weight total of this thread
-            for (int p = 0; p < NP; ++p) {
+            if (j == 0) gth[g] = tot.m != 0.0 ? xt_ldexp(tot.m, tot.e - fe) : 0.0;  // column 0: weight total of this group
+            for (int p = j; p < NP; p += PJ) {
                 const double* dtb = DT + p * TB;
                 const double* tp = tan + p * tstride;
                 double dl2[K];
@@ -454,9 +472,9 @@ XT_HD void xt_grad_body(const XtKernelArgs& a, const XtGradArgs& ga, Ctx& cx)
             }
         }
         cx.sync();
-        // fixed-order sums over the track's NG threads, one column per thread (0: weight total, 1 + p: direction p)
+        // fixed-order sums over the track's NG groups, one column per thread (0: weight total, 1 + p: direction p)
         if (act)
-            for (int col = g; col < NP + 1; col += NG) {
+            for (int col = rr_; col < NP + 1; col += NT) {
                 double s2 = 0.0;
                 for (int i = 0; i < NG; ++i) s2 += gth[col * NG + i];
                 csum[col] = s2;
@@ -466,7 +484,7 @@ XT_HD void xt_grad_body(const XtKernelArgs& a, const XtGradArgs& ga, Ctx& cx)
             const bool poisoned = red_e[1] != 0;
             const double sw = csum[0];
             const int fe = red_e[0];
-            for (int col = g; col < NP + 1; col += NG) {
+            for (int col = rr_; col < NP + 1; col += NT) {
                 if (col == 0) {
                     const double ll = poisoned ? NAN : log(sw) + (double)fe * XT_LN2 + b.ll_const;
                     if (b.ll_out) b.ll_out[trk] = ll;
@@ -477,7 +495,7 @@ XT_HD void xt_grad_body(const XtKernelArgs& a, const XtGradArgs& ga, Ctx& cx)
             }
         }
         cx.sync();
-        if (act && g == 0) red_e[1] = 0;
+        if (act && rr_ == 0) red_e[1] = 0;
     }
 
     // ---- block partials: fixed-order sum over the block's track slots, one column per thread

@@ -658,7 +658,7 @@ static bool emul_grad_dispatch_dk(int D, int K, L& l)
 extern "C" int xt_emul_grad(const double* tracks, const double* sigma, long long N, int L, int D, int KS, int S, int NS, int F, int isBL,
                             int min_len, int locerr_mode, int locerr_dims, const double* locerr, double slope, double offset, double pBL,
                             const double* ds, const double* Fs, const double* TrMat, const double* p_stay, int n_dir, const double* tangents,
-                            int nblocks, int tpb, int tan_lds, int generic_g, double* ll_out, double* out /* [1 + n_dir] */)
+                            int nblocks, int tpb, int tan_lds, int generic_g, int PJ, double* ll_out, double* out /* [1 + n_dir] */)
 {
     XtConfig cfg;
     if (!xt_build_config(S, NS, F, cfg).empty()) return -1;
@@ -686,7 +686,7 @@ extern "C" int xt_emul_grad(const double* tracks, const double* sigma, long long
     EmulGradLauncher l;
     memset(&l.a, 0, sizeof(l.a));
     xt_fill_args_from_config(cfg, l.a);
-    const int threads = (tpb * cfg.NG + 63) / 64 * 64;
+    const int threads = (tpb * cfg.NG * PJ + 63) / 64 * 64;
     if (threads > 1024) return -2;
     std::vector<double> gp((size_t)nblocks * (n_dir + 1), 0.0);
     l.a.tracks = tracks;
@@ -709,6 +709,7 @@ extern "C" int xt_emul_grad(const double* tracks, const double* sigma, long long
     l.ga.NP = n_dir;
     l.ga.TB = TB;
     l.ga.tan_lds = tan_lds;
+    l.ga.PJ = PJ;
     l.threads = threads;
     l.nblocks = nblocks;
     size_t d = (size_t)((xt_tab_doubles(S, cfg.G) + 1) & ~1);

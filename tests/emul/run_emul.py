@@ -171,7 +171,8 @@ def run_th_multi(buckets, locerr, ds, Fs, T, pBL, p_stay, ns, F, min_len, max_le
     return outs, tot.value
 
 
-def run_grad(Cs, LE, ds, Fs, T, pBL, isBL, p_stay, ns, F, min_len, tangents, nblocks=2, tpb=2, tan_lds=1, generic_g=0, slope=None, offset=None):
+def run_grad(Cs, LE, ds, Fs, T, pBL, isBL, p_stay, ns, F, min_len, tangents, nblocks=2, tpb=2, tan_lds=1, generic_g=0, PJ=1, slope=None,
+             offset=None):
     """Likelihood + gradient body on CPU threads.  tangents: list of dicts (keys ds2, Fs, TrMat, p_stay, locerr, slope, offset, pBL).
     Returns (per-track LL, total LL, gradient[n_dir])."""
     Cs = np.ascontiguousarray(Cs, float)
@@ -203,7 +204,7 @@ def run_grad(Cs, LE, ds, Fs, T, pBL, isBL, p_stay, ns, F, min_len, tangents, nbl
     ds, Fs, T, p_stay = [np.ascontiguousarray(x, float) for x in (ds, Fs, T, p_stay)]
     rc = lib().xt_emul_grad(dp(Cs), dp(sigma), C.c_longlong(N), L, D, KS, S, ns, F, int(isBL), int(min_len), mode, K, dp(locerr),
                             C.c_double(slope or 0.0), C.c_double(offset or 0.0), C.c_double(pBL), dp(ds), dp(Fs), dp(T), dp(p_stay),
-                            len(tangents), dp(tan), nblocks, tpb, tan_lds, generic_g, dp(ll), dp(out))
+                            len(tangents), dp(tan), nblocks, tpb, tan_lds, generic_g, PJ, dp(ll), dp(out))
     if rc != 0:
         raise RuntimeError("emul grad rc=%d" % rc)
     return ll, out[0], out[1:]

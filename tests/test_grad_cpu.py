@@ -64,9 +64,9 @@ def oracle_fd_gradient(Cs, le, ds2, Fs, T, pBL, isBL, cell, ns, F, min_len, dirs
     return np.array([_richardson(lambda x: total(x, d), h) for _, _, d, h in dirs])
 
 
-@pytest.mark.parametrize("S,ns,F,L,N,D,K,isBL,kw", [(2, 1, 4, 9, 10, 2, 1, 1, {}), (2, 1, 6, 12, 8, 2, 1, 0, {}), (3, 1, 3, 8, 6, 2, 2, 1, {}),
-                                                     (2, 2, 3, 7, 6, 1, 1, 1, {}), (3, 1, 4, 9, 4, 3, 3, 1, dict(tan_lds=0)),
-                                                     (2, 1, 4, 9, 10, 2, 1, 1, dict(generic_g=1))])
+@pytest.mark.parametrize("S,ns,F,L,N,D,K,isBL,kw", [(2, 1, 4, 9, 10, 2, 1, 1, {}), (2, 1, 6, 12, 8, 2, 1, 0, dict(PJ=4)), (3, 1, 3, 8, 6, 2, 2, 1, dict(PJ=8)),
+                                                     (2, 2, 3, 7, 6, 1, 1, 1, dict(PJ=2)), (3, 1, 4, 9, 4, 3, 3, 1, dict(tan_lds=0, PJ=4)),
+                                                     (2, 1, 4, 9, 10, 2, 1, 1, dict(generic_g=1, PJ=2))])
 def test_emulated_gradient_body_vs_oracle_differences(S, ns, F, L, N, D, K, isBL, kw):
     import run_emul as E
     from extrack_amd import synth
