@@ -16,7 +16,7 @@ EXPORTS = [
     "extrack_upload_bucket", "extrack_attach_bucket", "extrack_clear_buckets", "extrack_bucket_count",
     "extrack_loglik", "extrack_loglik_async", "extrack_predict", "extrack_last_kernel_ms",
     "extrack_last_launch_info", "extrack_p_stay_table", "extrack_loglik_th", "extrack_loglik_th_async", "extrack_th_plan_step",
-    "extrack_predict_th", "extrack_loglik_grad", "extrack_last_grad_ms",
+    "extrack_predict_th", "extrack_loglik_grad", "extrack_last_grad_ms", "extrack_segment_len_hist",
 ]
 
 _dp = C.POINTER(C.c_double)
@@ -102,6 +102,7 @@ def load():
     lib.extrack_predict_th.argtypes = [vp, C.POINTER(ExtrackModel), i32, C.c_double, i32, i32, vp]
     lib.extrack_th_plan_step.argtypes = [vp, i32, i64, i32, C.POINTER(i32), C.POINTER(i32), vp, vp, i32]
     lib.extrack_loglik_grad.argtypes = [vp, C.POINTER(ExtrackModel), i32, C.POINTER(ExtrackModelTangent), _dp, vp]
+    lib.extrack_segment_len_hist.argtypes = [vp, C.POINTER(ExtrackModel), i32, i32, vp]
     lib.extrack_last_grad_ms.argtypes = [vp, C.POINTER(C.c_float)]
     if lib.extrack_abi_version() != 3:
         raise ImportError("libextrack_hip.so ABI version mismatch")
@@ -240,6 +241,13 @@ class Context:
         g = np.zeros(max(n, 1))
         self._check(self._lib.extrack_loglik_grad(self._h, C.byref(model.c), n, arr, C.byref(tot), g.ctypes.data_as(C.c_void_p)))
         return tot.value, g[:n]
+
+    def segment_len_hist(self, model, bucket_id, max_nb_states=500):
+        """State-duration histogram [len - 1, S] of one bucket (extrack/histograms.py:26-286 semantics, see include/extrack_hip.h)."""
+        N, L, D, KS = self.buckets[bucket_id]
+        out = np.zeros((L - 1, model.c.n_states))
+        self._check(self._lib.extrack_segment_len_hist(self._h, C.byref(model.c), int(bucket_id), int(max_nb_states), out.ctypes.data_as(C.c_void_p)))
+        return out
 
     def last_grad_ms(self):
         ms = C.c_float(0)

@@ -26,6 +26,9 @@
  *       the merge groups fuse_tracks_th decided for one chunk and step (tracking.py:681-701) - diagnostic.
  *   extrack_p_stay_table
  *       the field-of-view survival table, extrack/tracking.py:182-191.
+ *   extrack_segment_len_hist
+ *       P_segment_len(...)[2] (extrack/histograms.py:26-286) summed over one bucket: the state-duration histogram that len_hist
+ *       (histograms.py:294-373) accumulates over chunks of 50 tracks.
  *   extrack_loglik_grad
  *       extrack_loglik AND its exact gradient in one pass.  It replaces the finite-difference loop that the reference's
  *       optimiser runs around cum_Proba_Cs (lmfit.minimize at extrack/tracking.py:1371: BFGS evaluates the objective
@@ -135,6 +138,15 @@ int extrack_loglik_grad(extrack_ctx* ctx, const extrack_model* model, int32_t n_
                         double* total_ll, double* grad);
 /* Device time (ms) of the gradient kernels of the last extrack_loglik_grad call. */
 int extrack_last_grad_ms(extrack_ctx* ctx, float* ms);
+
+/* State-duration histogram of one bucket (extrack/histograms.py:26-286 P_segment_len, third return value, summed over the bucket's
+ * tracks): hist host [(len - 1)][S], hist[k - 1][s] = expected number of segments of exactly k consecutive positions in state s
+ * (segments as long as the whole track are not counted, histograms.py:279).  Every state sequence is followed with its full
+ * history; after each position at most max_nb_states sequences survive, ranked by their probability including the next position's
+ * predictive density (histograms.py:185-203; len_hist's default is 500).  model->nb_substeps must be 1; model->min_len is the
+ * reference's min_l (smallest track length of the dataset), isBL = (len != model->max_len) as elsewhere.
+ * Limits: len * bits_per_state <= 256 (bits = 1 / 2 / 3 for <= 2 / 4 / 8 states), max_nb_states * n_states <= 16384. */
+int extrack_segment_len_hist(extrack_ctx* ctx, const extrack_model* model, int32_t bucket_id, int32_t max_nb_states, double* hist);
 
 /* Threshold-fusion log-likelihood (the kernel extrack.tracking.param_fitting / cum_Proba_Cs call in v1.6.3,
  * extrack/tracking.py:427-743).  Which state sequences are merged at a step is decided from the first 30 tracks

@@ -80,3 +80,20 @@ def make_params(**vals):
     for k, v in vals.items():
         p.add(k, value=v)
     return p
+
+
+def load_with_package(name):
+    """Modules of the reference that import their siblings through the package (``from extrack.tracking import ...``:
+    extrack/histograms.py:24, extrack/refined_localization.py:27-29): a stand-in ``extrack`` package whose submodules are the
+    path-loaded reference modules is put in ``sys.modules`` first (``import extrack`` itself fails on ``xmltodict``)."""
+    install_shims()
+    if "extrack" not in sys.modules or not getattr(sys.modules["extrack"], "_ref_stub", False):
+        pkg = types.ModuleType("extrack")
+        pkg._ref_stub = True
+        pkg.__path__ = []
+        sys.modules["extrack"] = pkg
+        for sub in ("tracking", "tracking_0"):
+            m = load(sub)
+            sys.modules["extrack." + sub] = m
+            setattr(pkg, sub, m)
+    return load(name)

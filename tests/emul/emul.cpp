@@ -14,6 +14,8 @@
 #include "../../extrack_amd/csrc/xt_fast2.h"
 #include "../../extrack_amd/csrc/xt_grad.h"
 #include "../../extrack_amd/csrc/xt_grad_host.h"
+#include "../../extrack_amd/csrc/xt_hist.h"
+#include "../../extrack_amd/csrc/xt_hist_host.h"
 #include "../../extrack_amd/csrc/xt_tables.h"
 #include "../../extrack_amd/csrc/xt_th.h"
 
@@ -726,6 +728,77 @@ extern "C" int xt_emul_grad(const double* tracks, const double* sigma, long long
         double s2 = 0.0;
         for (int b = 0; b < nblocks; ++b) s2 += gp[(size_t)b * (n_dir + 1) + c];
         out[c] = s2;
+    }
+    return 0;
+}
+
+
+// ---- state-duration histogram body (xt_hist.h): one bucket ---------------------------------------------------------------------
+template <int D, int K>
+static void emul_hist_run(const XtHistArgs& a, int nblocks, int threads, size_t lds_doubles)
+{
+    for (int b = 0; b < nblocks; ++b) {
+        std::vector<double> smem(lds_doubles + 16, 0.0);
+        pthread_barrier_t bar;
+        pthread_barrier_init(&bar, nullptr, threads);
+        std::vector<std::thread> th;
+        for (int t = 0; t < threads; ++t)
+            th.emplace_back([&, t]() {
+                HostCtx cx{t, threads, b, nblocks, smem.data(), &bar};
+                xt_hist_body<D, K>(a, cx);
+            });
+        for (auto& x : th) x.join();
+        pthread_barrier_destroy(&bar);
+    }
+}
+
+extern "C" int xt_emul_hist(const double* tracks, const double* sigma, long long N, int L, int D, int KS, int S, int isBL, int min_l,
+                            int locerr_mode, int locerr_dims, const double* locerr, double slope, double offset, double pBL, const double* ds,
+                            const double* Fs, const double* TrMat, const double* p_stay, int max_nb_states, int nblocks, int threads, int par_lds,
+                            double* hist /* [(L-1)][S] */)
+{
+    XtModelHost m{S, 1, locerr_dims, {0, 0, 0}, slope, offset, pBL, ds, Fs, TrMat, p_stay};
+    for (int k = 0; k < 3; ++k) m.locerr[k] = locerr ? locerr[k < locerr_dims ? k : 0] : 0.0;
+    std::vector<double> blob;
+    xt_hist_build_blob(m, blob);
+    const int K = locerr_mode == 0 ? locerr_dims : KS;
+    XtHistArgs a;
+    memset(&a, 0, sizeof(a));
+    a.bits = S <= 2 ? 1 : (S <= 4 ? 2 : 3);
+    a.HW = (L * a.bits + 63) / 64;
+    if (a.HW > XT_HIST_MAXW) return -2;
+    a.K = max_nb_states;
+    a.PC = max_nb_states > S * S ? max_nb_states : S * S;
+    a.NC = 1;
+    while (a.NC < a.PC * S) a.NC <<= 1;
+    a.tracks = tracks;
+    a.sigma = locerr_mode ? sigma : nullptr;
+    a.blob = blob.data();
+    a.N = N;
+    a.L = L;
+    a.S = S;
+    a.KS = KS;
+    a.locerr_mode = locerr_mode;
+    a.isBL = isBL;
+    a.min_l = min_l;
+    a.par_lds = par_lds;
+    const int nbins = (L - 1) * S;
+    std::vector<double> partials((size_t)nblocks * nbins, 0.0);
+    a.partials = partials.data();
+    a.ws_stride = 2 * (int64_t)xt_hist_parent_doubles(a.PC, D, K, a.HW);
+    std::vector<double> ws(par_lds ? 1 : (size_t)a.ws_stride * nblocks, 0.0);
+    a.ws = ws.data();
+    const size_t ldsd = xt_hist_lds_doubles(S, L, D, K, locerr_mode ? KS : 0, a.PC, a.NC, a.HW, threads, par_lds != 0);
+    if (D == 1 && K == 1) emul_hist_run<1, 1>(a, nblocks, threads, ldsd);
+    else if (D == 2 && K == 1) emul_hist_run<2, 1>(a, nblocks, threads, ldsd);
+    else if (D == 2 && K == 2) emul_hist_run<2, 2>(a, nblocks, threads, ldsd);
+    else if (D == 3 && K == 1) emul_hist_run<3, 1>(a, nblocks, threads, ldsd);
+    else if (D == 3 && K == 3) emul_hist_run<3, 3>(a, nblocks, threads, ldsd);
+    else return -3;
+    for (int i = 0; i < nbins; ++i) {
+        double s2 = 0.0;
+        for (int b = 0; b < nblocks; ++b) s2 += partials[(size_t)b * nbins + i];
+        hist[i] = s2;
     }
     return 0;
 }

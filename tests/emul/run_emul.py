@@ -14,7 +14,7 @@ def lib():
         so = os.path.join(HERE, "libxt_emul.so")
         src = os.path.join(HERE, "emul.cpp")
         hdrs = [os.path.join(HERE, "..", "..", "extrack_amd", "csrc", h) for h in ("xt_kernel.h", "xt_math.h", "xt_tables.h", "xt_dispatch.h", "xt_th.h", "xt_entry.h", "xt_fast2.h", "xt_grad.h",
-                                                                                             "xt_grad_host.h")]
+                                                                                             "xt_grad_host.h", "xt_hist.h", "xt_hist_host.h")]
         if not os.path.exists(so) or any(os.path.getmtime(f) > os.path.getmtime(so) for f in [src] + hdrs):
             import subprocess
             subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-pthread", "-o", so, src])
@@ -208,3 +208,27 @@ def run_grad(Cs, LE, ds, Fs, T, pBL, isBL, p_stay, ns, F, min_len, tangents, nbl
     if rc != 0:
         raise RuntimeError("emul grad rc=%d" % rc)
     return ll, out[0], out[1:]
+
+
+def run_hist(Cs, LE, ds, Fs, T, pBL, isBL, p_stay, min_l, max_nb_states, nblocks=2, threads=64, par_lds=1, slope=None, offset=None):
+    """State-duration histogram body on CPU threads: returns hist[L - 1, S] summed over the tracks."""
+    Cs = np.ascontiguousarray(Cs, float)
+    N, L, D = Cs.shape
+    S = len(ds)
+    LE = np.ascontiguousarray(LE, float)
+    if LE.shape[1] == 1 and L != 1:
+        mode, K, KS = 0, LE.shape[2], 1
+        locerr = np.zeros(3)
+        locerr[:K] = LE[0, 0]
+        sigma = None
+    else:
+        mode, KS = (2 if slope is not None else 1), LE.shape[2]
+        K, locerr, sigma = KS, np.zeros(3), np.ascontiguousarray(np.broadcast_to(LE, (N, L, LE.shape[2])))
+    out = np.zeros((L - 1, S))
+    ds, Fs, T, p_stay = [np.ascontiguousarray(x, float) for x in (ds, Fs, T, p_stay)]
+    rc = lib().xt_emul_hist(dp(Cs), dp(sigma), C.c_longlong(N), L, D, KS, S, int(isBL), int(min_l), mode, K, dp(locerr), C.c_double(slope or 0.0),
+                            C.c_double(offset or 0.0), C.c_double(pBL), dp(ds), dp(Fs), dp(T), dp(p_stay), int(max_nb_states), nblocks, threads,
+                            par_lds, dp(out))
+    if rc != 0:
+        raise RuntimeError("emul hist rc=%d" % rc)
+    return out

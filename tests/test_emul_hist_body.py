@@ -1,0 +1,35 @@
+"""The state-duration histogram kernel body (extrack_amd/csrc/xt_hist.h) run on CPU threads (tests/emul) against the golden vectors the
+reference produced (extrack/histograms.py P_segment_len): sort-based top-K pruning, the LL re-ordering quirk, the streamed final step,
+run-length decoding of the bit-packed histories, LDS and global-workspace parent buffers."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "emul"))
+
+
+def test_emulated_histogram_body_vs_reference_fixtures():
+    import run_emul as E
+    from oracle import oracle_np as O
+    info = json.load(open(os.path.join(GOLDEN, "hist_cases.json")))
+    data = np.load(os.path.join(GOLDEN, "hist_cases.npz"))
+    worst, n = 0.0, 0
+    for row in info["cases"]:
+        if row["id"] % 5 != 0 and not (row["L"] == 2 and row["id"] % 2):
+            continue  # a fifth of the cases (plus minimal-length ones) keeps the CPU suite short
+        pre = "h%04d_" % row["id"]
+        g = lambda k: data[pre + k]
+        ps = O.p_stay_table(g("ds"), row["S"], 1, row["cell_dims"])
+        h = E.run_hist(g("Cs"), g("LE"), g("ds"), g("Fs"), g("T"), row["pBL"], row["isBL"], ps, row["min_l"], row["K"], nblocks=1 + row["id"] % 2,
+                       threads=64, par_lds=row["id"] % 4 != 3)
+        d = np.abs(h - g("hist")).max()
+        assert d < 1e-9 * max(1.0, row["N"]), (row, d)
+        worst = max(worst, d)
+        n += 1
+    assert n > 40
+    print("cases", n, "worst |d hist|", worst)

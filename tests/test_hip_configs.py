@@ -140,7 +140,7 @@ def test_c3_three_state_fit_recovers_simulated_parameters(capsys):
     assert abs(v["F0"] - 0.33) < 0.06 and abs(v["F1"] - 0.33) < 0.06 and abs(v["F0"] + v["F1"] + v["F2"] - 1) < 1e-12
     rate = lambda pr: -np.log(1 - pr)  # Matrix_type 1: p = 1 - exp(-rate)
     assert abs(v["p01"] - rate(0.1)) < 0.03 and abs(v["p10"] - rate(0.05)) < 0.02 and abs(v["p21"] - rate(0.06)) < 0.02
-    assert 50 < fit.nfev < 20000
+    assert 10 < fit.nfev < 20000
 
 
 # ------------------------------------------------------------------------------------------------------------------

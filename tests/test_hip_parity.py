@@ -146,7 +146,7 @@ def test_c1_param_fitting_recovers_simulated_parameters(capsys):
     assert abs(v["LocErr"] - 0.02) < 0.002
     assert abs(v["F0"] - 0.6) < 0.05 and abs(v["F1"] - (1 - v["F0"])) < 1e-12
     assert abs(v["p01"] - 0.1) < 0.03 and abs(v["p10"] - 0.1) < 0.03
-    assert 50 < fit.nfev < 5000
+    assert 10 < fit.nfev < 5000  # ~30 evaluations with the analytic gradient (default), ~280 when differenced numerically
 
 
 @pytest.mark.parametrize("S,ns,F,L,N", [(2, 1, 6, 30, 5000), (3, 1, 6, 17, 600), (4, 1, 5, 20, 200), (4, 3, 4, 12, 24), (2, 2, 6, 40, 500),
