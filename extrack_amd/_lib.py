@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("EXTRACK_HIP_LIB", os.path.join(_HERE, "libextrack_hip
 
 EXPORTS = [
     "extrack_abi_version", "extrack_create", "extrack_destroy", "extrack_last_error", "extrack_set_stream",
-    "extrack_upload_bucket", "extrack_attach_bucket", "extrack_clear_buckets", "extrack_bucket_count",
+    "extrack_upload_bucket", "extrack_attach_bucket", "extrack_set_bucket_dt", "extrack_clear_buckets", "extrack_bucket_count",
     "extrack_loglik", "extrack_loglik_async", "extrack_predict", "extrack_last_kernel_ms",
     "extrack_last_launch_info", "extrack_p_stay_table", "extrack_loglik_th", "extrack_loglik_th_async", "extrack_th_plan_step",
     "extrack_predict_th", "extrack_loglik_grad", "extrack_last_grad_ms", "extrack_segment_len_hist",
@@ -26,7 +26,7 @@ class ExtrackModel(C.Structure):
     """Mirror of ``struct extrack_model`` (include/extrack_hip.h)."""
     _fields_ = [
         ("n_states", C.c_int32), ("nb_substeps", C.c_int32), ("frame_len", C.c_int32), ("min_len", C.c_int32),
-        ("max_len", C.c_int32), ("locerr_mode", C.c_int32), ("locerr_dims", C.c_int32), ("reserved", C.c_int32),
+        ("max_len", C.c_int32), ("locerr_mode", C.c_int32), ("locerr_dims", C.c_int32), ("n_p_stay", C.c_int32),
         ("locerr", C.c_double * 3), ("slope", C.c_double), ("offset", C.c_double), ("pBL", C.c_double),
         ("ds", _dp), ("Fs", _dp), ("TrMat", _dp), ("p_stay", _dp),
     ]
@@ -89,6 +89,7 @@ def load():
     lib.extrack_set_stream.argtypes = [vp, vp]
     lib.extrack_upload_bucket.argtypes = [vp, vp, i64, i32, i32, vp, i32, C.POINTER(i32)]
     lib.extrack_attach_bucket.argtypes = [vp, vp, i64, i32, i32, vp, i32, C.POINTER(i32)]
+    lib.extrack_set_bucket_dt.argtypes = [vp, i32, vp]
     lib.extrack_clear_buckets.argtypes = [vp]
     lib.extrack_bucket_count.argtypes = [vp]
     lib.extrack_loglik.argtypes = [vp, C.POINTER(ExtrackModel), _dp, vp]
@@ -121,9 +122,12 @@ class ModelHandle:
                  slope=0.0, offset=0.0):
         self.ds, self.Fs, self.TrMat, self.p_stay = _f64(ds), _f64(Fs), _f64(TrMat), _f64(p_stay)
         S = len(self.ds)
-        if self.TrMat.shape != (S, S) or self.Fs.shape != (S,) or self.p_stay.shape != (S ** int(nb_substeps),):
+        G = S ** int(nb_substeps)
+        ok_ps = self.p_stay.shape == (G,) or (self.p_stay.ndim == 2 and self.p_stay.shape[1] == G)
+        if self.TrMat.shape != (S, S) or self.Fs.shape != (S,) or not ok_ps:
             raise ValueError("inconsistent model array shapes")
         m = ExtrackModel()
+        m.n_p_stay = 1 if self.p_stay.ndim == 1 else int(self.p_stay.shape[0])  # one table, or one per chunk (per-track time steps)
         m.n_states, m.nb_substeps, m.frame_len = S, int(nb_substeps), int(frame_len)
         m.min_len, m.max_len = int(min_len), int(max_len)
         m.locerr_mode = int(locerr_mode)
@@ -194,6 +198,15 @@ class Context:
         self._check(self._lib.extrack_upload_bucket(self._h, tracks.ctypes.data_as(C.c_void_p), N, L, D, sp, KS, C.byref(bid)))
         self.buckets.append((N, L, D, KS))
         return bid.value
+
+    def set_bucket_dt(self, bucket_id, dt):
+        """Per-track time steps [n_tracks, len] of an uploaded bucket (None removes them); see include/extrack_hip.h."""
+        if dt is not None:
+            dt = _f64(dt)
+            N, L, D, KS = self.buckets[bucket_id]
+            if dt.shape != (N, L):
+                raise ValueError("dt must be an array [n_tracks, len] matching the bucket")
+        self._check(self._lib.extrack_set_bucket_dt(self._h, int(bucket_id), dt.ctypes.data_as(C.c_void_p) if dt is not None else None))
 
     def attach_bucket(self, tracks_t, sigma_t=None):
         """tracks_t / sigma_t: contiguous float64 torch CUDA tensors on this device (zero copy)."""

@@ -34,11 +34,11 @@ __global__ void __launch_bounds__(1024) xt_th_plan_kernel(XtThArgs a)
     xt_th_plan_body<D, K, PREDS>(a, cx);
 }
 
-template <int D, int K, bool UNI, bool SINGLE>
+template <int D, int K, bool UNI, bool SINGLE, bool DT>
 __global__ void __launch_bounds__(1024) xt_th_apply_kernel(XtThArgs a)
 {
     DevCtx cx;
-    xt_th_apply_body<D, K, UNI, SINGLE>(a, cx);
+    xt_th_apply_body<D, K, UNI, SINGLE, DT>(a, cx);
 }
 
 // Fixed-order reduction of the per-block partial sums (deterministic for a given launch geometry).
@@ -147,6 +147,7 @@ static void xt_free_bucket(XtBucket& b)
         if (b.d_sigma) (void)hipFree((void*)b.d_sigma);
     }
     if (b.d_ll) (void)hipFree(b.d_ll);
+    if (b.d_dt) (void)hipFree(b.d_dt);
     if (b.th_members) (void)hipFree(b.th_members);
     if (b.th_mpack) (void)hipFree(b.th_mpack);
     if (b.th_gnew) (void)hipFree(b.th_gnew);
@@ -184,6 +185,7 @@ extern "C" void extrack_destroy(extrack_ctx* ctx)
     }
     if (ctx->d_preds) (void)hipFree(ctx->d_preds);
     if (ctx->d_dblob) (void)hipFree(ctx->d_dblob);
+    if (ctx->d_th_blobs) (void)hipFree(ctx->d_th_blobs);
     if (ctx->d_gpartials) (void)hipFree(ctx->d_gpartials);
     if (ctx->d_partials) (void)hipFree(ctx->d_partials);
     if (ctx->d_total) (void)hipFree(ctx->d_total);
@@ -269,6 +271,22 @@ extern "C" int extrack_attach_bucket(extrack_ctx* ctx, const double* d_tracks, i
     return EXTRACK_OK;
 }
 
+extern "C" int extrack_set_bucket_dt(extrack_ctx* ctx, int32_t bucket_id, const double* dt)
+{
+    if (!ctx) return EXTRACK_E_INVALID;
+    if (bucket_id < 0 || bucket_id >= (int)ctx->buckets.size()) return xt_fail(ctx, EXTRACK_E_INVALID, "bucket id out of range");
+    XT_HIP(ctx, hipSetDevice(ctx->device));
+    XtBucket& b = ctx->buckets[bucket_id];
+    XT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (b.d_dt) (void)hipFree(b.d_dt);
+    b.d_dt = nullptr;
+    if (!dt) return EXTRACK_OK;
+    const size_t nb = (size_t)b.N * b.L * sizeof(double);
+    XT_HIP(ctx, hipMalloc(&b.d_dt, nb));
+    XT_HIP(ctx, hipMemcpy(b.d_dt, dt, nb, hipMemcpyHostToDevice));
+    return EXTRACK_OK;
+}
+
 int xt_validate_model(extrack_ctx* ctx, const extrack_model* m)
 {
     if (!m || !m->ds || !m->Fs || !m->TrMat || !m->p_stay) return xt_fail(ctx, EXTRACK_E_INVALID, "null model field");
@@ -332,8 +350,6 @@ static int xt_reserve_preds(extrack_ctx* ctx, size_t bytes)
     if (bytes <= ctx->preds_cap) return EXTRACK_OK;
     XT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->d_preds) (void)hipFree(ctx->d_preds);
-    if (ctx->d_dblob) (void)hipFree(ctx->d_dblob);
-    if (ctx->d_gpartials) (void)hipFree(ctx->d_gpartials);
     ctx->d_preds = nullptr;
     ctx->preds_cap = 0;
     XT_HIP(ctx, hipMalloc(&ctx->d_preds, bytes));
@@ -656,13 +672,20 @@ static hipError_t xt_th_launch_plan(extrack_ctx* ctx, const XtThArgs& a, int gri
     return hipGetLastError();
 }
 
+template <int D, int K, bool UNI, bool SINGLE, bool DT>
+static hipError_t xt_th_launch_apply_vd(extrack_ctx* ctx, const XtThArgs& a, int grid, int threads, size_t lds, hipStream_t stream)
+{
+    hipError_t e = xt_th_set_lds(ctx, xt_th_apply_kernel<D, K, UNI, SINGLE, DT>, lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((xt_th_apply_kernel<D, K, UNI, SINGLE, DT>), dim3(grid), dim3(threads), lds, stream, a);
+    return hipGetLastError();
+}
+
 template <int D, int K, bool UNI, bool SINGLE>
 static hipError_t xt_th_launch_apply_v(extrack_ctx* ctx, const XtThArgs& a, int grid, int threads, size_t lds, hipStream_t stream)
 {
-    hipError_t e = xt_th_set_lds(ctx, xt_th_apply_kernel<D, K, UNI, SINGLE>, lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((xt_th_apply_kernel<D, K, UNI, SINGLE>), dim3(grid), dim3(threads), lds, stream, a);
-    return hipGetLastError();
+    if (a.blob_stride != 0) return xt_th_launch_apply_vd<D, K, UNI, SINGLE, true>(ctx, a, grid, threads, lds, stream);  // per-track time steps
+    return xt_th_launch_apply_vd<D, K, UNI, SINGLE, false>(ctx, a, grid, threads, lds, stream);
 }
 
 // mode 0: general (fewer than 64 tracks per tile), 1: wave-uniform, two state buffers, 2: wave-uniform, one state buffer,
@@ -735,11 +758,51 @@ static int xt_th_upload_small(extrack_ctx* ctx, void** d_buf, size_t* cap, const
     return EXTRACK_OK;
 }
 
+// Per-track time steps (XtBucket::d_dt): the field-of-view table - hence the stay / end-of-track tables - belongs to the chunk
+// (tracking.py:507-511: median over the chunk's tracks of the first column of ds).  model->p_stay then holds one table of G entries
+// per chunk; `tables[c]` is the table index of the c-th chunk of this launch.  Builds and uploads one blob per chunk.
+static int xt_th_chunk_blobs(extrack_ctx* ctx, const extrack_model* m, const std::vector<int64_t>& tables, int G, int64_t* stride_out)
+{
+    XtModelHost mh;
+    xt_model_host(m, mh);
+    std::vector<double> all, one;
+    int64_t stride = 0;
+    for (size_t c = 0; c < tables.size(); ++c) {
+        mh.p_stay = m->p_stay + (size_t)tables[c] * G;
+        int G2 = 0;
+        xt_th_build_blob(mh, one, G2);
+        if (c == 0) {
+            stride = (int64_t)one.size();
+            all.assign((size_t)stride * tables.size(), 0.0);
+        }
+        memcpy(all.data() + c * (size_t)stride, one.data(), one.size() * sizeof(double));
+    }
+    if (all.size() > ctx->th_blobs_cap) {
+        XT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->d_th_blobs) (void)hipFree(ctx->d_th_blobs);
+        ctx->d_th_blobs = nullptr;
+        ctx->th_blobs_cap = 0;
+        XT_HIP(ctx, hipMalloc(&ctx->d_th_blobs, all.size() * sizeof(double)));
+        ctx->th_blobs_cap = all.size();
+    }
+    {
+        hipError_t e = hipMemcpy(ctx->d_th_blobs, all.data(), all.size() * sizeof(double), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            char msg[256];
+            snprintf(msg, sizeof(msg), "chunk blobs upload (%zu tables, stride %lld, capacity %zu doubles, dst %p): %s", tables.size(), (long long)stride,
+                     ctx->th_blobs_cap, (void*)ctx->d_th_blobs, hipGetErrorString(e));
+            return xt_fail(ctx, EXTRACK_E_HIP, msg);
+        }
+    }
+    *stride_out = stride;
+    return EXTRACK_OK;
+}
+
 // One launch group of a threshold-fusion evaluation: all buckets that share (dims, sigma dims) are served by ONE plan launch
 // and ONE apply launch through a device table of bucket descriptors (a real dataset has one bucket per track length; the plan
 // kernel of a single small bucket could not fill the GPU and its latency would add up bucket after bucket).
 static int xt_th_run_group(extrack_ctx* ctx, const extrack_model* m, const std::vector<XtBucket*>& bks, double threshold, int32_t max_nb_states,
-                           int32_t chunk, int G, bool per_track, size_t& poff)
+                           int32_t chunk, int G, bool per_track, size_t& poff, const std::vector<int64_t>* chunk_base)
 {
     const int S = m->n_states, NS = m->nb_substeps, F = m->frame_len;
     const XtBucket& b0 = *bks[0];
@@ -782,6 +845,18 @@ static int xt_th_run_group(extrack_ctx* ctx, const extrack_model* m, const std::
     a.nchunks = (int32_t)total;
     a.Lmax = Lmax;
     a.L = Lmax;
+    if (chunk_base) {  // per-track time steps: one blob per chunk, in this launch's chunk order
+        std::vector<int64_t> tables;
+        for (int i = 0; i < nbk; ++i) {
+            const int64_t base = (*chunk_base)[bks[i] - &ctx->buckets[0]];
+            for (int64_t c = 0; c < (bks[i]->N + chunk - 1) / chunk; ++c) tables.push_back(base + c);
+        }
+        int64_t stride = 0;
+        int rcb = xt_th_chunk_blobs(ctx, m, tables, G, &stride);
+        if (rcb) return rcb;
+        a.blob = ctx->d_th_blobs;
+        a.blob_stride = stride;
+    }
     // status of every chunk of the group: one device array, one pinned host copy
     if ((size_t)total * 4 > ctx->th_status_cap) {
         XT_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -808,6 +883,7 @@ static int xt_th_run_group(extrack_ctx* ctx, const extrack_model* m, const std::
             XtThBucket& k = desc[i];
             k.tracks = b.d_tracks;
             k.sigma = m->locerr_mode ? b.d_sigma : nullptr;
+            k.dt = chunk_base ? b.d_dt : nullptr;
             k.ll_out = per_track ? b.d_ll : nullptr;
             k.preds_out = nullptr;
             k.N = b.N;
@@ -1008,6 +1084,23 @@ static int xt_loglik_th_enqueue(extrack_ctx* ctx, const extrack_model* m, double
     if (!err.empty()) return xt_fail(ctx, EXTRACK_E_INVALID, err);
     if ((rc = xt_upload_blob(ctx, blob))) return rc;
     if (m->n_states * G > XT_TH_MAXCAP) return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "n_states^(nb_substeps+1) exceeds the plan capacity");
+    // per-track time steps: every bucket carries a dt array and the model one p_stay table per chunk (buckets in id order)
+    bool dt_mode = false;
+    std::vector<int64_t> chunk_base(ctx->buckets.size(), 0);
+    {
+        size_t ndt = 0;
+        int64_t acc = 0;
+        for (size_t i = 0; i < ctx->buckets.size(); ++i) {
+            ndt += ctx->buckets[i].d_dt ? 1 : 0;
+            chunk_base[i] = acc;
+            acc += (ctx->buckets[i].N + chunk - 1) / chunk;
+        }
+        dt_mode = ndt > 0;
+        if (dt_mode && ndt != ctx->buckets.size()) return xt_fail(ctx, EXTRACK_E_INVALID, "per-track time steps were set for some buckets only");
+        if (dt_mode && (int64_t)m->n_p_stay != acc)
+            return xt_fail(ctx, EXTRACK_E_INVALID, "per-track time steps: model->n_p_stay must be the number of chunks (one p_stay table per chunk)");
+        if (!dt_mode && m->n_p_stay > 1) return xt_fail(ctx, EXTRACK_E_INVALID, "several p_stay tables but no per-track time steps");
+    }
     if (per_track)
         for (auto& b : ctx->buckets)
             if (!b.d_ll) XT_HIP(ctx, hipMalloc(&b.d_ll, (size_t)b.N * sizeof(double)));
@@ -1024,7 +1117,7 @@ static int xt_loglik_th_enqueue(extrack_ctx* ctx, const extrack_model* m, double
         size_t jn = i;
         std::vector<XtBucket*> grp;
         while (jn < order.size() && order[jn]->D == order[i]->D && order[jn]->KS == order[i]->KS) grp.push_back(order[jn++]);
-        if ((rc = xt_th_run_group(ctx, m, grp, threshold, max_nb_states, chunk, G, per_track, poff))) return rc;
+        if ((rc = xt_th_run_group(ctx, m, grp, threshold, max_nb_states, chunk, G, per_track, poff, dt_mode ? &chunk_base : nullptr))) return rc;
         i = jn;
     }
     XT_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
@@ -1078,8 +1171,6 @@ extern "C" int extrack_predict_th(extrack_ctx* ctx, const extrack_model* m, int3
     if (bucket_id < 0 || bucket_id >= (int)ctx->buckets.size()) return xt_fail(ctx, EXTRACK_E_INVALID, "bucket id out of range");
     if (m->nb_substeps != 1) return xt_fail(ctx, EXTRACK_E_INVALID, "state predictions require nb_substeps == 1");
     if (nb_max < 1) return xt_fail(ctx, EXTRACK_E_INVALID, "nb_max must be >= 1");
-    if (nb_max > XT_TH_PILOT)
-        return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "nb_max > 30 (chunks larger than the pilot set) is not built for the threshold-fusion posteriors");
     if (!(threshold >= 0.0)) return xt_fail(ctx, EXTRACK_E_INVALID, "threshold must be >= 0");
     if (m->frame_len <= 1 || m->frame_len > 15) return xt_fail(ctx, EXTRACK_E_INVALID, "frame_len must be in (1, 15]");
     XT_HIP(ctx, hipSetDevice(ctx->device));
@@ -1108,6 +1199,25 @@ extern "C" int extrack_predict_th(extrack_ctx* ctx, const extrack_model* m, int3
     a.tracks = b.d_tracks;
     a.sigma = m->locerr_mode ? b.d_sigma : nullptr;
     a.blob = ctx->d_blob;
+    if (b.d_dt) {  // per-track time steps: one p_stay table (one blob) per chunk of nb_max tracks; model->p_stay covers ALL buckets
+        const int64_t nch = (b.N + nb_max - 1) / nb_max;
+        int64_t base = 0, total = 0;
+        for (size_t i = 0; i < ctx->buckets.size(); ++i) {
+            if ((int)i == bucket_id) base = total;
+            total += (ctx->buckets[i].N + nb_max - 1) / nb_max;
+        }
+        if ((int64_t)m->n_p_stay != total)
+            return xt_fail(ctx, EXTRACK_E_INVALID, "per-track time steps: model->n_p_stay must be the number of chunks (one p_stay table per chunk of nb_max tracks, buckets in id order)");
+        std::vector<int64_t> tables((size_t)nch);
+        for (int64_t c = 0; c < nch; ++c) tables[(size_t)c] = base + c;
+        int64_t stride = 0;
+        if ((rc = xt_th_chunk_blobs(ctx, m, tables, G, &stride))) return rc;
+        a.blob = ctx->d_th_blobs;
+        a.blob_stride = stride;
+        a.dt = b.d_dt;
+    } else if (m->n_p_stay > 1) {
+        return xt_fail(ctx, EXTRACK_E_INVALID, "several p_stay tables but no per-track time steps");
+    }
     a.preds_out = d_preds;
     a.N = b.N;
     a.L = b.L;
@@ -1123,7 +1233,7 @@ extern "C" int extrack_predict_th(extrack_ctx* ctx, const extrack_model* m, int3
     a.nchunks = (int32_t)((b.N + nb_max - 1) / nb_max);
     a.max_nb = max_nb_states;
     a.threshold = threshold;
-    a.pcap = nb_max;
+    a.pcap = std::min(nb_max, XT_TH_PILOT);  // slots of per-track state: the pilots, then the other tracks of the chunk 30 at a time
     a.pair_lanes_max_p = ctx->th_pair_lanes;
     int32_t* d_status = nullptr;
     hipError_t e = hipMalloc(&d_status, (size_t)a.nchunks * 4 * sizeof(int32_t));

@@ -75,6 +75,7 @@ struct DevCtx {
 struct XtBucket {
     const double* d_tracks = nullptr;
     const double* d_sigma = nullptr;
+    double* d_dt = nullptr;  // [N][L] per-track time steps (extrack_set_bucket_dt), owned
     bool owned = false;
     int64_t N = 0;
     int L = 0, D = 0, KS = 0;
@@ -111,6 +112,8 @@ struct extrack_ctx {
     unsigned blob_turn = 0;
     double* d_preds = nullptr;      // posterior output buffer, kept between extrack_predict / extrack_predict_th calls
     size_t preds_cap = 0;
+    double* d_th_blobs = nullptr;   // threshold-fusion path with per-track time steps: one table blob per chunk
+    size_t th_blobs_cap = 0;        // doubles
     double* d_dblob = nullptr;      // gradient path: tangent tables [n_dir][TB]
     size_t dblob_cap = 0;           // doubles
     double* d_gpartials = nullptr;  // gradient path: per-block partial sums [grid][NP + 1] + the reduced row

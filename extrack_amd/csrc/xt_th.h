@@ -25,9 +25,10 @@
 //     exists.  State lives in LDS as one record per (sequence, track) with TT tracks of ONE chunk per workgroup (same plan ->
 //     uniform control flow); with TT = 64 a wavefront is the 64 tracks for one sequence, every plan / table index is
 //     wave-uniform and read with scalar loads, and the merge is fused with the next integration in registers.
-//   * POSTERIORS (xt_th_plan_body<D,K,true>): predict_Bs cuts a bucket into chunks of nb_max <= 30 tracks, so every track is a
-//     pilot track and the plan kernel itself serves: forward pass with per-track histories truncated to frame_len, the merge
-//     weights recorded, then one backward pass over the merge tree reads the posteriors out.
+//   * POSTERIORS (xt_th_plan_body<D,K,true>): predict_Bs cuts a bucket into chunks of nb_max tracks; the (at most 30) first
+//     tracks of a chunk are the pilots and the plan kernel itself serves them: forward pass with per-track histories truncated to
+//     frame_len, the merge weights recorded, then one backward pass over the merge tree reads the posteriors out.  Tracks
+//     beyond the pilots (nb_max > 30) replay the recorded plan with their own merge weights, 30 at a time in the pilots' slots.
 //   * One launch of each kernel serves all length buckets of a dataset through a table of bucket descriptors (XtThBucket).
 #pragma once
 #include <type_traits>
@@ -69,6 +70,7 @@
 struct XtThBucket {
     const double* tracks;  // [N][L][D]
     const double* sigma;   // [N][L][KS] or nullptr
+    const double* dt;      // [N][L] per-track time steps (tracking.py:979-982) or nullptr: then the model's ds already contain dt
     double* ll_out;        // [N] or nullptr
     double* preds_out;     // [N][L][S] (prediction kernel)
     int64_t N;
@@ -86,6 +88,9 @@ struct XtThArgs {
     const double* tracks;  // [N][L][D]
     const double* sigma;   // [N][L][KS] or nullptr
     const double* blob;    // model tables, [prev][r] with r in the reference's digit order (digit 0 = newest sub-state)
+    int64_t blob_stride;   // 0: one blob for every chunk; else doubles between the blobs of consecutive (global) chunks - with per-track
+                           // time steps the field-of-view table, hence the stay / end-of-track tables, belongs to the chunk (tracking.py:507-511)
+    const double* dt;      // single-bucket form of XtThBucket::dt
     double* ll_out;        // [N] or nullptr
     double* partials;      // [grid] per-block LL sums (apply kernel)
     int64_t N;
@@ -157,6 +162,7 @@ XT_HD XtThBucket xt_th_bind(const XtThArgs& a, int gch, int& lc)
     if (a.buckets == nullptr) {
         k.tracks = a.tracks;
         k.sigma = a.sigma;
+        k.dt = a.dt;
         k.ll_out = a.ll_out;
         k.preds_out = a.preds_out;
         k.N = a.N;
@@ -187,6 +193,7 @@ XT_HD XtThBucket xt_th_bind(const XtThArgs& a, int gch, int& lc)
     lc = gch - (lo ? cend[lo - 1] : 0);
     k.tracks = tab[lo].tracks;
     k.sigma = tab[lo].sigma;
+    k.dt = tab[lo].dt;
     k.ll_out = tab[lo].ll_out;
     k.preds_out = tab[lo].preds_out;
     k.N = tab[lo].N;
@@ -239,7 +246,7 @@ XT_HD int64_t xt_th_cmat_doubles(int wsE) { return ((int64_t)wsE * ((wsE + 32) /
 XT_HD int64_t xt_th_hist_doubles(int wsE, int pcap, bool preds, int L)
 {
     if (!preds) return 0;
-    return ((int64_t)L * wsE + 1) / 2 + ((int64_t)L * (wsE + 1) + 3) / 4 + L + (int64_t)pcap * L * wsE + 4;
+    return 2 * (((int64_t)L * wsE + 1) / 2) + ((int64_t)L * (wsE + 1) + 3) / 4 + L + (int64_t)pcap * L * wsE + 4;
 }
 XT_HD int64_t xt_th_ws_doubles(int wsP, int wsE, int D, int K, int F, int NS, int S, int pcap = XT_TH_PILOT, bool preds = false)
 {
@@ -327,7 +334,7 @@ XT_HD void xt_th_integrate(const V& b, int idx, const double* c, const double* l
 // scale to exactly 0).
 template <int D, int K, class V, class MemP, class TabP>
 XT_HD void xt_th_gather_regs(const V& src, int gs, int xoff, MemP members, int k0, int k1, TabP TT, TabP TD2, double& W, int& E, double* M,
-                             double* U)
+                             double* U, const double d2s = 1.0)  // d2s: this track's time step at this position (1 with a fixed dt)
 {
     if (k1 - k0 == 1) {
         const uint32_t pk = members[k0];
@@ -335,7 +342,7 @@ XT_HD void xt_th_gather_regs(const V& src, int gs, int xoff, MemP members, int k
         W = src.zm(idx) * TT[o];
         E = src.ze(idx);
         for (int d = 0; d < D; ++d) M[d] = src.m(d, idx);
-        for (int k = 0; k < K; ++k) U[k] = src.u(k, idx) + TD2[o];
+        for (int k = 0; k < K; ++k) U[k] = xt_fma(TD2[o], d2s, src.u(k, idx));
     } else {
         E = XT_EMIN;
         for (int kk = k0; kk < k1; ++kk) {
@@ -351,7 +358,7 @@ XT_HD void xt_th_gather_regs(const V& src, int gs, int xoff, MemP members, int k
             const double av = xt_ldexp(src.zm(idx) * TT[o], src.ze(idx) - E);  // hugely negative shift saturates to 0
             W += av;
             for (int d = 0; d < D; ++d) M[d] = xt_fma(av, src.m(d, idx), M[d]);
-            for (int k = 0; k < K; ++k) U[k] = xt_fma(av, src.u(k, idx) + TD2[o], U[k]);
+            for (int k = 0; k < K; ++k) U[k] = xt_fma(av, xt_fma(TD2[o], d2s, src.u(k, idx)), U[k]);
         }
         const double rW = (W == 0.0) ? 0.0 : xt_rcp(W);
         for (int d = 0; d < D; ++d) M[d] *= rW;
@@ -363,11 +370,12 @@ XT_HD void xt_th_gather_regs(const V& src, int gs, int xoff, MemP members, int k
 }
 
 template <int D, int K, class V, class V2, class MemP, class TabP>
-XT_HD void xt_th_gather(const V& src, int gs, int xoff, MemP members, int k0, int k1, TabP TT, TabP TD2, const V2& dst, int didx)
+XT_HD void xt_th_gather(const V& src, int gs, int xoff, MemP members, int k0, int k1, TabP TT, TabP TD2, const V2& dst, int didx,
+                        const double d2s = 1.0)
 {
     double W, M[D], U[K];
     int E;
-    xt_th_gather_regs<D, K>(src, gs, xoff, members, k0, k1, TT, TD2, W, E, M, U);
+    xt_th_gather_regs<D, K>(src, gs, xoff, members, k0, k1, TT, TD2, W, E, M, U, d2s);
     dst.zm(didx) = W;
     dst.ze(didx) = E;
     for (int d = 0; d < D; ++d) dst.m(d, didx) = M[d];
@@ -432,7 +440,8 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
     const int PC = a.pcap;                          // pilot capacity: min(30, chunk)
     double* smem = cx.smem();
     const int ntab = xt_tab_doubles(S, G);
-    for (int i = tid; i < ntab; i += nt) smem[i] = a.blob[i];
+    if (a.blob_stride == 0)
+        for (int i = tid; i < ntab; i += nt) smem[i] = a.blob[i];
     const double* hdr = smem;
     const double* TAB = smem + XT_BLOB_HDR;
     const double* T64 = TAB + XT_NTAB * S * G;
@@ -485,7 +494,9 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
     // PREDS: what the backward pass needs - per merge step the members (parent << 16 | new state), group starts, counts
     // (shared by the chunk) and the members' normalised merge weights per track; two vectors of sequence masses per track
     double* beta = wgt + (PREDS ? plane + (plane + 1) / 2 : 0);  // [PC][2][wsP]
-    uint32_t* hmem = (uint32_t*)wh;          // [L][wsE]
+    uint32_t* hmem = (uint32_t*)wh;          // [L][wsE]  (parent << 16 | history entry of the new state)
+    wh += PREDS ? ((int64_t)L * wsE + 1) / 2 : 0;
+    uint32_t* hmpk = (uint32_t*)wh;          // [L][wsE]  (parent << 16 | table offset): the plan itself, replayed by tracks beyond the pilots
     wh += PREDS ? ((int64_t)L * wsE + 1) / 2 : 0;
     uint16_t* hgst = (uint16_t*)wh;          // [L][wsE + 1]
     wh += PREDS ? ((int64_t)L * (wsE + 1) + 3) / 4 : 0;
@@ -510,6 +521,13 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
         uint8_t* gnew_g = bk.gnew + (int64_t)ch * L * capE;
         int32_t* hdr_g = bk.hdr + (int64_t)ch * L * 2;
         cx.sync();  // tables loaded / previous chunk done
+        if (a.blob_stride != 0) {  // per-track time steps: the chunk's own tables
+            for (int i = tid; i < ntab; i += nt) smem[i] = a.blob[(int64_t)gch * a.blob_stride + i];
+            cx.sync();
+        }
+        // time step of track x of the chunk that scales the diffusion term added at step t (tracking.py:494-499, 548-551: column
+        // len - current_step of the unreversed array)
+        auto dtf = [&](int x, int t) -> double { return bk.dt ? bk.dt[(c0 + x) * L + (L - t)] : 1.0; };
 
         auto load_l2 = [&](int x, int pos, double* l2) {
             if (a.locerr_mode == 0) {
@@ -596,7 +614,7 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
                     for (int i = tid; i < P * nE; i += nt) {
                         const int x = i / nE, jj = i - x * nE, g = jj / G, r = jj - g * G;
                         for (int k = 0; k < K; ++k)
-                            sE[k * plane + x * wsE + jj] = sqrt(bA.u(k, x * wsP + g) + TD2[(int)nwA[g] * G + r]);
+                            sE[k * plane + x * wsE + jj] = sqrt(xt_fma(TD2[(int)nwA[g] * G + r], dtf(x, t), bA.u(k, x * wsP + g)));
                     }
                     for (int i = tid; i < nE * NWD; i += nt) cmat[i] = 0u;
                     const bool staged = stP > 0 && nPar <= stP && nE <= stE;
@@ -784,7 +802,7 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
                 const double* TTl = TAB + (stay ? 1 : 0) * S * G;
                 for (int i = tid; i < P * nG; i += nt) {
                     const int x = i / nG, g2 = i - x * nG;
-                    xt_th_gather<D, K>(bA, 1, x * wsP, mpk, (int)gst[g2], (int)gst[g2 + 1], TTl, TD2, bB, x * wsP + g2);
+                    xt_th_gather<D, K>(bA, 1, x * wsP, mpk, (int)gst[g2], (int)gst[g2 + 1], TTl, TD2, bB, x * wsP + g2, dtf(x, t));
                 }
                 // fit mode keeps frame_len history entries (tracking.py:699-701); when predicting the reference keeps all of
                 // them, but only the first frame_len are ever looked at before the final read-out, which is done here by a
@@ -818,6 +836,7 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
                         const int jj = mem[i], g = jj / G;
                         // history entry, not the state (the initial sequences, t == 1, come without the int8 index)
                         hmem[(int64_t)t * wsE + i] = ((uint32_t)g << 16) | (uint32_t)(t == 1 ? jj % S : xt_th_cat_digit(jj, S));
+                        hmpk[(int64_t)t * wsE + i] = mpk[i];
                     }
                     for (int i = tid; i <= nG; i += nt) hgst[(int64_t)t * (wsE + 1) + i] = gst[i];
                     if (tid == 0) {
@@ -925,32 +944,33 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
                 hdr_g[t * 2 + 1] = nG;
             }
         }
-        if (PREDS && !overflow) {
+        // tracks xb .. xb + cnt - 1 of the chunk sit in slots 0 .. cnt - 1 of the state `vA` (nParF parents)
+        auto finish = [&](const int xb, const int cnt, const View& vA, const int nParF) {
             // ---- posteriors (tracking.py:611-648): weights of the final sequences (parent g, new state r) at the last
             // position, then the weighted mean of their state histories; history index 0 = last position
             cx.sync();
-            const int tl = L - 1, nE = nPar * G;
+            const int tl = L - 1, nE = nParF * G;
             const bool stay = tl >= 2 && tl >= a.min_len;
             const double* TF = TAB + ((bk.isBL ? 2 : 0) + (stay ? 1 : 0)) * S * G;
-            for (int i = tid; i < P * nE; i += nt) {
+            for (int i = tid; i < cnt * nE; i += nt) {
                 const int x = i / nE, jj = i - x * nE, g = jj / G, r = jj - g * G, idx = x * wsP + g, o = (int)nwA[g] * G + r;
                 double cl[D], l2l[K], dq[D], dsq = 0.0;
-                load_l2(x, tl, l2l);
+                load_l2(xb + x, tl, l2l);
                 for (int d = 0; d < D; ++d) {
-                    cl[d] = bk.tracks[((c0 + x) * L + tl) * D + d];
-                    dq[d] = cl[d] - bA.m(d, idx);
+                    cl[d] = bk.tracks[((c0 + xb + x) * L + tl) * D + d];
+                    dq[d] = cl[d] - vA.m(d, idx);
                     dsq = xt_fma(dq[d], dq[d], dsq);
                 }
                 double quad, gf;
                 if (K == 1) {
-                    const double rr = xt_rcp(TD2[o] + bA.u(0, idx) + l2l[0]);
+                    const double rr = xt_rcp(xt_fma(TD2[o], dtf(xb + x, tl), vA.u(0, idx)) + l2l[0]);
                     quad = 0.5 * dsq * rr;
                     gf = xt_pow_half<D>(rr);
                 } else {
                     quad = 0.0;
                     gf = 1.0;
                     for (int d = 0; d < D; ++d) {
-                        const double rr = xt_rcp(TD2[o] + bA.u(d, idx) + l2l[d]);
+                        const double rr = xt_rcp(xt_fma(TD2[o], dtf(xb + x, tl), vA.u(d, idx)) + l2l[d]);
                         quad = xt_fma(0.5 * dq[d] * dq[d], rr, quad);
                         gf *= rr;
                     }
@@ -959,12 +979,12 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
                 double p;
                 int j6, n2;
                 xt_exp_tab(-quad, p, j6, n2);
-                const double wm = bA.zm(idx) * TF[o] * (gf * T64[j6]) * p;
+                const double wm = vA.zm(idx) * TF[o] * (gf * T64[j6]) * p;
                 wgt[x * wsE + jj] = wm;
-                wexp[x * wsE + jj] = (wm != 0.0) ? bA.ze(idx) + n2 : XT_EMIN;
+                wexp[x * wsE + jj] = (wm != 0.0) ? vA.ze(idx) + n2 : XT_EMIN;
             }
             cx.sync();
-            for (int x = tid; x < P; x += nt) {  // per track: common exponent, normalisation
+            for (int x = tid; x < cnt; x += nt) {  // per track: common exponent, normalisation
                 int E = XT_EMIN;
                 for (int jj = 0; jj < nE; ++jj) E = wexp[x * wsE + jj] > E ? wexp[x * wsE + jj] : E;
                 double tot = 0.0;
@@ -979,13 +999,13 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
             // backward pass (one thread per track, fixed summation order): the mass a final sequence carries flows back
             // through the merge tree; what passes through a member with new state r at merge step t is the posterior mass
             // of state r at position t
-            for (int x = tid; x < P; x += nt) {
-                double* post = bk.preds_out + (c0 + x) * (int64_t)L * S;
+            for (int x = tid; x < cnt; x += nt) {
+                double* post = bk.preds_out + (c0 + xb + x) * (int64_t)L * S;
                 for (int i = 0; i < L * S; ++i) post[i] = 0.0;
                 double* bc = beta + (int64_t)x * 2 * wsP;
                 double* bp = bc + wsP;
                 const double rt = 1.0 / pm[x];
-                for (int g = 0; g < nPar; ++g) bc[g] = 0.0;
+                for (int g = 0; g < nParF; ++g) bc[g] = 0.0;
                 for (int jj = 0; jj < nE; ++jj) {
                     const int g = jj / G;
                     const double om = wgt[x * wsE + jj] * rt;
@@ -1012,6 +1032,74 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
                 for (int s2 = 0; s2 < S; ++s2) post[s2] = bc[s2];
             }
             cx.sync();
+        };
+        if (PREDS && !overflow) {
+            finish(0, P, bA, nPar);
+            // ---- tracks beyond the pilots (predict_Bs with nb_max > 30, tracking.py:856-868): they take no part in the merge
+            // decisions (fuse_tracks_th looks at the first 30 tracks only, tracking.py:676-691) but are merged with THEIR OWN
+            // weights (tracking.py:703-741): replay the recorded plan batch by batch in the pilots' slots
+            for (int xb = P; xb < n; xb += PC) {
+                const int cnt = (n - xb) < PC ? (n - xb) : PC;
+                cx.sync();
+                for (int i = tid; i < cnt * S; i += nt) {
+                    const int x = i / S, s2 = i - x * S, idx = x * wsP + s2;
+                    double l2[K];
+                    load_l2(xb + x, 0, l2);
+                    A.zm(idx) = hdr[8 + s2];
+                    A.ze(idx) = 0;
+                    for (int d = 0; d < D; ++d) A.m(d, idx) = bk.tracks[((c0 + xb + x) * L + 0) * D + d];
+                    for (int k = 0; k < K; ++k) A.u(k, idx) = l2[k];
+                }
+                View fA = A, fB = B;
+                int fPar = S;
+                cx.sync();
+                for (int t = 1; t <= L - 1; ++t) {
+                    if (t >= 2) {
+                        const int pos = t - 1;
+                        for (int i = tid; i < cnt * fPar; i += nt) {
+                            const int x = i / fPar, g = i - x * fPar;
+                            double c[D], l2[K];
+                            for (int d = 0; d < D; ++d) c[d] = bk.tracks[((c0 + xb + x) * L + pos) * D + d];
+                            load_l2(xb + x, pos, l2);
+                            xt_th_integrate<D, K>(fA, x * wsP + g, c, l2, T64);
+                        }
+                        cx.sync();
+                    }
+                    if (t < L - 1) {
+                        const int nEt = hn[t * 2], nGt = hn[t * 2 + 1];
+                        for (int i = tid; i < nEt; i += nt) mpk[i] = hmpk[(int64_t)t * wsE + i];
+                        for (int i = tid; i <= nGt; i += nt) gst[i] = hgst[(int64_t)t * (wsE + 1) + i];
+                        cx.sync();
+                        const bool stay = t >= 2 && t >= a.min_len;
+                        const double* TTl = TAB + (stay ? 1 : 0) * S * G;
+                        for (int i = tid; i < cnt * nGt; i += nt) {
+                            const int x = i / nGt, g2 = i - x * nGt;
+                            const int k0 = gst[g2], k1 = gst[g2 + 1];
+                            xt_th_gather<D, K>(fA, 1, x * wsP, mpk, k0, k1, TTl, TD2, fB, x * wsP + g2, dtf(xb + x, t));
+                            int E = XT_EMIN;
+                            for (int kk = k0; kk < k1; ++kk) {
+                                const int e = fA.ze(x * wsP + (int)(mpk[kk] >> 16));
+                                E = e > E ? e : E;
+                            }
+                            double W = 0.0;
+                            for (int kk = k0; kk < k1; ++kk) {
+                                const int idx = x * wsP + (int)(mpk[kk] >> 16);
+                                const double av = xt_ldexp(fA.zm(idx) * TTl[mpk[kk] & 0xffffu], fA.ze(idx) - E);
+                                hw[((int64_t)x * L + t) * wsE + kk] = av;
+                                W += av;
+                            }
+                            for (int kk = k0; kk < k1; ++kk)
+                                hw[((int64_t)x * L + t) * wsE + kk] = (k1 - k0 == 1) ? 1.0 : hw[((int64_t)x * L + t) * wsE + kk] / W;
+                        }
+                        cx.sync();
+                        View tb = fA;
+                        fA = fB;
+                        fB = tb;
+                        fPar = nGt;
+                    }
+                }
+                finish(xb, cnt, fA, fPar);
+            }
         }
         XT_TH_PROF_DUMP(PREDS ? "posteriors" : "fit");
         if (tid == 0) {
@@ -1033,7 +1121,9 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
 //   UNI = false: TT < 64 (many live sequences: fewer tracks fit the LDS); a wavefront spans several groups, the chunk's
 //                plan is staged in LDS (all merged steps when they fit, else step by step).
 // ------------------------------------------------------------------------------------------------------------------
-template <int D, int K, bool UNI, bool SINGLE, class Ctx>
+// DT = true: per-track time steps (XtThBucket::dt) - a separate instantiation, so that the fixed-dt kernels keep their register
+// budget (the two extra VGPRs of the time step cost the wave-uniform variant one wave per SIMD, i.e. one of its two workgroups per CU).
+template <int D, int K, bool UNI, bool SINGLE, bool DT, class Ctx>
 XT_HD void xt_th_apply_body(const XtThArgs& a, Ctx& cx)
 {
     typedef XtThView<D, K, true> View;
@@ -1048,7 +1138,8 @@ XT_HD void xt_th_apply_body(const XtThArgs& a, Ctx& cx)
     const int TP = TT + 1;  // padded row of the position stage
     double* smem = cx.smem();
     const int ntab = xt_tab_doubles(S, G);
-    for (int i = tid; i < ntab; i += nt) smem[i] = a.blob[i];
+    const double* blob_c = a.blob + (int64_t)gch * a.blob_stride;  // the chunk's tables (the same for all chunks unless dt is per track)
+    for (int i = tid; i < ntab; i += nt) smem[i] = blob_c[i];
     const double* hdr = smem;
     const double* TABl = smem + XT_BLOB_HDR;
     const double* T64 = TABl + XT_NTAB * S * G;
@@ -1058,7 +1149,7 @@ XT_HD void xt_th_apply_body(const XtThArgs& a, Ctx& cx)
     typedef XtCPtr<UNI, uint16_t> CU16;
     typedef XtCPtr<UNI, uint8_t> CU8;
     typedef XtCPtr<UNI, int32_t> CI32;
-    const typename CD::type TAB = CD::make(UNI ? a.blob + XT_BLOB_HDR : TABl);
+    const typename CD::type TAB = CD::make(UNI ? blob_c + XT_BLOB_HDR : TABl);
     const typename CD::type TD2 = TAB + 4 * S * G;
     double* w = smem + ((ntab + 1) & ~1);
     const int plane = capG * TT;
@@ -1165,6 +1256,8 @@ XT_HD void xt_th_apply_body(const XtThArgs& a, Ctx& cx)
             }
         };
 
+        // this track's time step scaling the diffusion term added at step t (1 with a fixed dt: the tables then contain it)
+        auto dt_at = [&](int t) -> double { return (DT && act) ? bk.dt[(first + x) * L + (L - t)] : 1.0; };
         stage(0);
         // ---- position 0: S parents
         if (act) {
@@ -1195,6 +1288,7 @@ XT_HD void xt_th_apply_body(const XtThArgs& a, Ctx& cx)
                 double c[D], l2[K];
                 for (int d = 0; d < D; ++d) c[d] = spos[((t & (XT_TH_STAGE - 1)) * D + d) * TP + x];
                 load_l2(t, l2);
+                const double dtv = dt_at(t);
                 if (SINGLE) {
                     // half the LDS: every wavefront first merges its (at most XT_TH_GPW) groups into registers, and the
                     // integrated results overwrite the buffer only after all wavefronts have finished reading it
@@ -1207,7 +1301,7 @@ XT_HD void xt_th_apply_body(const XtThArgs& a, Ctx& cx)
                         const int g2 = g0 + q * gstep;
                         if (g2 < nG)
                             xt_th_gather_regs<D, K>(cur, TT, x, mem, (int)gst[g2], (int)gst[g2 + 1], TTl, TABl + 4 * S * G, Wq[q], Eq[q], Mq[q],
-                                                    Uq[q]);
+                                                    Uq[q], dtv);
                     }
                     cx.sync();
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1224,7 +1318,7 @@ XT_HD void xt_th_apply_body(const XtThArgs& a, Ctx& cx)
                 for (int g2 = g0; g2 < nG; g2 += gstep) {
                     double W, M[D], U[K];
                     int E;
-                    xt_th_gather_regs<D, K>(cur, TT, x, mem, (int)gst[g2], (int)gst[g2 + 1], TTl, TABl + 4 * S * G, W, E, M, U);
+                    xt_th_gather_regs<D, K>(cur, TT, x, mem, (int)gst[g2], (int)gst[g2 + 1], TTl, TABl + 4 * S * G, W, E, M, U, dtv);
                     xt_th_integrate_store<D, K>(W, E, M, U, c, l2, T64, nxt, g2 * TT + x);
                 }
                 cx.sync();
@@ -1252,6 +1346,7 @@ XT_HD void xt_th_apply_body(const XtThArgs& a, Ctx& cx)
                 double c[D], l2[K];
                 for (int d = 0; d < D; ++d) c[d] = spos[((t & (XT_TH_STAGE - 1)) * D + d) * TP + x];
                 load_l2(t, l2);
+                const double dtv = dt_at(t);
                 double Wq[XT_TH_GPW], Mq[XT_TH_GPW][D], Uq[XT_TH_GPW][K];
                 int Eq[XT_TH_GPW];
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1260,7 +1355,7 @@ XT_HD void xt_th_apply_body(const XtThArgs& a, Ctx& cx)
                 for (int q = 0; q < XT_TH_GPW; ++q) {
                     const int g2 = g0 + q * gstep;
                     if (act && g2 < nG)
-                        xt_th_gather_regs<D, K>(cur, TT, x, mem, (int)gst[g2], (int)gst[g2 + 1], TTl, TABl + 4 * S * G, Wq[q], Eq[q], Mq[q], Uq[q]);
+                        xt_th_gather_regs<D, K>(cur, TT, x, mem, (int)gst[g2], (int)gst[g2 + 1], TTl, TABl + 4 * S * G, Wq[q], Eq[q], Mq[q], Uq[q], dtv);
                 }
                 cx.sync();
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1297,9 +1392,10 @@ XT_HD void xt_th_apply_body(const XtThArgs& a, Ctx& cx)
                 cx.sync();
                 const bool stay = t >= 2 && t >= a.min_len;
                 const typename CD::type TTl = TAB + (stay ? 1 : 0) * S * G;
+                const double dtv = dt_at(t);
                 if (act || UNI)  // UNI: keep the control flow wave-uniform (inactive lanes work on slot garbage, never stored out)
                     for (int g2 = g0; g2 < nG; g2 += gstep)
-                        xt_th_gather<D, K>(cur, TT, x, mem, (int)gst[g2], (int)gst[g2 + 1], TTl, TD2, nxt, g2 * TT + x);
+                        xt_th_gather<D, K>(cur, TT, x, mem, (int)gst[g2], (int)gst[g2 + 1], TTl, TD2, nxt, g2 * TT + x, dtv);
                 cx.sync();
                 View tb = cur;
                 cur = nxt;
@@ -1320,6 +1416,7 @@ XT_HD void xt_th_apply_body(const XtThArgs& a, Ctx& cx)
             double cl[D], l2l[K];
             for (int d = 0; d < D; ++d) cl[d] = spos[((tl & (XT_TH_STAGE - 1)) * D + d) * TP + x];
             load_l2(tl, l2l);
+            const double dtl = dt_at(tl);
             for (int g = g0; g < nPar; g += gstep) {
                 const int idx = g * TT + x;
                 XtAcc acc;
@@ -1337,14 +1434,14 @@ XT_HD void xt_th_apply_body(const XtThArgs& a, Ctx& cx)
                 for (int r = 0; r < G; ++r) {
                     double quad, gf;
                     if (K == 1) {
-                        const double rr = xt_rcp(TD2[o + r] + uq[0] + l2l[0]);
+                        const double rr = xt_rcp(xt_fma(TD2[o + r], dtl, uq[0]) + l2l[0]);
                         quad = 0.5 * dsq * rr;
                         gf = xt_pow_half<D>(rr);
                     } else {
                         quad = 0.0;
                         gf = 1.0;
                         for (int d = 0; d < D; ++d) {
-                            const double rr = xt_rcp(TD2[o + r] + uq[d] + l2l[d]);
+                            const double rr = xt_rcp(xt_fma(TD2[o + r], dtl, uq[d]) + l2l[d]);
                             quad = xt_fma(0.5 * dq[d] * dq[d], rr, quad);
                             gf *= rr;
                         }

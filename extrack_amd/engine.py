@@ -98,13 +98,17 @@ class TrackSet:
     dataset must be given the global ones (extrack/tracking.py:1009-1010 uses the whole list).
     """
 
-    def __init__(self, buckets, sigmas=None, device=0, min_len=None, max_len=None, allow_empty=False):
+    def __init__(self, buckets, sigmas=None, device=0, min_len=None, max_len=None, allow_empty=False, dts=None):
         """allow_empty: a shard of a distributed dataset may hold no track at all (its objective is 0.0, its posteriors are
-        empty); the dataset-global ``min_len`` / ``max_len`` must then be given."""
+        empty); the dataset-global ``min_len`` / ``max_len`` must then be given.
+        dts: optional list of per-track time steps [N_l, l] matching ``buckets`` (extrack/tracking.py:979-982: ``dt`` given as a
+        dict of arrays); only the threshold-fusion kernels take them."""
         if len(buckets) < 1 and not allow_empty:
             raise ValueError("No track could be detected. The loaded tracks seem empty. Errors often come from wrong input paths.")
         self.ctx = _lib.Context(device)
         self.shapes = []
+        self.dt0 = []  # first column of every bucket's dt array (host copy): what the per-chunk field-of-view tables are made from
+        self.has_dt = dts is not None
         for i, b in enumerate(buckets):
             b = np.asarray(b, dtype=np.float64)
             if b.ndim != 3:
@@ -115,8 +119,14 @@ class TrackSet:
             if s is not None and (s.ndim != 3 or s.shape[:2] != b.shape[:2] or s.shape[2] not in (1, b.shape[2])):
                 raise ValueError("Localization error is not specified correctly: input_LocErr must match all_tracks")
             if len(b):
-                self.ctx.upload_bucket(b, s)
+                bid = self.ctx.upload_bucket(b, s)
                 self.shapes.append(b.shape)
+                if dts is not None:
+                    t = np.asarray(dts[i], dtype=np.float64)
+                    if t.shape != b.shape[:2]:
+                        raise ValueError("dt must be a float or, per bucket, an array [n_tracks, len] matching all_tracks")
+                    self.ctx.set_bucket_dt(bid, t)
+                    self.dt0.append(np.array(t[:, 0]))
         if not self.shapes and not (allow_empty and min_len is not None and max_len is not None):
             self.ctx.close()
             raise ValueError("No track could be detected. The loaded tracks seem empty. Errors often come from wrong input paths.")
@@ -128,12 +138,25 @@ class TrackSet:
         self.dims = int(self.shapes[0][2]) if self.shapes else 0
 
     # ---- model handle -------------------------------------------------------------------------------------
-    def make_model(self, LocErr, ds, Fs, TrMat, pBL, cell_dims, nb_substeps, frame_len, slope_offset=None):
+    def make_model(self, LocErr, ds, Fs, TrMat, pBL, cell_dims, nb_substeps, frame_len, slope_offset=None, dt_chunk=None):
         """LocErr: global localisation error array of shape (1,1,k) (k = 1 or dims), or None when the per-peak
-        errors uploaded with the buckets are to be used (then slope_offset = (slope, offset) or None)."""
+        errors uploaded with the buckets are to be used (then slope_offset = (slope, offset) or None).
+        With per-track time steps (``dts``): ``ds`` are the diffusion lengths of a UNIT time step, sqrt(2 D), and ``dt_chunk`` the
+        chunk size of the evaluation the model is for - the field-of-view table of a chunk is computed from the median over its
+        tracks of sqrt(2 D dt[track, 0]) (extrack/tracking.py:507-511)."""
         ds = np.asarray(ds, float)
         S = len(ds)
-        ps = p_stay_table(ds, S, nb_substeps, cell_dims)
+        if self.has_dt:
+            if not dt_chunk:
+                raise ValueError("per-track time steps: the model needs the chunk size of the evaluation (dt_chunk)")
+            tabs = []
+            for t0 in self.dt0:
+                for a in range(0, len(t0), int(dt_chunk)):
+                    med = np.median(np.sqrt(ds[None] ** 2 * t0[a:a + int(dt_chunk), None]), axis=0)
+                    tabs.append(p_stay_table(med, S, nb_substeps, cell_dims))
+            ps = np.array(tabs)
+        else:
+            ps = p_stay_table(ds, S, nb_substeps, cell_dims)
         if LocErr is None:
             if not self.has_sigma:
                 raise ValueError("per-peak localisation errors requested but none were uploaded")

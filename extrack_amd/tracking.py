@@ -20,7 +20,7 @@ keyword ``fusion``:
   ``fusion="threshold"``         the THRESHOLD-FUSION kernel ``P_Cs_inter_bound_stats_th`` (tracking.py:427-743) that
                                  ``extrack.tracking.param_fitting`` calls in v1.6.3, chunked by 2000 tracks like
                                  ``cum_Proba_Cs`` (tracking.py:1043); ``predict_Bs`` then works in chunks of ``nb_max``
-                                 tracks (tracking.py:856-868; nb_max <= 30).
+                                 tracks (tracking.py:856-868).
 ``workers`` is accepted and ignored: the tracks are sharded over GPUs instead (extrack_amd.distributed).
 """
 import os
@@ -83,8 +83,9 @@ def extract_params(params, dt, nb_states, nb_substeps, input_LocErr=None, Matrix
     ``nb_states`` is accepted and unused, exactly like the reference.  ``LocErr`` is a list: one
     (1,1,k) array for a global error, or one per-peak array per bucket when ``input_LocErr`` is given
     (affinely rescaled and clipped at 1e-6 if ``slope_LocErr``/``offset_LocErr`` are parameters)."""
-    if isinstance(dt, (list, dict)):
-        raise NotImplementedError("per-track time steps (dt as list/dict, extrack/tracking.py:979-982) are not built: scalar dt only")
+    if isinstance(dt, dict):
+        raise TypeError("dt as a dict is sorted into a list (bucket order) by param_fitting / predict_Bs before extract_params "
+                        "(extrack/tracking.py:1349-1368): pass that list")
     le, Ds, Fs, TrMat, pBL, so = _extract_arrays(params, dt, nb_substeps, Matrix_type)
     LocErr = [le[None, None]]
     if input_LocErr is not None:
@@ -92,7 +93,10 @@ def extract_params(params, dt, nb_states, nb_substeps, input_LocErr=None, Matrix
             LocErr = [np.clip(x * so[0] + so[1], 0.000001, np.inf) for x in input_LocErr]
         else:
             LocErr = input_LocErr
-    ds = np.sqrt(2 * Ds * dt)
+    if isinstance(dt, list):  # per-track time steps: one array [n_tracks, len, S] per bucket (tracking.py:979-982)
+        ds = [np.sqrt(2 * Ds[None, None] * np.asarray(t, float)[:, :, None]) for t in dt]
+    else:
+        ds = np.sqrt(2 * Ds * dt)
     return LocErr, ds, Fs, TrMat, pBL
 
 
@@ -188,6 +192,15 @@ def get_params(nb_states=2, steady_state=False, vary_params=_GP_VARY, estimated_
     return params
 
 
+def _sorted_dt(dt, all_tracks):
+    """dt given as {len: array[n_tracks, len]} -> list in the order of the non-empty buckets (extrack/tracking.py:1349-1368); a scalar
+    dt is returned unchanged."""
+    if not isinstance(dt, dict):
+        return dt
+    keys = np.sort(np.array(list(all_tracks.keys())).astype(int)).astype(str)
+    return [np.asarray(dt[k], dtype=np.float64) for k in keys if len(all_tracks[k]) > 0]
+
+
 def _check_fusion(fusion):
     if fusion is None:
         fusion = default_fusion()
@@ -270,7 +283,7 @@ def _resolve_device(device, comm):
     return comm.local_device() if comm is not None else 0
 
 
-def _as_trackset(all_tracks, input_LocErr, device=None, comm=None):
+def _as_trackset(all_tracks, input_LocErr, device=None, comm=None, dt=None):
     """(TrackSet, owned).  A ``TrackSet`` is used as is.  A list of bucket arrays (what the reference's objective receives at
     every call) is uploaded for THIS call only and released afterwards (``owned``): device copies are never cached behind the
     caller's back, so edited or re-allocated arrays can not be confused with earlier ones.  Keep a ``TrackSet`` (or use
@@ -279,21 +292,28 @@ def _as_trackset(all_tracks, input_LocErr, device=None, comm=None):
     if isinstance(all_tracks, TrackSet):
         return all_tracks, False
     dev = _resolve_device(device, comm)
+    dts = dt if isinstance(dt, list) else None
     if comm is None:
-        return TrackSet(list(all_tracks), input_LocErr, device=dev), True
+        return TrackSet(list(all_tracks), input_LocErr, device=dev, dts=dts), True
+    if dts is not None:
+        raise NotImplementedError("per-track time steps with a communicator: shard with Comm.shard_trackset(..., dts=...)")
     lo, hi = comm.global_min_max_len([np.shape(b)[1] for b in all_tracks if len(b)])
     return TrackSet(list(all_tracks), input_LocErr, device=dev, min_len=lo, max_len=hi, allow_empty=True), True
 
 
-def _objective_model(params, ts, dt, cell_dims, input_LocErr, nb_states, nb_substeps, frame_len, Matrix_type):
-    LocErr, ds, Fs, TrMat, pBL = extract_params(params, dt, nb_states, nb_substeps, None, Matrix_type)
+def _objective_model(params, ts, dt, cell_dims, input_LocErr, nb_states, nb_substeps, frame_len, Matrix_type, dt_chunk=None):
+    """Model handle of one objective evaluation, or None for invalid parameters (tracking.py:1017).  With per-track time steps
+    (``ts.has_dt``; ``dt`` is then ignored, the arrays live with the TrackSet) the diffusion lengths are those of a unit time step
+    and the validity check looks at the diffusion coefficients themselves (the reference compares medians of ds, tracking.py:1011-1017:
+    the same order)."""
+    le, Ds, Fs, TrMat, pBL, so = _extract_arrays(params, dt, nb_substeps, Matrix_type)
+    ds = np.sqrt(2 * Ds) if ts.has_dt else np.sqrt(2 * Ds * dt)
     valid = bool(np.all(TrMat > 0) and np.all(Fs > 0) and np.all(ds[1:] - ds[:-1] >= 0))  # tracking.py:1017
     if not valid:
         return None
     if ts.has_sigma:  # per-peak errors win over any LocErr parameter (tracking.py:926-932)
-        so = (params["slope_LocErr"].value, params["offset_LocErr"].value) if "slope_LocErr" in params else None
-        return ts.make_model(None, ds, Fs, TrMat, pBL, cell_dims, nb_substeps, frame_len, slope_offset=so)
-    return ts.make_model(LocErr[0], ds, Fs, TrMat, pBL, cell_dims, nb_substeps, frame_len)
+        return ts.make_model(None, ds, Fs, TrMat, pBL, cell_dims, nb_substeps, frame_len, slope_offset=so, dt_chunk=dt_chunk)
+    return ts.make_model(le[None, None], ds, Fs, TrMat, pBL, cell_dims, nb_substeps, frame_len, dt_chunk=dt_chunk)
 
 
 def cum_Proba_Cs(params, all_tracks, dt, cell_dims, input_LocErr, nb_states, nb_substeps, frame_len, verbose=1, workers=1,
@@ -310,9 +330,14 @@ def cum_Proba_Cs(params, all_tracks, dt, cell_dims, input_LocErr, nb_states, nb_
     th = _check_fusion(fusion)
     if th and comm is not None and not isinstance(all_tracks, TrackSet):
         raise ValueError("fusion='threshold' with comm needs chunk-aligned shards: pass the TrackSet of comm.shard_trackset(..., chunk=...)")
-    ts, owned = _as_trackset(all_tracks, input_LocErr, device, comm)
+    ts, owned = _as_trackset(all_tracks, input_LocErr, device, comm, dt)
     try:
-        model = _objective_model(params, ts, dt, cell_dims, input_LocErr, nb_states, nb_substeps, frame_len, Matrix_type)
+        if ts.has_dt and not th:
+            raise NotImplementedError("per-track time steps (dt as a dict / list of arrays) exist in the threshold-fusion kernel only "
+                                      "(extrack/tracking.py:494-499); the fixed-window kernel of extrack/tracking_0.py has no such input: "
+                                      "use fusion='threshold'")
+        model = _objective_model(params, ts, dt, cell_dims, input_LocErr, nb_states, nb_substeps, frame_len, Matrix_type,
+                                 dt_chunk=max_number_of_tracks_per_matrix)
         if model is not None:
             if th and comm is not None:  # shards are whole chunks, so the chunking is that of the unsharded dataset
                 Cum_P = comm.allreduce_loglik_th(ts, model, threshold, max_nb_states, max_number_of_tracks_per_matrix)
@@ -401,10 +426,17 @@ def param_fitting(all_tracks, dt, params=None, nb_states=2, nb_substeps=1, frame
         print("Warning frame_len has to be at least nb_substeps + 1")
         frame_len = nb_substeps + 1
     print("cell_dims", cell_dims)
+    dt = _sorted_dt(dt, all_tracks)
+    dts = dt if isinstance(dt, list) else None
+    if dts is not None and fusion != "threshold":
+        raise NotImplementedError("per-track time steps (dt as a dict of arrays) exist in the threshold-fusion kernel only "
+                                  "(extrack/tracking.py:494-499): use fusion='threshold' (or EXTRACK_FUSION=threshold)")
     if comm is not None:
+        if dts is not None:
+            raise NotImplementedError("per-track time steps are not sharded over a communicator yet: one GPU")
         ts = comm.shard_trackset(tracks, sigmas, device=device, chunk=2000 if fusion == "threshold" else None)
     else:
-        ts = TrackSet(tracks, sigmas, device=device)
+        ts = TrackSet(tracks, sigmas, device=device, dts=dts)
     from . import lmfit_compat
     can_grad = fusion == "window" and not lmfit_compat.HAVE_LMFIT and str(method).lower() in lmfit_compat._GRADIENT_METHODS
     if gradient not in (None, "analytic", "fd"):
@@ -442,25 +474,31 @@ def predict_Bs(all_tracks, dt, params, cell_dims=[1], nb_states=4, frame_len=5, 
                                                      for k, v in input_LocErr.items()}
         if _check_fusion(fusion) and nb_max != 1:
             raise NotImplementedError("fusion='threshold' with nb_max > 1 depends on the chunking of the whole bucket: one GPU only")
-        local = predict_Bs(loc_tracks, dt, params, cell_dims, nb_states, frame_len, max_nb_states, threshold, workers, loc_sig, verbose,
+        loc_dt = dt if not isinstance(dt, dict) else {k: np.asarray(v)[slice(*shard_range(len(v), comm.rank, comm.world))] for k, v in dt.items()}
+        local = predict_Bs(loc_tracks, loc_dt, params, cell_dims, nb_states, frame_len, max_nb_states, threshold, workers, loc_sig, verbose,
                            nb_max, device, None, fusion)
         return comm.gather_rows(local)
     keys, tracks, sigmas = engine.sort_buckets(all_tracks, input_LocErr)
     if not is_parameters(params):
         raise TypeError("params must be either of the class 'lmfit.parameter.Parameters' or a dictionary of the relevant parameters")
     nb_substeps = 1
-    LocErr, ds, Fs, TrMat, pBL = extract_params(params, dt, nb_states, nb_substeps, None)
+    dt = _sorted_dt(dt, all_tracks)
+    dts = dt if isinstance(dt, list) else None
+    if dts is not None and fusion != "threshold":
+        raise NotImplementedError("per-track time steps (dt as a dict of arrays) exist in the threshold-fusion kernel only "
+                                  "(extrack/tracking.py:494-499): use fusion='threshold' (or EXTRACK_FUSION=threshold)")
+    le, Ds, Fs, TrMat, pBL, so = _extract_arrays(params, dt, nb_substeps, 1)
+    ds = np.sqrt(2 * Ds) if dts is not None else np.sqrt(2 * Ds * dt)
     S = len(ds)
     out = {l: np.empty((0, int(l), S)) for l in keys}
     if not tracks:
         return out
-    ts = TrackSet(tracks, sigmas, device=device, min_len=max(int(keys[0]), 2), max_len=int(keys[-1]))
+    ts = TrackSet(tracks, sigmas, device=device, min_len=max(int(keys[0]), 2), max_len=int(keys[-1]), dts=dts)
     try:
         if sigmas is not None:
-            so = (params["slope_LocErr"].value, params["offset_LocErr"].value) if "slope_LocErr" in params else None
-            model = ts.make_model(None, ds, Fs, TrMat, pBL, cell_dims, 1, frame_len, slope_offset=so)
+            model = ts.make_model(None, ds, Fs, TrMat, pBL, cell_dims, 1, frame_len, slope_offset=so, dt_chunk=nb_max)
         else:
-            model = ts.make_model(LocErr[0], ds, Fs, TrMat, pBL, cell_dims, 1, frame_len)
+            model = ts.make_model(le[None, None], ds, Fs, TrMat, pBL, cell_dims, 1, frame_len, dt_chunk=nb_max)
         res = ts.predict_th(model, threshold, max_nb_states, nb_max) if _check_fusion(fusion) else ts.predict(model)
         for arr, pr in zip(tracks, res):
             out[str(arr.shape[1])] = pr

@@ -69,7 +69,8 @@ typedef struct extrack_model {
     int32_t locerr_mode; /* 0: global locerr[]; 1: per-peak sigma uploaded with the bucket;
                             2: per-peak, sigma' = clip(sigma*slope + offset, 1e-6, inf) (tracking.py:928-930) */
     int32_t locerr_dims; /* mode 0: 1 (one value for all dims) or D (one per dim) */
-    int32_t reserved;
+    int32_t n_p_stay;    /* 0 or 1: p_stay is ONE table; n > 1: p_stay holds n tables, one per chunk (per-track time steps, see
+                            extrack_set_bucket_dt) */
     double locerr[3];    /* mode 0: localisation error (std) */
     double slope, offset;
     double pBL;          /* bleaching probability per step */
@@ -101,6 +102,13 @@ int extrack_upload_bucket(extrack_ctx* ctx, const double* tracks, int64_t n, int
  * them alive until extrack_clear_buckets / extrack_destroy. */
 int extrack_attach_bucket(extrack_ctx* ctx, const double* d_tracks, int64_t n, int32_t len, int32_t dims,
                           const double* d_sigma, int32_t sigma_dims, int32_t* bucket_id_out);
+/* Per-track time steps of one bucket (extrack/tracking.py:979-982: dt given as {len: array[n][len]}): dt host [n][len], copied
+ * to the device; NULL removes them.  Only the threshold-fusion entry points use them (the reference's fixed-window kernel has no
+ * such input).  With time steps set, model->ds must be the diffusion lengths for a UNIT time step (sqrt(2 D)): the diffusion
+ * term added at step t is scaled by dt[track][len - t] (tracking.py:494-499, 548-551 - the reference reads its UNREVERSED array
+ * at column len - current_step), and model->p_stay must hold one table per chunk, buckets in id order, chunks in row order: the
+ * field-of-view table of a chunk comes from the median over the chunk's tracks of sqrt(2 D dt[track][0]) (tracking.py:507-511). */
+int extrack_set_bucket_dt(extrack_ctx* ctx, int32_t bucket_id, const double* dt);
 int extrack_clear_buckets(extrack_ctx* ctx);
 int extrack_bucket_count(const extrack_ctx* ctx);
 
@@ -154,7 +162,7 @@ int extrack_segment_len_hist(extrack_ctx* ctx, const extrack_model* model, int32
  * tracking.py:1043) and applied to the whole chunk, so the value depends on `chunk` and on the track order.
  * model->frame_len is the number of most recent states whose equality forces a merge; threshold and
  * max_nb_states as in tracking.py:427 (threshold is multiplied by 1.2 at every step with more than
- * max_nb_states live sequences).  Fixed time step only (scalar dt).
+ * max_nb_states live sequences).  Time steps: fixed (in model->ds) or per track (extrack_set_bucket_dt).
  * total_ll / per_track as in extrack_loglik. */
 int extrack_loglik_th(extrack_ctx* ctx, const extrack_model* model, double threshold, int32_t max_nb_states, int32_t chunk,
                       double* total_ll, double* per_track);
@@ -164,8 +172,9 @@ int extrack_loglik_th_async(extrack_ctx* ctx, const extrack_model* model, double
                             double* d_total_ll);
 /* Threshold-fusion state posteriors of one bucket (P_Cs_inter_bound_stats_th(..., do_preds=1), extrack/tracking.py:427-650,
  * driven as predict_Bs drives it, tracking.py:792-906): preds host [n][len][S].  The bucket is cut into chunks of nb_max
- * consecutive tracks (predict_Bs default: 1, i.e. every track decides its own merges); nb_max <= 30, so that every track of a
- * chunk is one of the tracks the merge decisions are taken on.  model->nb_substeps must be 1 (tracking.py:839). */
+ * consecutive tracks (predict_Bs default: 1, i.e. every track decides its own merges); with nb_max > 30 the first 30 tracks of a
+ * chunk decide the merges (tracking.py:676-691) and the others follow them with their own merge weights (tracking.py:703-741).
+ * model->nb_substeps must be 1 (tracking.py:839). */
 int extrack_predict_th(extrack_ctx* ctx, const extrack_model* model, int32_t bucket_id, double threshold, int32_t max_nb_states,
                        int32_t nb_max, double* preds);
 

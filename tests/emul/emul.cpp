@@ -335,6 +335,34 @@ static void th_emul_blocks(int nblocks, int threads, size_t lds_doubles, Body bo
     }
 }
 
+// Per-track time steps for the next xt_emul_th_run / xt_emul_th_predict call: dt [N][L] and one p_stay table [G] per chunk.
+static const double* g_th_dt = nullptr;
+static const double* g_th_pstay_chunks = nullptr;
+extern "C" void xt_emul_th_set_dt(const double* dt, const double* p_stay_chunks)
+{
+    g_th_dt = dt;
+    g_th_pstay_chunks = p_stay_chunks;
+}
+
+// blobs of all chunks, one after the other (p_stay differs per chunk); returns the stride in doubles
+static int64_t th_chunk_blobs(const XtModelHost& m, int nchunks, int G, std::vector<double>& blobs)
+{
+    int64_t stride = 0;
+    for (int c = 0; c < nchunks; ++c) {
+        XtModelHost mc = m;
+        mc.p_stay = g_th_pstay_chunks + (size_t)c * G;
+        std::vector<double> b;
+        int G2 = 0;
+        xt_th_build_blob(mc, b, G2);
+        if (c == 0) {
+            stride = (int64_t)b.size();
+            blobs.assign((size_t)stride * nchunks, 0.0);
+        }
+        memcpy(blobs.data() + (size_t)c * stride, b.data(), b.size() * sizeof(double));
+    }
+    return stride;
+}
+
 extern "C" int xt_emul_th_run(const double* tracks, const double* sigma, long long N, int L, int D, int KS, int S, int NS, int F, int isBL,
                               int min_len, int locerr_mode, int locerr_dims, const double* locerr, double slope, double offset, double pBL,
                               const double* ds, const double* Fs, const double* TrMat, const double* p_stay, double threshold, int max_nb,
@@ -370,6 +398,13 @@ extern "C" int xt_emul_th_run(const double* tracks, const double* sigma, long lo
     a.max_nb = max_nb;
     a.threshold = threshold;
     a.ll_const = -(double)(L - 1) * D * 0.5 * XT_LOG2PI;
+    std::vector<double> chunk_blobs;
+    if (g_th_dt) {
+        a.dt = g_th_dt;
+        a.blob_stride = th_chunk_blobs(m, a.nchunks, G, chunk_blobs);
+        a.blob = chunk_blobs.data();
+        g_th_dt = nullptr;
+    }
     std::vector<uint16_t> mem((size_t)a.nchunks * L * capE, 0), gst((size_t)a.nchunks * L * (capE + 1), 0);
     std::vector<uint32_t> mpack((size_t)a.nchunks * L * capE, 0);
     std::vector<uint8_t> gnew((size_t)a.nchunks * L * capE, 0);
@@ -433,10 +468,10 @@ extern "C" int xt_emul_th_run(const double* tracks, const double* sigma, long lo
     const bool uni = TT == 64;
     const bool single_buf = getenv("XT_EMUL_TH_SINGLE") && (uni ? (apply_threads / 64) : (apply_threads / TT)) * XT_TH_GPW >= maxG;
     const size_t apply_lds = xt_th_apply_lds_doubles(S, G, maxG, TT, D, K, a.locerr_mode ? a.KS : 0, L, a.plan_cap, uni, single_buf);
-#define TH_APPLY_SGL(DD, KK) th_emul_blocks(grid, apply_threads, apply_lds, [&](HostCtx& cx) { xt_th_apply_body<DD, KK, true, true>(a, cx); })
-#define TH_APPLY_UNI(DD, KK) th_emul_blocks(grid, apply_threads, apply_lds, [&](HostCtx& cx) { xt_th_apply_body<DD, KK, true, false>(a, cx); })
-#define TH_APPLY_GEN(DD, KK) th_emul_blocks(grid, apply_threads, apply_lds, [&](HostCtx& cx) { xt_th_apply_body<DD, KK, false, false>(a, cx); })
-#define TH_APPLY_GSG(DD, KK) th_emul_blocks(grid, apply_threads, apply_lds, [&](HostCtx& cx) { xt_th_apply_body<DD, KK, false, true>(a, cx); })
+#define TH_APPLY_SGL(DD, KK) th_emul_blocks(grid, apply_threads, apply_lds, [&](HostCtx& cx) { (a.dt ? xt_th_apply_body<DD, KK, true, true, true>(a, cx) : xt_th_apply_body<DD, KK, true, true, false>(a, cx)); })
+#define TH_APPLY_UNI(DD, KK) th_emul_blocks(grid, apply_threads, apply_lds, [&](HostCtx& cx) { (a.dt ? xt_th_apply_body<DD, KK, true, false, true>(a, cx) : xt_th_apply_body<DD, KK, true, false, false>(a, cx)); })
+#define TH_APPLY_GEN(DD, KK) th_emul_blocks(grid, apply_threads, apply_lds, [&](HostCtx& cx) { (a.dt ? xt_th_apply_body<DD, KK, false, false, true>(a, cx) : xt_th_apply_body<DD, KK, false, false, false>(a, cx)); })
+#define TH_APPLY_GSG(DD, KK) th_emul_blocks(grid, apply_threads, apply_lds, [&](HostCtx& cx) { (a.dt ? xt_th_apply_body<DD, KK, false, true, true>(a, cx) : xt_th_apply_body<DD, KK, false, true, false>(a, cx)); })
 #define TH_APPLY(DD, KK)                            \
     do {                                            \
         if (single_buf && uni) TH_APPLY_SGL(DD, KK); \
@@ -458,13 +493,12 @@ extern "C" int xt_emul_th_run(const double* tracks, const double* sigma, long lo
 }
 
 
-// ---- threshold-fusion posteriors: the plan body in prediction mode (every track of a chunk of <= 30 tracks is a pilot).
+// ---- threshold-fusion posteriors: the plan body in prediction mode (the first <= 30 tracks of a chunk are the pilots).
 extern "C" int xt_emul_th_predict(const double* tracks, const double* sigma, long long N, int L, int D, int KS, int S, int F, int isBL,
                                   int min_len, int locerr_mode, int locerr_dims, const double* locerr, double slope, double offset, double pBL,
                                   const double* ds, const double* Fs, const double* TrMat, const double* p_stay, double threshold, int max_nb,
                                   int chunk, int capE, int threads, int nblocks, double* preds_out, int* status_out)
 {
-    if (chunk > XT_TH_PILOT) return -6;
     XtModelHost m{S, 1, locerr_dims, {0, 0, 0}, slope, offset, pBL, ds, Fs, TrMat, p_stay};
     for (int k = 0; k < 3; ++k) m.locerr[k] = locerr ? locerr[k < locerr_dims ? k : 0] : 0.0;
     std::vector<double> blob;
@@ -492,10 +526,17 @@ extern "C" int xt_emul_th_predict(const double* tracks, const double* sigma, lon
     a.capE = capE;
     a.max_nb = max_nb;
     a.threshold = threshold;
-    a.pcap = chunk;
+    a.pcap = chunk < XT_TH_PILOT ? chunk : XT_TH_PILOT;
     a.pair_lanes_max_p = 4;
     a.wsP = a.wsE = capE;
     a.ws_lds = 0;
+    std::vector<double> chunk_blobs;
+    if (g_th_dt) {
+        a.dt = g_th_dt;
+        a.blob_stride = th_chunk_blobs(m, a.nchunks, G, chunk_blobs);
+        a.blob = chunk_blobs.data();
+        g_th_dt = nullptr;
+    }
     std::vector<int32_t> status((size_t)a.nchunks * 4, 0);
     a.status = status.data();
     const int blocks = nblocks < a.nchunks ? nblocks : a.nchunks;
@@ -572,7 +613,7 @@ extern "C" int xt_emul_th_run_multi(int nbuckets, const double** tracks, const l
         gnw[i].assign(nch * Ls[i] * capE, 0);
         gst[i].assign(nch * Ls[i] * (capE + 1), 0);
         hdr[i].assign(nch * Ls[i] * 2, 0);
-        desc[i] = XtThBucket{tracks[i], nullptr, ll_out ? ll_out[i] : nullptr, nullptr, Ns[i], Ls[i], Ls[i] != max_len ? 1 : 0,
+        desc[i] = XtThBucket{tracks[i], nullptr, nullptr, ll_out ? ll_out[i] : nullptr, nullptr, Ns[i], Ls[i], Ls[i] != max_len ? 1 : 0,
                              -(double)(Ls[i] - 1) * D * 0.5 * XT_LOG2PI, mem[i].data(), mpk[i].data(), gst[i].data(), gnw[i].data(),
                              hdr[i].data(), status.data() + (size_t)(i ? cend[i - 1] : 0) * 4};
     }
@@ -606,11 +647,11 @@ extern "C" int xt_emul_th_run_multi(int nbuckets, const double** tracks, const l
     const bool uni = TT == 64;
     const size_t lds = xt_th_apply_lds_doubles(S, G, maxG, TT, D, K, 0, Lmax, a.plan_cap, uni, false);
     if (D == 2 && K == 1) {
-        if (uni) th_emul_blocks(grid, threads, lds, [&](HostCtx& cx) { xt_th_apply_body<2, 1, true, false>(a, cx); });
-        else th_emul_blocks(grid, threads, lds, [&](HostCtx& cx) { xt_th_apply_body<2, 1, false, false>(a, cx); });
+        if (uni) th_emul_blocks(grid, threads, lds, [&](HostCtx& cx) { xt_th_apply_body<2, 1, true, false, false>(a, cx); });
+        else th_emul_blocks(grid, threads, lds, [&](HostCtx& cx) { xt_th_apply_body<2, 1, false, false, false>(a, cx); });
     } else {
-        if (uni) th_emul_blocks(grid, threads, lds, [&](HostCtx& cx) { xt_th_apply_body<3, 1, true, false>(a, cx); });
-        else th_emul_blocks(grid, threads, lds, [&](HostCtx& cx) { xt_th_apply_body<3, 1, false, false>(a, cx); });
+        if (uni) th_emul_blocks(grid, threads, lds, [&](HostCtx& cx) { xt_th_apply_body<3, 1, true, false, false>(a, cx); });
+        else th_emul_blocks(grid, threads, lds, [&](HostCtx& cx) { xt_th_apply_body<3, 1, false, false, false>(a, cx); });
     }
     double sacc = 0.0;
     for (double p : partials) sacc += p;

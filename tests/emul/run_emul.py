@@ -232,3 +232,8 @@ def run_hist(Cs, LE, ds, Fs, T, pBL, isBL, p_stay, min_l, max_nb_states, nblocks
     if rc != 0:
         raise RuntimeError("emul hist rc=%d" % rc)
     return out
+
+
+def set_th_dt(dt, p_stay_chunks):
+    """Per-track time steps for the NEXT run_th / run_th_predict call: dt [N, L], one p_stay table [G] per chunk (keep both alive)."""
+    lib().xt_emul_th_set_dt(dp(dt), dp(p_stay_chunks))

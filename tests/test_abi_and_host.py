@@ -136,8 +136,12 @@ def test_predict_bs_type_error_and_sorting():
         T.predict_Bs(tr, 0.02, {"D0": 0.1})
     with pytest.raises(ValueError):
         T.param_fitting({"5": np.zeros((0, 5, 2))}, 0.02)
-    with pytest.raises(NotImplementedError):
-        T.extract_params(_mk(dict(D0=0, D1=1, F0=.5, F1=.5, p01=.1, p10=.1, pBL=.1, LocErr=.02)), [np.ones((1, 1))], 2, 1)
+    # per-track time steps: dt as a list of arrays [n, len] (bucket order) gives one ds array [n, len, S] per bucket (tracking.py:979-982)
+    dts = [np.full((2, 3), 0.02), np.array([[0.01, 0.02, 0.03, 0.04]])]
+    _, ds, _, _, _ = T.extract_params(_mk(dict(D0=0, D1=1, F0=.5, F1=.5, p01=.1, p10=.1, pBL=.1, LocErr=.02)), dts, 2, 1)
+    assert [d.shape for d in ds] == [(2, 3, 2), (1, 4, 2)] and np.allclose(ds[1][0, :, 1], np.sqrt(2 * np.array([0.01, 0.02, 0.03, 0.04])))
+    with pytest.raises(TypeError):
+        T.extract_params(_mk(dict(D0=0, D1=1, F0=.5, F1=.5, p01=.1, p10=.1, pBL=.1, LocErr=.02)), {"3": dts[0]}, 2, 1)
 
 
 def test_invalid_parameters_short_circuit_to_inf(capsys):
@@ -146,6 +150,7 @@ def test_invalid_parameters_short_circuit_to_inf(capsys):
 
     class FakeTS:
         has_sigma = False
+        has_dt = False
     bad = _mk(dict(D0=0.25, D1=1e-3, LocErr=0.02, F0=0.6, F1=0.4, p01=0.1, p10=0.1, pBL=0.1))
     assert T._objective_model(bad, FakeTS(), 0.02, [1], None, 2, 1, 6, 1) is None
     neg = _mk(dict(D0=1e-3, D1=0.25, LocErr=0.02, F0=1.2, F1=-0.2, p01=0.1, p10=0.1, pBL=0.1))

@@ -97,6 +97,27 @@ def test_th_posteriors_body_on_golden_subset():
     assert len(rows) >= 8 and worst < 1e-9, (len(rows), worst)
 
 
+def test_th_posteriors_body_chunks_beyond_the_pilots():
+    """Reference fixtures with 40 / 60 tracks per chunk (predict_Bs with nb_max > 30): the first 30 tracks decide the merges, the
+    others replay the plan with their own merge weights (tracking.py:676-691, 703-741)."""
+    E = _emul()
+    meta = json.load(open(os.path.join(GOLDEN, "th_kernel_cases.json")))
+    data = np.load(os.path.join(GOLDEN, "th_kernel_cases.npz"))
+    rows = [r for r in meta if r["do_preds"] and r["N"] > 30][::6]
+    worst = 0.0
+    for row in rows:
+        pre = "t%04d_" % row["id"]
+        Cs, LE, ds, Fs, T = [data[pre + k] for k in ("Cs", "LE", "ds", "Fs", "T")]
+        ps = p_stay_table(ds, len(ds), 1, row["cell_dims"])
+        pr = E.run_th_predict(Cs, LE, ds, Fs, T, row["pBL"], row["isBL"], ps, row["F"], row["min_len"], row["threshold"], row["max_nb_states"],
+                              chunk=len(Cs), capE=256, threads=64, nblocks=2)
+        d = np.abs(pr - data[pre + "preds"]).max()
+        assert d < 1e-9, (row, d)
+        worst = max(worst, d)
+    assert len(rows) >= 12
+    print("chunks beyond the pilots:", len(rows), "worst", worst)
+
+
 @pytest.mark.parametrize("TT,threads", [(8, 128), (64, 256)])
 def test_th_multi_bucket_launch(TT, threads):
     """Three buckets of different lengths (one with a single ragged chunk, one shorter than the merge horizon) served by ONE plan
@@ -135,3 +156,34 @@ def test_th_bodies_on_extra_golden_subset():
                                               row["threshold"], row["max_nb_states"], chunk=len(Cs), capE=1024, TT=8, threads=64, nblocks=2)
         worst = max(worst, np.abs(ll - data[pre + "LPC"]).max())
     assert len(rows) >= 6 and worst < 1e-10, (len(rows), worst)
+
+
+def test_th_bodies_with_per_track_time_steps():
+    """Reference fixtures with dt per track and position (3-D ds): plan + apply (LL) and the prediction mode, incl. chunks beyond the
+    30 pilot tracks; the diffusion term of step t is scaled by dt[track, len - t], every chunk has its own field-of-view table."""
+    E = _emul()
+    info = json.load(open(os.path.join(GOLDEN, "th_dt_cases.json")))
+    data = np.load(os.path.join(GOLDEN, "th_dt_cases.npz"))
+    rows = [r for r in info["cases"] if r["id"] % 7 == 0 or (r["N"] == 45 and r["id"] % 3 == 0)]
+    worst_ll = worst_pr = 0.0
+    nll = npr = 0
+    for row in rows:
+        pre = "d%04d_" % row["id"]
+        g = lambda k: data[pre + k]
+        Cs, LE, dt, Ds, Fs, T = [np.ascontiguousarray(g(k)) for k in ("Cs", "LE", "dt", "Ds", "Fs", "T")]
+        S = len(Ds)
+        ds_unit = np.sqrt(2 * Ds)
+        ps = np.ascontiguousarray(p_stay_table(np.median(np.sqrt(2 * Ds[None] * dt[:, 0, None]), axis=0), S, row["ns"], row["cell_dims"])[None])
+        E.set_th_dt(dt, ps)
+        if row["do_preds"]:
+            pr = E.run_th_predict(Cs, LE, ds_unit, Fs, T, row["pBL"], row["isBL"], ps[0], row["F"], row["min_len"], row["threshold"],
+                                  row["max_nb_states"], chunk=len(Cs), capE=256, threads=64, nblocks=1)
+            worst_pr = max(worst_pr, np.abs(pr - g("preds")).max())
+            npr += 1
+        else:
+            ll, tot, plan, hdr, status = E.run_th(Cs, LE, ds_unit, Fs, T, row["pBL"], row["isBL"], ps[0], row["ns"], row["F"], row["min_len"],
+                                                  row["threshold"], row["max_nb_states"], chunk=len(Cs), capE=256, TT=8, threads=64, nblocks=1)
+            worst_ll = max(worst_ll, np.abs(ll - g("LPC")).max())
+            nll += 1
+    assert nll >= 10 and npr >= 10 and worst_ll < 1e-10 and worst_pr < 1e-9, (nll, npr, worst_ll, worst_pr)
+    print("dt cases: LL", nll, worst_ll, "posteriors", npr, worst_pr)
