@@ -16,7 +16,7 @@ EXPORTS = [
     "extrack_upload_bucket", "extrack_attach_bucket", "extrack_set_bucket_dt", "extrack_clear_buckets", "extrack_bucket_count",
     "extrack_loglik", "extrack_loglik_async", "extrack_predict", "extrack_last_kernel_ms",
     "extrack_last_launch_info", "extrack_p_stay_table", "extrack_loglik_th", "extrack_loglik_th_async", "extrack_th_plan_step",
-    "extrack_predict_th", "extrack_loglik_grad", "extrack_last_grad_ms", "extrack_segment_len_hist",
+    "extrack_predict_th", "extrack_loglik_grad", "extrack_last_grad_ms", "extrack_segment_len_hist", "extrack_refine_positions",
 ]
 
 _dp = C.POINTER(C.c_double)
@@ -104,6 +104,7 @@ def load():
     lib.extrack_th_plan_step.argtypes = [vp, i32, i64, i32, C.POINTER(i32), C.POINTER(i32), vp, vp, i32]
     lib.extrack_loglik_grad.argtypes = [vp, C.POINTER(ExtrackModel), i32, C.POINTER(ExtrackModelTangent), _dp, vp]
     lib.extrack_segment_len_hist.argtypes = [vp, C.POINTER(ExtrackModel), i32, i32, vp]
+    lib.extrack_refine_positions.argtypes = [vp, C.POINTER(ExtrackModel), i32, C.c_double, i32, vp, vp]
     lib.extrack_last_grad_ms.argtypes = [vp, C.POINTER(C.c_float)]
     if lib.extrack_abi_version() != 3:
         raise ImportError("libextrack_hip.so ABI version mismatch")
@@ -261,6 +262,14 @@ class Context:
         out = np.zeros((L - 1, model.c.n_states))
         self._check(self._lib.extrack_segment_len_hist(self._h, C.byref(model.c), int(bucket_id), int(max_nb_states), out.ctypes.data_as(C.c_void_p)))
         return out
+
+    def refine_positions(self, model, bucket_id, threshold=0.1, max_nb_states=1000):
+        """Refined positions [n, len, dims] and their stds [n, len] of one bucket (extrack/refined_localization.py:304-338 semantics)."""
+        N, L, D, KS = self.buckets[bucket_id]
+        mu, sg = np.zeros((N, L, D)), np.zeros((N, L))
+        self._check(self._lib.extrack_refine_positions(self._h, C.byref(model.c), int(bucket_id), C.c_double(threshold), int(max_nb_states),
+                                                       mu.ctypes.data_as(C.c_void_p), sg.ctypes.data_as(C.c_void_p)))
+        return mu, sg
 
     def last_grad_ms(self):
         ms = C.c_float(0)

@@ -1350,6 +1350,303 @@ extern "C" int extrack_predict_th(extrack_ctx* ctx, const extrack_model* m, int3
     return rc;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// position refinement (extrack/refined_localization.py:207-338): two recording passes of the prediction-mode plan kernel
+// (xt_th.h, refine mode) + the combination of the "future" and "past" predictions of every position
+// ------------------------------------------------------------------------------------------------
+struct XtRefineArgs {
+    const double* tracks;  // [N][L][D] original time order
+    const double* fut;     // records of the pass over the time-reversed track: entry e = state after positions L-1 .. L-1-e
+    const double* past;    // records of the pass over the track as it is:      entry e = state after positions 0 .. e
+    const uint8_t* fut_new;
+    const uint8_t* past_new;
+    const int32_t* fut_cnt;
+    const int32_t* past_cnt;
+    double* mu_out;        // [N][L][D]
+    double* sig_out;       // [N][L]
+    int64_t N;
+    int32_t L, S, cap_f, cap_p;  // sequences recorded per (entry, track) by the two passes
+    double l2;             // squared localisation error
+    double logF[XT_MAX_STATES];
+};
+
+// One thread per (track, position): softmax-weighted mean of the pair means / root mean of the pair variances
+// (refined_localization.py:222-298 get_pos_PDF + :329-337).  Two sweeps over the pairs: maximum of the log-weights, then the sums.
+template <int D>
+__global__ void __launch_bounds__(256) xt_refine_combine(XtRefineArgs a)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.N * a.L) return;
+    const int64_t x = i / a.L;
+    const int k = (int)(i - x * a.L);
+    const int L = a.L, R = 2 + D;
+    double c[D];
+    for (int d = 0; d < D; ++d) c[d] = a.tracks[(x * L + k) * D + d];
+    double wmax = -INFINITY, sw = 0.0, smu[D], ssg = 0.0;
+    for (int d = 0; d < D; ++d) smu[d] = 0.0;
+    for (int sweep = 0; sweep < 2; ++sweep) {
+        if (k == 0 || k == L - 1) {
+            // end positions: one pass only; the reference's last record already carries the density of this position (and the
+            // initial fractions for position 0) through its in-place update (refined_localization.py:188-193), and get_pos_PDF adds the
+            // overlap term once more
+            const int cap = k == 0 ? a.cap_f : a.cap_p;
+            const double* rec = (k == 0 ? a.fut : a.past) + (((int64_t)(L - 2) * a.N + x) * cap) * R;
+            const uint8_t* nw = (k == 0 ? a.fut_new : a.past_new) + (int64_t)(L - 2) * cap;
+            const int n = (k == 0 ? a.fut_cnt : a.past_cnt)[L - 2];
+            for (int q = 0; q < n; ++q) {
+                const double lp = rec[q * R], sd = rec[q * R + 1 + D], v = sd * sd + a.l2;
+                double dsq = 0.0;
+                for (int d = 0; d < D; ++d) dsq += (c[d] - rec[q * R + 1 + d]) * (c[d] - rec[q * R + 1 + d]);
+                const double lk = -0.5 * D * log(2.0 * M_PI * v) - dsq / (2.0 * v);
+                const double w = lp + 2.0 * lk + (k == 0 ? a.logF[nw[q]] : 0.0);
+                if (sweep == 0) {
+                    wmax = w > wmax ? w : wmax;
+                } else {
+                    const double p = exp(w - wmax);
+                    sw += p;
+                    for (int d = 0; d < D; ++d) smu[d] += p * (rec[q * R + 1 + d] * a.l2 + c[d] * sd * sd) / v;
+                    ssg += p * (a.l2 * sd * sd / v);
+                }
+            }
+        } else {
+            const double* rf = a.fut + (((int64_t)(L - 2 - k) * a.N + x) * a.cap_f) * R;
+            const double* rp = a.past + (((int64_t)(k - 1) * a.N + x) * a.cap_p) * R;
+            const uint8_t* nf = a.fut_new + (int64_t)(L - 2 - k) * a.cap_f;
+            const uint8_t* np_ = a.past_new + (int64_t)(k - 1) * a.cap_p;
+            const int n1 = a.fut_cnt[L - 2 - k], n2 = a.past_cnt[k - 1];
+            for (int q1 = 0; q1 < n1; ++q1) {
+                const double lp1 = rf[q1 * R], s1 = rf[q1 * R + 1 + D];
+                const double v12 = s1 * s1 + a.l2, vA = s1 * s1 * a.l2 / v12;
+                double muA[D], d1 = 0.0;
+                for (int d = 0; d < D; ++d) {
+                    const double m1 = rf[q1 * R + 1 + d];
+                    muA[d] = (m1 * a.l2 + c[d] * s1 * s1) / v12;
+                    d1 += (m1 - c[d]) * (m1 - c[d]);
+                }
+                const double lk1 = -0.5 * D * log(2.0 * M_PI * v12) - d1 / (2.0 * v12);
+                for (int q2 = 0; q2 < n2; ++q2) {
+                    if (np_[q2] != nf[q1]) continue;  // pairs that agree on the state at this position
+                    const double s3 = rp[q2 * R + 1 + D], v3 = vA + s3 * s3;
+                    double d2 = 0.0;
+                    for (int d = 0; d < D; ++d) d2 += (muA[d] - rp[q2 * R + 1 + d]) * (muA[d] - rp[q2 * R + 1 + d]);
+                    const double w = lp1 + rp[q2 * R] + lk1 - 0.5 * D * log(2.0 * M_PI * v3) - d2 / (2.0 * v3);
+                    if (sweep == 0) {
+                        wmax = w > wmax ? w : wmax;
+                    } else {
+                        const double p = exp(w - wmax);
+                        sw += p;
+                        for (int d = 0; d < D; ++d) smu[d] += p * (muA[d] * s3 * s3 + rp[q2 * R + 1 + d] * vA) / v3;
+                        ssg += p * (vA * s3 * s3 / v3);
+                    }
+                }
+            }
+        }
+    }
+    for (int d = 0; d < D; ++d) a.mu_out[(x * L + k) * D + d] = smu[d] / sw;
+    a.sig_out[x * L + k] = sqrt(ssg / sw);
+}
+
+// One recording pass over bucket `d_tracks` ([N][L][D] on the device): capacity probe on the pilot tracks, then the full launch.
+static int xt_refine_pass(extrack_ctx* ctx, const extrack_model* m, const double* d_tracks, int64_t N, int L, int D, double threshold,
+                          int32_t max_nb_states, double** d_rec, uint8_t** d_new, int32_t** d_cnt, int* cap_out)
+{
+    const int S = m->n_states, F = m->frame_len, G = S;
+    XtThArgs a;
+    memset(&a, 0, sizeof(a));
+    a.tracks = d_tracks;
+    a.blob = ctx->d_blob;
+    a.L = L;
+    a.S = S;
+    a.NS = 1;
+    a.G = G;
+    a.F = F;
+    a.isBL = 0;
+    a.min_len = L + 2;  // no field-of-view / bleaching factors in the recorded weights
+    a.locerr_mode = 0;
+    a.KS = 1;
+    a.max_nb = max_nb_states;
+    a.threshold = threshold;
+    a.pcap = (int)std::min<int64_t>(N, XT_TH_PILOT);
+    a.pair_lanes_max_p = ctx->th_pair_lanes;
+    a.refine = 1;
+    int32_t* d_status = nullptr;
+    XT_HIP(ctx, hipMalloc(&d_status, 4 * sizeof(int32_t)));
+    a.status = d_status;
+    int rc = EXTRACK_OK, maxE = 0;
+    hipError_t e = hipSuccess;
+    for (int stage = 0; stage < 2 && rc == EXTRACK_OK; ++stage) {
+        // stage 0: pilots only, nothing recorded -> sequence counts; stage 1: everything
+        for (;;) {
+            int capE = ctx->th_capE;
+            while (capE < S * G) capE *= 2;
+            ctx->th_capE = capE;
+            a.capE = a.wsP = a.wsE = capE;
+            a.ws_lds = 0;
+            a.N = stage == 0 ? std::min<int64_t>(N, XT_TH_PILOT) : N;
+            a.chunk = (int32_t)std::min<int64_t>(a.N, (int64_t)1 << 30);
+            a.nchunks = 1;
+            a.cmat_words = 0;
+            const int64_t nbatch = a.N > a.pcap ? (a.N - a.pcap + a.pcap - 1) / a.pcap : 0;
+            const int grid = stage == 0 ? 1 : (int)std::max<int64_t>(1, std::min<int64_t>(nbatch, (int64_t)ctx->n_cu * 4));
+            const size_t lds = (size_t)xt_th_plan_lds_doubles(S, G, capE, D, 1) * sizeof(double);
+            a.ws_stride = xt_th_hist_doubles(a.wsE, a.pcap, true, L) + xt_th_ws_doubles(a.wsP, a.wsE, D, 1, F, 1, S, a.pcap, true);
+            const size_t need = (size_t)a.ws_stride * grid * sizeof(double);
+            if (need > ctx->th_ws_cap) {
+                (void)hipStreamSynchronize(ctx->stream);
+                if (ctx->d_th_ws) (void)hipFree(ctx->d_th_ws);
+                ctx->d_th_ws = nullptr;
+                ctx->th_ws_cap = 0;
+                if ((e = hipMalloc(&ctx->d_th_ws, need)) != hipSuccess) {
+                    rc = xt_fail(ctx, EXTRACK_E_HIP, std::string("refinement workspace: ") + hipGetErrorString(e));
+                    break;
+                }
+                ctx->th_ws_cap = need;
+            }
+            a.ws = ctx->d_th_ws;
+            if (lds > 160 * 1024) {
+                rc = xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "plan tables do not fit the 160 KiB LDS of a CU");
+                break;
+            }
+            if (D == 1) e = xt_th_launch_predict<1, 1>(ctx, a, grid, 256, lds);
+            else if (D == 2) e = xt_th_launch_predict<2, 1>(ctx, a, grid, 256, lds);
+            else e = xt_th_launch_predict<3, 1>(ctx, a, grid, 256, lds);
+            int32_t st[4] = {0, 0, 0, 0};
+            if (e == hipSuccess) e = hipMemcpyAsync(st, d_status, sizeof(st), hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            if (e != hipSuccess) {
+                rc = xt_fail(ctx, EXTRACK_E_HIP, std::string("refinement pass: ") + hipGetErrorString(e));
+                break;
+            }
+            if (st[0]) {  // capacity overflow: grow and repeat
+                int ncap = capE;
+                while (ncap < std::max(st[1], st[2])) ncap *= 2;
+                if (ncap == capE) ncap *= 2;
+                if (ncap > XT_TH_MAXCAP) {
+                    rc = xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "more than 8192 live state sequences per step: raise threshold or lower max_nb_states");
+                    break;
+                }
+                ctx->th_capE = ncap;
+                continue;
+            }
+            maxE = std::max(st[1], st[2]);
+            break;
+        }
+        if (rc != EXTRACK_OK) break;
+        if (stage == 0) {
+            a.rf_cap = std::max(maxE, S * G);
+            const size_t nrec = (size_t)(L - 1) * (size_t)N * a.rf_cap * (2 + D);
+            if ((e = hipMalloc(d_rec, nrec * sizeof(double))) != hipSuccess || (e = hipMalloc(d_new, (size_t)(L - 1) * a.rf_cap)) != hipSuccess ||
+                (e = hipMalloc(d_cnt, (size_t)(L - 1) * sizeof(int32_t))) != hipSuccess) {
+                rc = xt_fail(ctx, EXTRACK_E_HIP, std::string("refinement records: ") + hipGetErrorString(e));
+                break;
+            }
+            a.rf_out = *d_rec;
+            a.rf_new = *d_new;
+            a.rf_cnt = *d_cnt;
+        }
+    }
+    (void)hipFree(d_status);
+    *cap_out = a.rf_cap;
+    return rc;
+}
+
+extern "C" int extrack_refine_positions(extrack_ctx* ctx, const extrack_model* m, int32_t bucket_id, double threshold, int32_t max_nb_states,
+                                        double* mu, double* sigma)
+{
+    if (!ctx || !mu || !sigma) return xt_fail(ctx, EXTRACK_E_INVALID, "null argument");
+    int rc = xt_validate_model(ctx, m);
+    if (rc) return rc;
+    if (bucket_id < 0 || bucket_id >= (int)ctx->buckets.size()) return xt_fail(ctx, EXTRACK_E_INVALID, "bucket id out of range");
+    if (m->nb_substeps != 1) return xt_fail(ctx, EXTRACK_E_INVALID, "position refinement is defined for nb_substeps == 1");
+    if (m->locerr_mode != 0 || m->locerr_dims != 1)
+        return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "position refinement is built for one global localisation error (as the reference's reshapes assume)");
+    if (!(threshold >= 0.0)) return xt_fail(ctx, EXTRACK_E_INVALID, "threshold must be >= 0");
+    if (m->frame_len <= 1 || m->frame_len > 15) return xt_fail(ctx, EXTRACK_E_INVALID, "frame_len must be in (1, 15]");
+    XtBucket& b = ctx->buckets[bucket_id];
+    const int S = m->n_states, L = b.L, D = b.D;
+    if (L < 3) return xt_fail(ctx, EXTRACK_E_INVALID, "position refinement needs tracks of at least 3 positions");
+    XT_HIP(ctx, hipSetDevice(ctx->device));
+    // time-reversed copy of the bucket for the pass "from the future" (made on the host: the tracks are small next to the records)
+    const size_t nel = (size_t)b.N * L * D;
+    std::vector<double> h((size_t)nel), hr((size_t)nel);
+    XT_HIP(ctx, hipMemcpy(h.data(), b.d_tracks, nel * sizeof(double), hipMemcpyDeviceToHost));
+    for (int64_t x = 0; x < b.N; ++x)
+        for (int p = 0; p < L; ++p)
+            for (int d = 0; d < D; ++d) hr[((size_t)x * L + p) * D + d] = h[((size_t)x * L + (L - 1 - p)) * D + d];
+    double* d_rev = nullptr;
+    XT_HIP(ctx, hipMalloc(&d_rev, nel * sizeof(double)));
+    double *d_fut = nullptr, *d_past = nullptr;
+    uint8_t *d_fnew = nullptr, *d_pnew = nullptr;
+    int32_t *d_fcnt = nullptr, *d_pcnt = nullptr;
+    double *d_mu = nullptr, *d_sig = nullptr;
+    hipError_t e = hipMemcpy(d_rev, hr.data(), nel * sizeof(double), hipMemcpyHostToDevice);
+    if (e != hipSuccess) rc = xt_fail(ctx, EXTRACK_E_HIP, std::string("refinement: ") + hipGetErrorString(e));
+    int capF = 0, capP = 0;
+    std::vector<double> ones(S, 1.0), Tt((size_t)S * S);
+    for (int i = 0; i < S; ++i)
+        for (int j = 0; j < S; ++j) Tt[(size_t)i * S + j] = m->TrMat[(size_t)j * S + i];
+    for (int pass = 0; pass < 2 && rc == EXTRACK_OK; ++pass) {
+        // pass 0: from the future (reversed track, the matrix as given, refined_localization.py:211); pass 1: from the past (track as it
+        // is, transposed matrix, :213-216).  No initial fractions in the recorded weights (:93).
+        XtModelHost mh;
+        xt_model_host(m, mh);
+        mh.Fs = ones.data();
+        mh.TrMat = pass == 0 ? m->TrMat : Tt.data();
+        std::vector<double> blob;
+        int G = 0;
+        std::string err = xt_th_build_blob(mh, blob, G);
+        if (!err.empty()) {
+            rc = xt_fail(ctx, EXTRACK_E_INVALID, err);
+            break;
+        }
+        if ((rc = xt_upload_blob(ctx, blob))) break;
+        rc = pass == 0 ? xt_refine_pass(ctx, m, d_rev, b.N, L, D, threshold, max_nb_states, &d_fut, &d_fnew, &d_fcnt, &capF)
+                       : xt_refine_pass(ctx, m, b.d_tracks, b.N, L, D, threshold, max_nb_states, &d_past, &d_pnew, &d_pcnt, &capP);
+    }
+    if (rc == EXTRACK_OK) {
+        if ((e = hipMalloc(&d_mu, nel * sizeof(double))) != hipSuccess || (e = hipMalloc(&d_sig, (size_t)b.N * L * sizeof(double))) != hipSuccess)
+            rc = xt_fail(ctx, EXTRACK_E_HIP, std::string("refinement output: ") + hipGetErrorString(e));
+    }
+    if (rc == EXTRACK_OK) {
+        XtRefineArgs ra;
+        memset(&ra, 0, sizeof(ra));
+        ra.tracks = b.d_tracks;
+        ra.fut = d_fut;
+        ra.past = d_past;
+        ra.fut_new = d_fnew;
+        ra.past_new = d_pnew;
+        ra.fut_cnt = d_fcnt;
+        ra.past_cnt = d_pcnt;
+        ra.mu_out = d_mu;
+        ra.sig_out = d_sig;
+        ra.N = b.N;
+        ra.L = L;
+        ra.S = S;
+        ra.cap_f = capF;
+        ra.cap_p = capP;
+        ra.l2 = m->locerr[0] * m->locerr[0];
+        for (int s2 = 0; s2 < S; ++s2) ra.logF[s2] = log(m->Fs[s2]);
+        {
+            const int grid = (int)(((int64_t)b.N * L + 255) / 256);
+            XT_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+            if (D == 1) hipLaunchKernelGGL(xt_refine_combine<1>, dim3(grid), dim3(256), 0, ctx->stream, ra);
+            else if (D == 2) hipLaunchKernelGGL(xt_refine_combine<2>, dim3(grid), dim3(256), 0, ctx->stream, ra);
+            else hipLaunchKernelGGL(xt_refine_combine<3>, dim3(grid), dim3(256), 0, ctx->stream, ra);
+            e = hipGetLastError();
+            if (e == hipSuccess) e = hipEventRecord(ctx->ev1, ctx->stream);
+            ctx->timed = true;
+            if (e == hipSuccess) e = hipMemcpyAsync(mu, d_mu, nel * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(sigma, d_sig, (size_t)b.N * L * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            if (e != hipSuccess) rc = xt_fail(ctx, EXTRACK_E_HIP, std::string("refinement combine: ") + hipGetErrorString(e));
+        }
+    }
+    for (void* p : {(void*)d_rev, (void*)d_fut, (void*)d_past, (void*)d_fnew, (void*)d_pnew, (void*)d_fcnt, (void*)d_pcnt, (void*)d_mu, (void*)d_sig})
+        if (p) (void)hipFree(p);
+    return rc;
+}
+
 extern "C" int extrack_th_plan_step(extrack_ctx* ctx, int32_t bucket_id, int64_t chunk_index, int32_t t, int32_t* n_expanded,
                                     int32_t* n_groups, uint16_t* members, uint16_t* gstart, int32_t cap)
 {

@@ -125,6 +125,13 @@ struct XtThArgs {
     int32_t capG;          // apply kernel: parent-sequence capacity of the LDS buffers
     int32_t bpc;           // apply kernel: workgroups per chunk (a workgroup serves tiles of ONE chunk)
     int32_t plan_cap;      // apply kernel: members of ALL merged steps kept in LDS (0: the plan is streamed step by step)
+    // Position refinement (extrack/refined_localization.py:48-204 get_LC_Km_Ks): the prediction-mode plan kernel run on ONE chunk
+    // (the whole bucket) records, after every position, each track's surviving sequences instead of reading out posteriors.
+    int32_t refine;        // 1: record mode; every workgroup repeats the pilot pass (same plan) and serves its share of the other tracks
+    int32_t rf_cap;        // sequences recorded per (entry, track)
+    double* rf_out;        // [L - 1][N][rf_cap][2 + D]: log-weight, mean[D], std   (nullptr: nothing is recorded - capacity probe)
+    uint8_t* rf_new;       // [L - 1][rf_cap] newest state of every recorded sequence (shared by the tracks)
+    int32_t* rf_cnt;       // [L - 1] recorded sequences per entry
 };
 
 // Pointer to read-only data that is addressed with wave-uniform indices: on the device it lives in the constant address
@@ -508,7 +515,8 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
     pwS[0] = 1;
     for (int i = 1; i < 8; ++i) pwS[i] = pwS[i - 1] * S;
 
-    for (int gch = cx.block(); gch < a.nchunks; gch += cx.nblocks()) {
+    const bool RF = PREDS && a.refine != 0;
+    for (int gch = RF ? 0 : cx.block(); gch < a.nchunks; gch += RF ? a.nchunks : cx.nblocks()) {
         int ch;  // chunk index inside its bucket
         const XtThBucket bk = xt_th_bind(a, gch, ch);
         const int L = bk.L;
@@ -529,6 +537,13 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
         // len - current_step of the unreversed array)
         auto dtf = [&](int x, int t) -> double { return bk.dt ? bk.dt[(c0 + x) * L + (L - t)] : 1.0; };
 
+        // refinement record of sequence q of entry `ent` (0 .. L-2) of chunk track xg: log-weight (constants dropped), mean, std
+        auto rf_put = [&](int ent, int64_t xg, int q, double zm, int ze, const double* mv, double var0) {
+            double* o = a.rf_out + (((int64_t)ent * bk.N + xg) * a.rf_cap + q) * (2 + D);
+            o[0] = zm > 0.0 ? log(zm) + (double)ze * XT_LN2 : -INFINITY;
+            for (int d = 0; d < D; ++d) o[1 + d] = mv[d];
+            o[1 + D] = sqrt(var0);
+        };
         auto load_l2 = [&](int x, int pos, double* l2) {
             if (a.locerr_mode == 0) {
                 for (int k = 0; k < K; ++k) l2[k] = hdr[k];
@@ -803,6 +818,15 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
                 for (int i = tid; i < P * nG; i += nt) {
                     const int x = i / nG, g2 = i - x * nG;
                     xt_th_gather<D, K>(bA, 1, x * wsP, mpk, (int)gst[g2], (int)gst[g2 + 1], TTl, TD2, bB, x * wsP + g2, dtf(x, t));
+                    if (RF && a.rf_out && cx.block() == 0 && g2 < a.rf_cap) {
+                        double mv[D];
+                        for (int d = 0; d < D; ++d) mv[d] = bB.m(d, x * wsP + g2);
+                        rf_put(t - 1, c0 + x, g2, bB.zm(x * wsP + g2), bB.ze(x * wsP + g2), mv, bB.u(0, x * wsP + g2));
+                    }
+                }
+                if (RF && a.rf_out && cx.block() == 0) {
+                    for (int i = tid; i < nG && i < a.rf_cap; i += nt) a.rf_new[(int64_t)(t - 1) * a.rf_cap + i] = (uint8_t)((int)mem[gst[i]] % S);
+                    if (tid == 0) a.rf_cnt[t - 1] = nG;
                 }
                 // fit mode keeps frame_len history entries (tracking.py:699-701); when predicting the reference keeps all of
                 // them, but only the first frame_len are ever looked at before the final read-out, which is done here by a
@@ -945,6 +969,23 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
             }
         }
         // tracks xb .. xb + cnt - 1 of the chunk sit in slots 0 .. cnt - 1 of the state `vA` (nParF parents)
+        // last entry of the refinement record: the expanded, unfused sequences (parent g, new state r) after the last integration
+        auto rf_last = [&](const int xb, const int cnt, const View& vA, const int nParF, const bool shared) {
+            cx.sync();
+            const int tl = L - 1, nE = nParF * G;
+            for (int i = tid; i < cnt * nE; i += nt) {
+                const int x = i / nE, jj = i - x * nE, g = jj / G, r = jj - g * G, idx = x * wsP + g, o = (int)nwA[g] * G + r;
+                if (jj >= a.rf_cap) continue;
+                double mv[D];
+                for (int d = 0; d < D; ++d) mv[d] = vA.m(d, idx);
+                rf_put(tl - 1, c0 + xb + x, jj, vA.zm(idx) * TAB[o], vA.ze(idx), mv, xt_fma(TD2[o], dtf(xb + x, tl), vA.u(0, idx)));
+            }
+            if (shared) {
+                for (int i = tid; i < nE && i < a.rf_cap; i += nt) a.rf_new[(int64_t)(tl - 1) * a.rf_cap + i] = (uint8_t)(i % G % S);
+                if (tid == 0) a.rf_cnt[tl - 1] = nE;
+            }
+            cx.sync();
+        };
         auto finish = [&](const int xb, const int cnt, const View& vA, const int nParF) {
             // ---- posteriors (tracking.py:611-648): weights of the final sequences (parent g, new state r) at the last
             // position, then the weighted mean of their state histories; history index 0 = last position
@@ -1034,11 +1075,14 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
             cx.sync();
         };
         if (PREDS && !overflow) {
-            finish(0, P, bA, nPar);
+            if (!RF)
+                finish(0, P, bA, nPar);
+            else if (a.rf_out && cx.block() == 0)
+                rf_last(0, P, bA, nPar, true);
             // ---- tracks beyond the pilots (predict_Bs with nb_max > 30, tracking.py:856-868): they take no part in the merge
             // decisions (fuse_tracks_th looks at the first 30 tracks only, tracking.py:676-691) but are merged with THEIR OWN
             // weights (tracking.py:703-741): replay the recorded plan batch by batch in the pilots' slots
-            for (int xb = P; xb < n; xb += PC) {
+            for (int xb = RF ? P + PC * cx.block() : P; xb < n && (!RF || a.rf_out); xb += RF ? PC * cx.nblocks() : PC) {
                 const int cnt = (n - xb) < PC ? (n - xb) : PC;
                 cx.sync();
                 for (int i = tid; i < cnt * S; i += nt) {
@@ -1090,6 +1134,11 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
                             }
                             for (int kk = k0; kk < k1; ++kk)
                                 hw[((int64_t)x * L + t) * wsE + kk] = (k1 - k0 == 1) ? 1.0 : hw[((int64_t)x * L + t) * wsE + kk] / W;
+                            if (RF && g2 < a.rf_cap) {
+                                double mv[D];
+                                for (int d = 0; d < D; ++d) mv[d] = fB.m(d, x * wsP + g2);
+                                rf_put(t - 1, c0 + xb + x, g2, fB.zm(x * wsP + g2), fB.ze(x * wsP + g2), mv, fB.u(0, x * wsP + g2));
+                            }
                         }
                         cx.sync();
                         View tb = fA;
@@ -1098,11 +1147,14 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
                         fPar = nGt;
                     }
                 }
-                finish(xb, cnt, fA, fPar);
+                if (!RF)
+                    finish(xb, cnt, fA, fPar);
+                else
+                    rf_last(xb, cnt, fA, fPar, false);
             }
         }
         XT_TH_PROF_DUMP(PREDS ? "posteriors" : "fit");
-        if (tid == 0) {
+        if (tid == 0 && (!RF || cx.block() == 0)) {
             bk.status[ch * 4 + 0] = overflow;
             bk.status[ch * 4 + 1] = maxE;
             bk.status[ch * 4 + 2] = maxG;

@@ -29,6 +29,8 @@
  *   extrack_segment_len_hist
  *       P_segment_len(...)[2] (extrack/histograms.py:26-286) summed over one bucket: the state-duration histogram that len_hist
  *       (histograms.py:294-373) accumulates over chunks of 50 tracks.
+ *   extrack_refine_positions
+ *       get_pos_PDF + the weighted read-out of position_refinement for one bucket (extrack/refined_localization.py:207-338).
  *   extrack_loglik_grad
  *       extrack_loglik AND its exact gradient in one pass.  It replaces the finite-difference loop that the reference's
  *       optimiser runs around cum_Proba_Cs (lmfit.minimize at extrack/tracking.py:1371: BFGS evaluates the objective
@@ -155,6 +157,17 @@ int extrack_last_grad_ms(extrack_ctx* ctx, float* ms);
  * reference's min_l (smallest track length of the dataset), isBL = (len != model->max_len) as elsewhere.
  * Limits: len * bits_per_state <= 256 (bits = 1 / 2 / 3 for <= 2 / 4 / 8 states), max_nb_states * n_states <= 16384. */
 int extrack_segment_len_hist(extrack_ctx* ctx, const extrack_model* model, int32_t bucket_id, int32_t max_nb_states, double* hist);
+
+/* Refined positions of one bucket (extrack/refined_localization.py:304-338 position_refinement -> get_pos_PDF :207 -> get_LC_Km_Ks :48):
+ * mu host [n][len][dims], sigma host [n][len].  Two passes of the threshold-fusion recursion (merge decisions from the first 30
+ * tracks of the bucket, fuse_tracks_th with per-track histories) - over the time-reversed tracks with model->TrMat and over the tracks
+ * as they are with its transpose - record every position's surviving state sequences (mean, std, log-weight, newest state); for each
+ * position the sequences of both passes that agree on its state are paired and the three Gaussians (prediction from the future,
+ * localisation, prediction from the past) multiplied; mu / sigma are the probability-weighted mean / root mean variance of the pairs.
+ * model: n_states, ds, TrMat, Fs (position 0 only, through a quirk of the reference), locerr[0] (one global error: locerr_mode 0,
+ * locerr_dims 1), frame_len; nb_substeps must be 1; p_stay / pBL / min_len / max_len are not used.  Tracks need >= 3 positions. */
+int extrack_refine_positions(extrack_ctx* ctx, const extrack_model* model, int32_t bucket_id, double threshold, int32_t max_nb_states,
+                             double* mu, double* sigma);
 
 /* Threshold-fusion log-likelihood (the kernel extrack.tracking.param_fitting / cum_Proba_Cs call in v1.6.3,
  * extrack/tracking.py:427-743).  Which state sequences are merged at a step is decided from the first 30 tracks

@@ -1,0 +1,58 @@
+"""GPU tests of the position refinement (extrack_refine_positions) through the C ABI: all 50
+reference-generated buckets (2-3 states, 3-20 positions, 1-45 tracks, 1-3 dims, different frame_len / threshold / max_nb_states) to
+1e-9, a larger bucket against the oracle."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+def test_position_refinement_golden():
+    from extrack_amd import refined_localization as RL
+    meta = json.load(open(os.path.join(GOLDEN, "refine_cases.json")))
+    data = np.load(os.path.join(GOLDEN, "refine_cases.npz"))
+    worst_mu = worst_sig = 0.0
+    for row in meta:
+        pre = "r%04d_" % row["id"]
+        g = lambda k: data[pre + k]
+        mus, sigs = RL.position_refinement({str(row["L"]): g("Cs")}, row["LocErr"], g("ds"), g("Fs"), g("T"), row["F"], row["threshold"],
+                                           row["max_nb_states"])
+        dm, dsg = np.abs(mus[str(row["L"])] - g("mu")).max(), np.abs(sigs[str(row["L"])] - g("sig")).max()
+        assert dm < 1e-9 and dsg < 1e-9, (row, dm, dsg)
+        worst_mu, worst_sig = max(worst_mu, dm), max(worst_sig, dsg)
+    print("refine cases", len(meta), "worst |d mu|", worst_mu, "worst |d sigma|", worst_sig)
+
+
+def test_position_refinement_larger_bucket_vs_oracle_and_errors():
+    """700 tracks of 25 positions (23 batches of followers spread over the workgroups): first 60 rows against the oracle run on the same
+    first-30-pilots bucket... the merge decisions come from the first 30 tracks of the WHOLE bucket, so the oracle must see the whole
+    bucket too; refined positions must lie closer to the simulated true positions than the raw localisations do."""
+    from extrack_amd import refined_localization as RL
+    from oracle import oracle_refine as OR
+    rng = np.random.default_rng(3)
+    N, L, S = 700, 25, 2
+    ds = np.array([0.01, 0.09])
+    Tm = np.array([[0.93, 0.07], [0.12, 0.88]])
+    Fs = np.array([0.55, 0.45])
+    st = np.zeros((N, L), int)
+    st[:, 0] = rng.random(N) > Fs[0]
+    for k in range(1, L):
+        st[:, k] = np.where(rng.random(N) < Tm[st[:, k - 1], 0], 0, 1)
+    truth = np.cumsum(rng.normal(0, 1, (N, L, 2)) * ds[st][:, :, None], 1)
+    Cs = truth + rng.normal(0, 0.03, (N, L, 2))
+    mus, sigs = RL.position_refinement({str(L): Cs}, 0.03, ds, Fs, Tm, frame_len=6, threshold=0.1, max_nb_states=100)
+    ref_mu, ref_sig = OR.position_refinement({str(L): Cs}, 0.03, ds, Fs, Tm, 6, 0.1, 100)
+    assert np.abs(mus[str(L)] - ref_mu[str(L)]).max() < 1e-9 and np.abs(sigs[str(L)] - ref_sig[str(L)]).max() < 1e-9
+    raw = np.sqrt(((Cs - truth) ** 2).mean())
+    ref = np.sqrt(((mus[str(L)] - truth) ** 2).mean())
+    assert ref < 0.9 * raw, (raw, ref)
+    assert sigs[str(L)].shape == (N, L) and np.all(sigs[str(L)] > 0) and np.all(sigs[str(L)] < 0.03)
+    with pytest.raises(NotImplementedError):
+        RL.position_refinement({str(L): Cs}, {str(L): np.full((N, L, 1), 0.03)}, ds, Fs, Tm)
+    with pytest.raises(Exception):
+        RL.position_refinement({"2": Cs[:, :2]}, 0.03, ds, Fs, Tm)

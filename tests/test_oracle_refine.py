@@ -1,0 +1,24 @@
+"""The position-refinement oracle (oracle/oracle_refine.py) against golden vectors produced by the reference itself
+(tests/golden/make_golden_refine.py: extrack/refined_localization.py position_refinement on 50 buckets)."""
+import json
+import os
+
+import numpy as np
+
+from conftest import GOLDEN
+
+
+def test_position_refinement_matches_reference():
+    from oracle import oracle_refine as OR
+    meta = json.load(open(os.path.join(GOLDEN, "refine_cases.json")))
+    data = np.load(os.path.join(GOLDEN, "refine_cases.npz"))
+    worst_mu = worst_sig = 0.0
+    for row in meta:
+        pre = "r%04d_" % row["id"]
+        g = lambda k: data[pre + k]
+        mus, sigs = OR.position_refinement({str(row["L"]): g("Cs")}, row["LocErr"], g("ds"), g("Fs"), g("T"), row["F"], row["threshold"],
+                                           row["max_nb_states"])
+        worst_mu = max(worst_mu, np.abs(mus[str(row["L"])] - g("mu")).max())
+        worst_sig = max(worst_sig, np.abs(sigs[str(row["L"])] - g("sig")).max())
+    assert worst_mu < 1e-10 and worst_sig < 1e-10, (worst_mu, worst_sig)
+    print("refine cases", len(meta), "worst |d mu|", worst_mu, "worst |d sigma|", worst_sig)
