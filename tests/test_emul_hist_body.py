@@ -20,8 +20,8 @@ def test_emulated_histogram_body_vs_reference_fixtures():
     data = np.load(os.path.join(GOLDEN, "hist_cases.npz"))
     worst, n = 0.0, 0
     for row in info["cases"]:
-        if row["id"] % 5 != 0 and not (row["L"] == 2 and row["id"] % 2):
-            continue  # a fifth of the cases (plus minimal-length ones) keeps the CPU suite short
+        if (row["id"] % 9 != 0 and not (row["L"] == 2 and row["id"] % 4 == 1)) or row["K"] > 50:
+            continue  # a subset (incl. minimal-length cases; the 200-sequence sorts are left to the GPU test) keeps the CPU suite short
         pre = "h%04d_" % row["id"]
         g = lambda k: data[pre + k]
         ps = O.p_stay_table(g("ds"), row["S"], 1, row["cell_dims"])
@@ -31,5 +31,5 @@ def test_emulated_histogram_body_vs_reference_fixtures():
         assert d < 1e-9 * max(1.0, row["N"]), (row, d)
         worst = max(worst, d)
         n += 1
-    assert n > 40
+    assert n > 15
     print("cases", n, "worst |d hist|", worst)

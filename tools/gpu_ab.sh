@@ -1,0 +1,8 @@
+#!/bin/bash
+# A/B of library variants on ONE box: tools/gpu_ab.sh libA.so libB.so ...   (interleaved rounds, kernel ms of the headline bench)
+cd $GRAFT_REPO_ROOT
+for round in 1 2 3; do
+  for lib in "$@"; do
+    EXTRACK_HIP_LIB=$PWD/$lib python bench.py --no-cpu-baseline --no-extra --steps 30 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$lib', round(d['roofline']['kernel_ms'],4), round(d['ms_per_step'],4), round(d['threshold_fusion']['kernels_ms'],4))"
+  done
+done
