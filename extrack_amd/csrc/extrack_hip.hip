@@ -108,8 +108,12 @@ extern "C" int extrack_create(int device_id, extrack_ctx** out)
     }
     if (const char* ev = getenv("EXTRACK_TH_PLAN_THREADS")) {
         int v = atoi(ev);
-        if (v >= 64 && v <= 1024 && v % 64 == 0) c->th_plan_threads = v;
+        if (v >= 64 && v <= 1024 && v % 64 == 0) {
+            c->th_plan_threads = v;
+            c->th_plan_threads_forced = true;
+        }
     }
+    if (const char* ev = getenv("EXTRACK_TH_PLAN_BS")) c->th_plan_bs = atoi(ev);
     if (const char* ev = getenv("EXTRACK_TH_STAGE_LDS")) c->th_stage_in_lds_mode = atoi(ev) != 0;
     if (const char* ev = getenv("EXTRACK_TH_NO_GEN_SINGLE")) c->th_no_gen_single = atoi(ev) != 0;
     if (const char* ev = getenv("EXTRACK_TH_PAIR_LANES")) c->th_pair_lanes = atoi(ev);
@@ -664,11 +668,11 @@ static hipError_t xt_th_set_lds(extrack_ctx* ctx, KernT kern, size_t lds)
 }
 
 template <int D, int K>
-static hipError_t xt_th_launch_plan(extrack_ctx* ctx, const XtThArgs& a, int grid, size_t lds, hipStream_t stream)
+static hipError_t xt_th_launch_plan(extrack_ctx* ctx, const XtThArgs& a, int grid, int threads, size_t lds, hipStream_t stream)
 {
     hipError_t e = xt_th_set_lds(ctx, xt_th_plan_kernel<D, K, false>, lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((xt_th_plan_kernel<D, K, false>), dim3(grid), dim3(ctx->th_plan_threads), lds, stream, a);
+    hipLaunchKernelGGL((xt_th_plan_kernel<D, K, false>), dim3(grid), dim3(threads), lds, stream, a);
     return hipGetLastError();
 }
 
@@ -832,6 +836,7 @@ static int xt_th_run_group(extrack_ctx* ctx, const extrack_model* m, const std::
     a.threshold = threshold;
     a.pcap = std::min(chunk, XT_TH_PILOT);
     a.pair_lanes_max_p = ctx->th_pair_lanes;
+    a.plan_bs = ctx->th_plan_bs;
     a.nbuckets = nbk;
     std::vector<int32_t> chunk_end(nbk);
     int64_t total = 0;
@@ -951,7 +956,10 @@ static int xt_th_run_group(extrack_ctx* ctx, const extrack_model* m, const std::
         }
         a.ws = ctx->d_th_ws;
         if (lds > 160 * 1024) return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "plan tables do not fit the 160 KiB LDS of a CU");
-#define XT_TH_PLAN_CALL(...) xt_th_launch_plan<__VA_ARGS__>(ctx, a, grid, lds, ctx->stream)
+        // workgroup size: a chunk's plan is a serial walk over its positions; with many live sequences (more than 64 expanded per
+        // step at the previous evaluation) the grouping's pair tests dominate a step and are shared by all wavefronts
+        const int plan_threads = ctx->th_plan_threads_forced ? ctx->th_plan_threads : (ctx->th_learnE > 64 + 64 / 4 + 2 ? 1024 : ctx->th_plan_threads);
+#define XT_TH_PLAN_CALL(...) xt_th_launch_plan<__VA_ARGS__>(ctx, a, grid, plan_threads, lds, ctx->stream)
         if (D == 1 && K == 1) e = XT_TH_PLAN_CALL(1, 1);
         else if (D == 2 && K == 1) e = XT_TH_PLAN_CALL(2, 1);
         else if (D == 2 && K == 2) e = XT_TH_PLAN_CALL(2, 2);
@@ -1038,7 +1046,8 @@ static int xt_th_run_group(extrack_ctx* ctx, const extrack_model* m, const std::
     const int64_t tpc = (chunk + TT - 1) / TT;
     int blocks_per_cu = (int)std::min<size_t>(8, (160 * 1024) / lds);
     blocks_per_cu = std::max(1, std::min(blocks_per_cu, 2048 / threads));
-    const int64_t target = (int64_t)ctx->n_cu * blocks_per_cu * ctx->th_oversub;
+    // several length buckets in one launch: chunks differ in cost by the ratio of their track lengths, so cut them finer
+    const int64_t target = (int64_t)ctx->n_cu * blocks_per_cu * ctx->th_oversub * (nbk > 1 ? 2 : 1);
     int64_t bpc = (target + a.nchunks - 1) / a.nchunks;
     bpc = std::max<int64_t>(1, std::min<int64_t>(bpc, tpc));
     a.bpc = (int32_t)bpc;
@@ -1054,6 +1063,9 @@ static int xt_th_run_group(extrack_ctx* ctx, const extrack_model* m, const std::
 #undef XT_TH_APPLY_CALL
     if (e != hipSuccess) return xt_fail(ctx, EXTRACK_E_HIP, std::string("apply kernel launch: ") + hipGetErrorString(e));
     poff += (size_t)grid;
+    if (getenv("EXTRACK_TH_DEBUG"))
+        fprintf(stderr, "[th] chunks %d  plan: lds_mode %d wsP %d wsE %d stP %d | maxG %d sumE %d plan_cap %d | apply: uni %d single %d TT %d threads %d lds %zu bpc %d grid %d\n",
+                a.nchunks, a.ws_lds, a.wsP, a.wsE, a.stP, maxG, sumE, a.plan_cap, (int)uni, single_buf, TT, threads, lds, a.bpc, grid);
     ctx->launch_info[0] = grid;
     ctx->launch_info[1] = threads;
     ctx->launch_info[2] = (int32_t)lds;
@@ -1107,9 +1119,12 @@ static int xt_loglik_th_enqueue(extrack_ctx* ctx, const extrack_model* m, double
     // launch groups: buckets with the same (dims, sigma dims)
     std::vector<XtBucket*> order;
     for (auto& b : ctx->buckets) order.push_back(&b);
+    // longest tracks first inside a launch group: a chunk's plan is a serial walk over its positions, so the long chunks are the
+    // critical path of the plan kernel and must not be the last ones to start
     std::stable_sort(order.begin(), order.end(), [](const XtBucket* x, const XtBucket* y) {
         if (x->D != y->D) return x->D < y->D;
-        return x->KS < y->KS;
+        if (x->KS != y->KS) return x->KS < y->KS;
+        return x->L > y->L;
     });
     size_t poff = 0;
     XT_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));

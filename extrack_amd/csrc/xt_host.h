@@ -146,6 +146,8 @@ struct extrack_ctx {
     int th_pair_lanes = 4;  // EXTRACK_TH_PAIR_LANES
     int th_stage_in_lds_mode = 0;  // EXTRACK_TH_STAGE_LDS: LDS-typed copy of the pilot means/stds also when the state is in LDS (measured: no gain)
     int th_no_gen_single = 0;  // EXTRACK_TH_NO_GEN_SINGLE: never use the one-buffer general apply variant
+    int th_plan_bs = 0;         // plan kernel, > 64 sequences: pivot rows per batch = wavefronts x max(n, 1); < 0: one batch (EXTRACK_TH_PLAN_BS)
+    bool th_plan_threads_forced = false;
     int th_plan_threads = 512;  // workgroup size of the plan kernel (EXTRACK_TH_PLAN_THREADS)
     int th_force_tt = 0, th_force_threads = 0, th_oversub = 2;  // tuning knobs (EXTRACK_TH_TT / _THREADS / _OVERSUB)
     std::string err;

@@ -114,6 +114,8 @@ struct XtThArgs {
     int32_t ws_lds;        // 1: the pilot-track state lives in LDS (capacities learned from the previous evaluation)
     int32_t wsP, wsE;      // workspace capacities: parent sequences / expanded sequences per pilot track
     int32_t cmat_words;        // LDS words reserved for the compatibility bit matrix (0: XT_TH_CMAT_WORDS)
+    int32_t plan_bs;           // grouping with more than 64 sequences: batches of wavefronts x max(plan_bs, 1) pivot rows with the greedy scan in
+                               // between; < 0: all rows of a step in one batch
     int32_t pair_lanes_max_p;  // pilot counts up to this use one lane per (pivot, candidate) pair in the grouping, more use ballots
     int32_t stP, stE;      // global workspace only: capacities of the LDS staging copy of the pilots' means / stds that the
                            // grouping reads (0: none); steps with more sequences read the workspace directly
@@ -226,6 +228,16 @@ XT_HD bool xt_div_lt(double a, double b, double thr)
     if (fabs(q - thr) > 1e-5 * thr) return q < thr;
 #endif
     return a / b < thr;
+}
+
+// Hardware reciprocal (no Newton step): callers allow for its error and re-do borderline cases exactly.
+XT_HD double xt_rcp_raw(double b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcp(b);
+#else
+    return 1.0 / b;
+#endif
 }
 
 // View of a parent-sequence state buffer {zm, m[D], u[K], ze} per entry.  u = variance: after a merge s2 incl. the diffusion
@@ -569,6 +581,11 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
         }
         for (int i = tid; i < S; i += nt) newA[i] = (uint8_t)i;
         int nPar = S, Hc = 1, maxE = 0, maxG = S, overflow = 0, nfuse = 0, sumE = 0;
+        // np.mean(flags) > 0.8 over the P*K flags of a (pivot, candidate) pair <=> count >= cmin, with cmin found with the very same
+        // double arithmetic (count / (P*K) > 0.8) once per chunk instead of two divisions per pair
+        int cmin = P * K + 1;
+        for (int cnt = P * K; cnt >= 0; --cnt)
+            if ((double)cnt / (double)(P * K) > 0.8) cmin = cnt;
         XT_TH_PROF_DECL;
         double thr = a.threshold;
         uint8_t *nwA = newA, *nwB = newB;
@@ -661,14 +678,103 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
                         for (int c = 0; c < NS; ++c) eq = eq && xt_th_cat_digit(jj / pwS[c], S) == xt_th_cat_digit(bb / pwS[c], S);
                         return eq;
                     };
-                    // np.mean(flags) > 0.8 over the P*K flags <=> count >= cmin, with cmin found with the very same double
-                    // arithmetic (count / (P*K) > 0.8) once per step instead of two divisions per pair
-                    int cmin = P * K + 1;
-                    for (int cnt = P * K; cnt >= 0; --cnt)
-                        if ((double)cnt / (double)(P * K) > 0.8) cmin = cnt;
-                    // Rows are computed in batches of one pivot candidate per wavefront, the greedy scan advancing batch by batch:
-                    // a sequence that an earlier batch has already put into a group never becomes a pivot, so its row - more than
-                    // half of all rows - is never computed.
+                    // Wrapped classes: the candidates of a pivot are every third (S-th) later sequence only inside a block of 128 - instead of
+                    // testing the class of EVERY later sequence the rows walk per-class lists, clist[first(c) + k] = k-th sequence of class c as
+                    // (sequence | parent << 16).  The list lives in the member-word array, which is free until this step's members are known.
+                    // class_count(jend, c0, c1): sequences j < jend whose class is in [c0, c1)  (the class advances by one per sequence inside
+                    // a block of 128 sequences and jumps between blocks, see xt_th_cat_digit)
+                    auto class_count = [&](int jend, int c0, int c1) -> int {
+                        int k = 0;
+                        for (int t0 = 0; t0 < jend; t0 += 128) {
+                            const int n = (jend - t0) < 128 ? (jend - t0) : 128, f = xt_th_cat_digit(t0, S);
+                            for (int c = c0; c < c1; ++c) {
+                                const int r = (c - f + S) % S;
+                                k += n > r ? (n - r + S - 1) / S : 0;
+                            }
+                        }
+                        return k;
+                    };
+                    const bool clisted = wrapS && P > a.pair_lanes_max_p;
+                    uint32_t* clist = mpk;
+                    // One pivot row, lanes = pilot tracks (two candidates at a time, 32 pilot slots each; the counts of the reference's
+                    // np.mean(...) > 0.8 tests come from wave ballots).  Written for latency: every load of a candidate pair is
+                    // unconditional (slots beyond the pilots / the last odd candidate read valid addresses and are masked out of the ballots)
+                    // and issued before the arithmetic; a / b < thr is decided by the hardware reciprocal, the correctly rounded divisions run
+                    // in a wave-uniform branch taken only when some lane is within 1e-5 of the threshold (or not finite).  STG: the pilots'
+                    // means / stds are read from their LDS staging copy (compile-time, so that the loads are LDS loads, not flat ones).
+                    auto row_ballot = [&](const int b, auto WRAP, auto STG) {
+                        constexpr bool ST = decltype(STG)::value;
+                        auto Mq = [&](int d, int x, int g) -> double { return ST ? stM[(x * stP + g) * D + d] : bA.m(d, x * wsP + g); };
+                        auto Sq = [&](int k, int x, int jj) -> double { return ST ? stS[(x * stE + jj) * K + k] : sE[k * plane + x * wsE + jj]; };
+                        const int lane = cx.lane(), half = lane >> 5, x = lane & 31;
+                        const unsigned long long hmask = half ? 0xffffffff00000000ull : 0x00000000ffffffffull;
+                        const bool xl = x < P;
+                        const int xs = xl ? x : 0;
+                        const int gb = b / G, rb = b - gb * G;
+                        const double tol = 1e-5 * thr, invD = 1.0 / (double)D, invK = 1.0 / (double)K;
+                        double pmv[D], psv[K];
+                        for (int d = 0; d < D; ++d) pmv[d] = Mq(d, xs, gb);
+                        for (int k = 0; k < K; ++k) psv[k] = Sq(k, xs, b);
+                        const unsigned long long keyb = (!PREDS && useA) ? kyA[gb] : 0ull;
+                        auto test_pair = [&](const bool valid, const int jj, const int gj, const int rj, const int ci) {
+                            const int jv = valid ? jj : b, gv = valid ? gj : gb;
+                            double mj[D], sj[K];
+                            for (int d = 0; d < D; ++d) mj[d] = Mq(d, xs, gv);
+                            for (int k = 0; k < K; ++k) sj[k] = Sq(k, xs, jv);
+                            bool same_hist = valid && useA && same_digits(WRAP, jj, b, rj, rb);
+                            if (PREDS) {
+                                if (same_hist)  // predicting: on every pilot track (mean > 0.999, tracking.py:686)
+                                    for (int xx = 0; xx < P; ++xx) same_hist = same_hist && kyA[xx * wsP + gj] == kyA[xx * wsP + gb];
+                            } else if (useA) {
+                                same_hist = same_hist && kyA[gv] == keyb;
+                            }
+                            const bool live = valid && xl && !same_hist;
+                            double dmn = 0.0, dsd = 0.0;
+                            for (int d = 0; d < D; ++d) dmn += fabs(mj[d] - pmv[d]);
+                            for (int k = 0; k < K; ++k) dsd += fabs(sj[k] - psv[k]);
+                            int cm = 0, cs = 0;
+                            for (int k = 0; k < K; ++k) {
+                                const double ri = xt_rcp_raw(sj[k]);
+                                const double q1 = (dmn * invD) * ri, q2 = (dsd * invK) * ri;
+                                bool t1 = q1 < thr, t2 = q2 < thr;
+                                const bool border = !(fabs(q1 - thr) > tol) || !(fabs(q2 - thr) > tol);  // incl. NaN
+                                if (cx.ballot(live && border) != 0ull) {
+                                    if (border) {
+                                        t1 = (dmn / (double)D) / sj[k] < thr;
+                                        t2 = (dsd / (double)K) / sj[k] < thr;
+                                    }
+                                }
+                                const unsigned long long bm = cx.ballot(live && t1);
+                                const unsigned long long bs = cx.ballot(live && t2);
+                                cm += xt_popc64(bm & hmask);
+                                cs += xt_popc64(bs & hmask);
+                            }
+                            const bool flag = valid && (same_hist || (cm >= cmin && cs >= cmin));
+                            if (x == 0 && flag) cx.atomic_or_u32(&cmat[b * NWD + (ci >> 5)], 1u << (ci & 31));
+                        };
+                        if (decltype(WRAP)::value) {
+                            // wrapped classes: walk the class list (cstep == 1: bit = distance to the pivot - 1)
+                            const int c = xt_th_cat_digit(b, S);
+                            const int cb = class_count(nE, 0, c), kb = class_count(b, c, c + 1), nc = class_count(nE, c, c + 1);
+                            for (int kq = kb + 1; kq < nc; kq += 2) {
+                                const bool valid = kq + half < nc;
+                                const uint32_t ent = clist[cb + (valid ? kq + half : kb)];
+                                const int jj = (int)(ent & 0xffffu), gj = (int)(ent >> 16);
+                                test_pair(valid, jj, gj, jj - gj * G, jj - b - 1);
+                            }
+                        } else {
+                            const int dg = (2 * cstep) / G, dr = (2 * cstep) - dg * G;  // (parent, new digits) advance of a candidate per iteration
+                            int gj = (b + cstep + half * cstep) / G, rj = (b + cstep + half * cstep) - gj * G, ci = half;
+                            for (int j0 = b + cstep; j0 < nE; j0 += 2 * cstep, gj += dg, rj += dr, ci += 2) {
+                                if (rj >= G) {
+                                    rj -= G;
+                                    ++gj;
+                                }
+                                const int jj = j0 + half * cstep;
+                                test_pair(jj < nE, jj, gj, rj, ci);
+                            }
+                        }
+                    };
                     auto compute_row = [&](const int b, auto WRAP) {
                     if (P <= a.pair_lanes_max_p) {
                         // few pilot tracks (predict_Bs with nb_max <= 4): one lane per (pivot, candidate) pair, pilots in a loop
@@ -704,60 +810,32 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
                             }
                         }
                     } else {
-                        const int lane = cx.lane(), half = lane >> 5, x = lane & 31;
-                        const unsigned long long hmask = half ? 0xffffffff00000000ull : 0x00000000ffffffffull;
-                        const bool xl = x < P;
-                        const int dg = (2 * cstep) / G, dr = (2 * cstep) - dg * G;  // (parent, new digits) advance of a candidate per iteration
-                        {
-                            const int gb = b / G, rb = b - gb * G;
-                            double pmv[D], psv[K];
-                            for (int d = 0; d < D; ++d) pmv[d] = xl ? Mv(d, x, gb) : 0.0;
-                            for (int k = 0; k < K; ++k) psv[k] = xl ? Sv(k, x, b) : 1.0;
-                            int gj = (b + cstep + half * cstep) / G, rj = (b + cstep + half * cstep) - gj * G, ci = half;
-                            for (int j0 = b + cstep; j0 < nE; j0 += 2 * cstep, gj += dg, rj += dr, ci += 2) {
-                                if (rj >= G) {
-                                    rj -= G;
-                                    ++gj;
-                                }
-                                const int jj = j0 + half * cstep;
-                                const bool valid = jj < nE && same_class(WRAP, jj, b);
-                                bool same_hist = valid && useA && same_digits(WRAP, jj, b, rj, rb);
-                                if (same_hist)  // predicting: on every pilot track (mean > 0.999, tracking.py:686)
-                                    for (int xx = 0; xx < (PREDS ? P : 1); ++xx) same_hist = same_hist && kyA[xx * wsP + gj] == kyA[xx * wsP + gb];
-                                const bool live = valid && xl && !same_hist;
-                                double dmn = 0.0, dsd = 0.0, sj[K];
-                                for (int k = 0; k < K; ++k) sj[k] = 1.0;
-                                if (live) {
-                                    for (int d = 0; d < D; ++d) dmn += fabs(Mv(d, x, gj) - pmv[d]);
-                                    dmn = dmn / (double)D;
-                                    for (int k = 0; k < K; ++k) {
-                                        sj[k] = Sv(k, x, jj);
-                                        dsd += fabs(sj[k] - psv[k]);
-                                    }
-                                    dsd = dsd / (double)K;
-                                }
-                                int cm = 0, cs = 0;
-                                for (int k = 0; k < K; ++k) {
-                                    const unsigned long long bm = cx.ballot(live && xt_div_lt(dmn, sj[k], thr));
-                                    const unsigned long long bs = cx.ballot(live && xt_div_lt(dsd, sj[k], thr));
-                                    cm += xt_popc64(bm & hmask);
-                                    cs += xt_popc64(bs & hmask);
-                                }
-                                const bool flag = valid && (same_hist || (cm >= cmin && cs >= cmin));
-                                if (x == 0 && flag) cx.atomic_or_u32(&cmat[b * NWD + (ci >> 5)], 1u << (ci & 31));
-                            }
-                        }
+                        if (staged)
+                            row_ballot(b, WRAP, std::true_type());
+                        else
+                            row_ballot(b, WRAP, std::false_type());
                     }
                     };
-                    int mpos = 0, ng = 0;  // used by thread 0
+                    int mpos = 0, ng = 0;  // used by the first wavefront (uniform)
                     for (int i = tid; i < ((nE + 31) >> 5); i += nt) gbits[i] = 0u;
+                    if (clisted)
+                        for (int j = tid; j < nE; j += nt) {
+                            const int c = xt_th_cat_digit(j, S);
+                            clist[class_count(nE, 0, c) + class_count(j, c, c + 1)] = (uint32_t)j | ((uint32_t)(j / G) << 16);
+                        }
                     cx.sync();
+                    XT_TH_TICK(7);
                     const int NWv = cx.waves_per_block();
-                    // batch size: one row per wavefront; with few sequences (<= 64) and several wavefronts everything in one batch
-                    // (the barriers of more batches would cost more than the skipped rows save)
-                    const int BS = (NWv > 1 && nE <= 64) ? nE : NWv;
+                    // Rows are computed in batches of one pivot candidate per wavefront, the greedy scan advancing batch by batch: a
+                    // sequence that an earlier batch has already put into a group never becomes a pivot, so its row - more than half of
+                    // all rows - is never computed.  With few sequences (<= 64) and several wavefronts everything is one batch (the
+                    // barriers of more batches would cost more than the skipped rows save); row b then has ~(nE - b) / S candidates and
+                    // the rows are dealt in snake order (w, 2 NWv - 1 - w, 2 NWv + w, ...) so that every wavefront gets the same work.
+                    const bool one_batch = NWv > 1 && (nE <= 64 || a.plan_bs < 0);
+                    const int BS = one_batch ? nE : NWv * (a.plan_bs > 0 ? a.plan_bs : 1);
                     for (int b0 = 0; b0 < nE; b0 += BS) {
-                        for (int bw = b0 + cx.wave_in_block(); bw < b0 + BS && bw < nE; bw += NWv)
+                        for (int it = 0, bw = b0 + cx.wave_in_block(); bw < b0 + BS && bw < nE;
+                             ++it, bw = b0 + (it >> 1) * 2 * NWv + (one_batch && (it & 1) ? 2 * NWv - 1 - cx.wave_in_block() : cx.wave_in_block() + (it & 1) * NWv))
                             if (!((gbits[bw >> 5] >> (bw & 31)) & 1u)) {
                                 if (wrapS)
                                     compute_row(bw, std::true_type());
@@ -766,25 +844,45 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
                             }
                         cx.sync();
                         XT_TH_TICK(2);
-                        if (tid == 0) {
+                        if (cx.wave_in_block() == 0) {
+                            // The greedy scan, by the first wavefront: rows in order (inherently serial), the candidates of a pivot in
+                            // parallel - lane i looks at candidate bit c0 + i, the members are appended in candidate order (ranks from the
+                            // ballot).  mpos / ng are wave-uniform.  The grouped flags of the word the row index is in are kept in a
+                            // register between pivots, so a row that is already grouped costs no LDS round trip.
                             const int bend = b0 + BS < nE ? b0 + BS : nE;
+                            const int lane = cx.lane();
+                            const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+                            uint32_t gcur = 0u;
                             for (int b = b0; b < bend; ++b) {
-                                if ((gbits[b >> 5] >> (b & 31)) & 1u) continue;
-                                gst[ng++] = (uint16_t)mpos;
-                                mem[mpos++] = (uint16_t)b;  // the pivot itself
-                                gbits[b >> 5] |= 1u << (b & 31);
-                                const int nc = (nE - 1 - b) / cstep;  // candidates b + cstep, ..., b + nc cstep
-                                for (int wd = 0; wd < ((nc + 31) >> 5); ++wd) {
-                                    uint32_t bits = cmat[b * NWD + wd];
-                                    while (bits) {
-                                        const int jj = b + cstep * ((wd << 5) + __builtin_ctz(bits) + 1);
-                                        bits &= bits - 1;
-                                        if (!((gbits[jj >> 5] >> (jj & 31)) & 1u)) {
-                                            gbits[jj >> 5] |= 1u << (jj & 31);
-                                            mem[mpos++] = (uint16_t)jj;
-                                        }
-                                    }
+                                if ((b & 31) == 0 || b == b0) {
+                                    gcur = gbits[b >> 5];
+                                    cx.wave_sync();  // (CPU emulation: every lane has its copy before lane 0 touches the word)
                                 }
+                                if ((gcur >> (b & 31)) & 1u) continue;
+                                if (lane == 0) {
+                                    gst[ng] = (uint16_t)mpos;
+                                    mem[mpos] = (uint16_t)b;  // the pivot itself
+                                    gbits[b >> 5] = gcur | (1u << (b & 31));
+                                }
+                                ++ng;
+                                ++mpos;
+                                cx.wave_sync();
+                                const int nc = (nE - 1 - b) / cstep;  // candidates b + cstep, ..., b + nc cstep
+                                for (int c0 = 0; c0 < nc; c0 += 64) {
+                                    const int ci = c0 + lane;
+                                    const int jj = b + cstep * (ci + 1);
+                                    bool take = false;
+                                    if (ci < nc) take = ((cmat[b * NWD + (ci >> 5)] >> (ci & 31)) & 1u) && !((gbits[jj >> 5] >> (jj & 31)) & 1u);
+                                    const unsigned long long tk = cx.ballot(take);
+                                    if (take) {
+                                        mem[mpos + xt_popc64(tk & below)] = (uint16_t)jj;
+                                        cx.atomic_or_u32(&gbits[jj >> 5], 1u << (jj & 31));
+                                    }
+                                    mpos += xt_popc64(tk);
+                                }
+                                cx.wave_sync();
+                                gcur = gbits[b >> 5];
+                                cx.wave_sync();  // (CPU emulation: every lane has its copy before lane 0 touches the word again)
                             }
                         }
                         cx.sync();

@@ -45,6 +45,34 @@ def test_th_bodies_on_golden_subset():
     assert len(rows) >= 20 and worst < 1e-10, (len(rows), worst)
 
 
+@pytest.mark.parametrize("threshold,max_nb,threads,staged", [(0.12, 400, 128, False), (0.1, 100, 192, True)])
+def test_th_plan_many_sequences_wrapped_classes(threshold, max_nb, threads, staged, monkeypatch):
+    """More than 128 expanded sequences per step with 3 states: the reference's int8 index wrap makes the history classes irregular;
+    the plan kernel then walks per-class candidate lists.  Several wavefronts, global workspace with / without the LDS staging copy.
+    Groups identical to the oracle's."""
+    if staged:
+        for k in ("STP", "STE"):
+            monkeypatch.setenv("XT_EMUL_TH_" + k, "600")
+    E = _emul()
+    rng = np.random.default_rng(5)
+    S, ns, F, L, N = 3, 1, 6, 9, 36
+    ds = np.array([0.004, 0.03, 0.11])
+    Fs = np.array([0.3, 0.3, 0.4])
+    T = np.array([[0.9, 0.07, 0.03], [0.05, 0.9, 0.05], [0.03, 0.07, 0.9]])
+    Cs = np.cumsum(rng.normal(0, 1, (N, L, 2)) * ds[rng.integers(0, S, (N, L, 1))], 1) + rng.normal(0, 0.02, (N, L, 2))
+    LE = np.full((1, 1, 1), 0.02)
+    ps = p_stay_table(ds, S, ns, [1.0])
+    tr = []
+    ref = OT.proba_cs_th(Cs, LE, ds, Fs, T, 0.1, 1, [1.0], ns, F, 5, threshold, max_nb)
+    OT.p_cs_inter_bound_stats_th(Cs, LE, ds, Fs, T, 0.1, 1, [1.0], ns, F, 0, 5, threshold, max_nb, trace=tr)
+    ll, tot, plan, hdr, status = E.run_th(Cs, LE, ds, Fs, T, 0.1, 1, ps, ns, F, 5, threshold, max_nb, chunk=N, capE=1024, TT=8, threads=threads, nblocks=1)
+    assert status[:, 0].max() == 0
+    assert status[0, 1] > 128, status  # expanded sequences: the shared-row path and the wrapped classes were exercised
+    for i, t in enumerate(range(2, L - 1)):
+        assert [list(g) for g in tr[i]] == [list(g) for g in plan[0][t]], t
+    assert np.abs(ll - ref).max() < 1e-10
+
+
 @pytest.mark.parametrize("variant", ["general", "streamed", "uniform", "uniform_single", "general_single", "general_single_streamed", "lds_workspace"])
 def test_th_apply_variants_chunked(variant, monkeypatch):
     """Two chunks (the second ragged), 3 states, per-peak errors: every apply-kernel variant and the LDS-resident plan workspace."""
