@@ -87,18 +87,21 @@ class Comm:
         return int(self.allreduce_scalar(lo, "min")), int(self.allreduce_scalar(hi, "max"))
 
     # ---- sharding -----------------------------------------------------------------------------------------
-    def shard_buckets(self, tracks, sigmas=None, chunk=None):
+    def shard_buckets(self, tracks, sigmas=None, chunk=None, dts=None):
         """Row-shards every bucket per ``shard_plan`` (whole chunks when ``chunk`` is given); buckets whose local share is empty
-        are dropped locally (a rank may end up with no bucket at all: it then contributes 0 to the objective)."""
+        are dropped locally (a rank may end up with no bucket at all: it then contributes 0 to the objective).  ``dts`` (per-track
+        time steps [N_l, l]) are cut like the tracks; returns (tracks, sigmas) or, with ``dts``, (tracks, sigmas, dts)."""
         plan = shard_plan([len(b) for b in tracks], [b.shape[1] for b in tracks], self.world, chunk)
-        t_out, s_out = [], ([] if sigmas is not None else None)
+        t_out, s_out, d_out = [], ([] if sigmas is not None else None), ([] if dts is not None else None)
         for i, b in enumerate(tracks):
             a, z = plan[i][self.rank]
             if z > a:
                 t_out.append(b[a:z])
                 if sigmas is not None:
                     s_out.append(sigmas[i][a:z])
-        return t_out, s_out
+                if dts is not None:
+                    d_out.append(dts[i][a:z])
+        return (t_out, s_out) if dts is None else (t_out, s_out, d_out)
 
     def agree(self, ok, what="an operation"):
         """Collective error agreement: every rank passes its local success flag; if ANY rank failed, all ranks raise here, so that
@@ -111,9 +114,11 @@ class Comm:
         d = str(self.device)
         return int(d.split(":")[1]) if d.startswith("cuda:") else 0
 
-    def shard_trackset(self, tracks, sigmas=None, device=None, chunk=None):
+    def shard_trackset(self, tracks, sigmas=None, device=None, chunk=None, dts=None):
         """Uploads this rank's shard of ``tracks`` (the WHOLE dataset, same list on every rank) to its GPU.  ``min_len`` /
-        ``max_len`` are the dataset-global ones.  A rank left without tracks gets an empty TrackSet (objective 0.0)."""
+        ``max_len`` are the dataset-global ones.  A rank left without tracks gets an empty TrackSet (objective 0.0).  ``dts``:
+        per-track time steps [N_l, l] per bucket (threshold-fusion objective; needs ``chunk``: the field-of-view table of a chunk
+        comes from the time steps of ITS tracks, tracking.py:507-511, so the shards must be whole chunks)."""
         from .engine import TrackSet
         lens = [b.shape[1] for b in tracks if len(b)]
         lo, hi = self.global_min_max_len(lens)
@@ -123,8 +128,14 @@ class Comm:
         try:
             if not lens:
                 raise ValueError("No track could be detected. The loaded tracks seem empty. Errors often come from wrong input paths.")
-            t_loc, s_loc = self.shard_buckets(tracks, sigmas, chunk)
-            ts = TrackSet(t_loc, s_loc, device=device, min_len=lo, max_len=hi, allow_empty=True)
+            if dts is not None and chunk is None:
+                raise ValueError("per-track time steps need chunk-aligned shards: pass chunk=max_number_of_tracks_per_matrix")
+            d_loc = None
+            if dts is None:
+                t_loc, s_loc = self.shard_buckets(tracks, sigmas, chunk)
+            else:
+                t_loc, s_loc, d_loc = self.shard_buckets(tracks, sigmas, chunk, dts)
+            ts = TrackSet(t_loc, s_loc, device=device, min_len=lo, max_len=hi, allow_empty=True, dts=d_loc)
             ts.shard_chunk = chunk  # chunk alignment of the shard boundaries (None: row-balanced)
         except Exception as e:  # agree before raising: a lone raising rank would leave the others blocked in the next collective
             err = e

@@ -296,7 +296,8 @@ def _as_trackset(all_tracks, input_LocErr, device=None, comm=None, dt=None):
     if comm is None:
         return TrackSet(list(all_tracks), input_LocErr, device=dev, dts=dts), True
     if dts is not None:
-        raise NotImplementedError("per-track time steps with a communicator: shard with Comm.shard_trackset(..., dts=...)")
+        raise ValueError("per-track time steps with a communicator need chunk-aligned shards: pass the TrackSet of "
+                         "Comm.shard_trackset(..., chunk=max_number_of_tracks_per_matrix, dts=...)")
     lo, hi = comm.global_min_max_len([np.shape(b)[1] for b in all_tracks if len(b)])
     return TrackSet(list(all_tracks), input_LocErr, device=dev, min_len=lo, max_len=hi, allow_empty=True), True
 

@@ -35,7 +35,11 @@ class OracleContext:
         assert sigma is None
         self.buckets.append(tracks.shape + (0,))
         self.data.append(np.array(tracks, float))
+        self.dts = getattr(self, "dts", {})
         return len(self.data) - 1
+
+    def set_bucket_dt(self, bucket_id, dt):
+        self.dts[bucket_id] = np.array(dt, float)
 
     def n_tracks(self):
         return sum(b[0] for b in self.buckets)
@@ -62,9 +66,11 @@ class OracleContext:
         from oracle import oracle_th as OT
         le, ds, Fs, T, pBL, ns, F, lo, hi = self._model(model)
         tot = 0.0
-        for b in self.data:
+        for i, b in enumerate(self.data):
             for a0 in range(0, len(b), chunk):
-                tot += OT.proba_cs_th(b[a0:a0 + chunk], le, ds, Fs, T, pBL, 0 if b.shape[1] == hi else 1, CELL, ns, F, lo, threshold,
+                # per-track time steps: the model's ds are those of a unit time step, the reference's 3-D ds follow from the dt array
+                dsc = ds if i not in self.dts else ds[None, None] * np.sqrt(self.dts[i][a0:a0 + chunk])[:, :, None]
+                tot += OT.proba_cs_th(b[a0:a0 + chunk], le, dsc, Fs, T, pBL, 0 if b.shape[1] == hi else 1, CELL, ns, F, lo, threshold,
                                       max_nb_states).sum()
         return tot
 
@@ -124,6 +130,17 @@ def _worker(rank, world, port, q, scenario):
                                     max_number_of_tracks_per_matrix=chunk, comm=comm, fusion="threshold")
             out.update(th=th, th_ref=OT.cum_proba_cs_th(vals, tracks, 0.02, CELL, None, 1, 6, 1, 0.2, 120, chunk=chunk), th_n=ts.n_tracks)
             ts.close()
+            # the same with per-track time steps: the dt arrays are cut like the tracks, every chunk's field-of-view table comes from its own tracks
+            rng = np.random.default_rng(3)
+            dts = [0.02 * rng.uniform(0.5, 1.5, b.shape[:2]) for b in lst]
+            ts = comm.shard_trackset(lst, chunk=chunk, dts=dts)
+            assert ts.has_dt or ts.n_tracks == 0
+            with contextlib.redirect_stdout(io.StringIO()):
+                th_dt = T.cum_Proba_Cs(p, ts, None, CELL, None, 2, 1, 6, verbose=0, threshold=0.2, max_nb_states=120,
+                                       max_number_of_tracks_per_matrix=chunk, comm=comm, fusion="threshold")
+            out.update(th_dt=th_dt, th_dt_ref=OT.cum_proba_cs_th(vals, tracks, {k: d for k, d in zip(keys, dts)}, CELL, None, 1, 6, 1, 0.2, 120,
+                                                                  chunk=chunk))
+            ts.close()
             # posteriors: per-rank row ranges, ordered gather on rank 0
             pr = T.predict_Bs(tracks, 0.02, p, cell_dims=CELL, nb_states=2, frame_len=5, comm=comm)
             if rank == 0:
@@ -179,6 +196,7 @@ def test_two_rank_product_path_matches_unsharded():
         assert abs(r["got"] - r["ref"]) < 1e-12 * abs(r["ref"]), r
         assert abs(r["got_list"] - r["ref"]) < 1e-12 * abs(r["ref"]), r
         assert abs(r["th"] - r["th_ref"]) < 1e-12 * abs(r["th_ref"]), r
+        assert abs(r["th_dt"] - r["th_dt_ref"]) < 1e-12 * abs(r["th_dt_ref"]), r
         assert r["ranges"] == [(0, 21), (21, 41)] and r["ranges_chunk"] == [(0, 32), (32, 41)]
     assert res[0]["got"] == res[1]["got"] and res[0]["th"] == res[1]["th"]  # every rank sees the same reduced scalar
     assert sorted(r["has12"] for r in res) == [False, True]
