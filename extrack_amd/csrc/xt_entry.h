@@ -2,7 +2,8 @@
 // a group then has G = S^ns members (up to 64) but a track has only S^(F-ns) groups, so "one thread per group"
 // (xt_kernel.h) leaves most lanes idle and loops serially over the members.  Here ONE THREAD OWNS ONE SEQUENCE:
 //   * lanes [g*GP, g*GP + G) of a wave are the members of group g (GP = G rounded up to a power of two <= 64), so the
-//     moment-matching merge (max exponent, W, sum z*m, sum z*u) is a log2(GP)-step wave butterfly - no LDS, no atomics;
+//     moment-matching merge (max exponent, W, sum z*m, sum z*u) is a log2(GP)-step all-reduce over those lanes - DPP lane
+//     permutations inside a row of 16, one ds_swizzle / v_readlane step beyond (DevCtx::group_sum_f64): no LDS storage, no atomics;
 //   * after the merge every member expands/integrates ITS OWN new digit combination q and writes its own sequence in
 //     place; the only cross-thread hazard is the re-grouping of the next step (one workgroup barrier per position);
 //   * the last position enumerates all (old sequence, new digits) pairs: each thread loops over the G digit combinations
@@ -126,20 +127,11 @@ XT_HD void xt_entry_body(const XtKernelArgs& a, Ctx& cx)
                 }
             }
             // group merge: butterfly over the GP lanes of the group (every lane of the wave takes part)
-            int emax = e;
-            for (int m = 1; m < GP; m <<= 1) {
-                const int o = cx.shfl_xor_i32(emax, m);
-                emax = o > emax ? o : emax;
-            }
+            const int emax = cx.template group_max_i32<GP>(e);
             const double aq = xt_ldexp(z, e - emax);
-            double W = aq, M[D], U[K];
-            for (int d = 0; d < D; ++d) M[d] = aq * mq[d];
-            for (int k = 0; k < K; ++k) U[k] = aq * uq[k];
-            for (int m = 1; m < GP; m <<= 1) {
-                W += cx.shfl_xor_f64(W, m);
-                for (int d = 0; d < D; ++d) M[d] += cx.shfl_xor_f64(M[d], m);
-                for (int k = 0; k < K; ++k) U[k] += cx.shfl_xor_f64(U[k], m);
-            }
+            double W = cx.template group_sum_f64<GP>(aq), M[D], U[K];
+            for (int d = 0; d < D; ++d) M[d] = cx.template group_sum_f64<GP>(aq * mq[d]);
+            for (int k = 0; k < K; ++k) U[k] = cx.template group_sum_f64<GP>(aq * uq[k]);
             if (act && qvalid) {
                 const double rW = W > 0.0 ? xt_rcp(W) : 0.0;
                 for (int d = 0; d < D; ++d) M[d] *= rW;

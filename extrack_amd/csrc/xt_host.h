@@ -51,6 +51,44 @@ struct DevCtx {
         total = __popcll(b);
         return __popcll(b & ((1ull << (threadIdx.x & 63)) - 1ull));
     }
+    // All-reduce over aligned groups of GP lanes (power of two) without the LDS crossbar where the hardware allows it: DPP lane
+    // permutations inside a row of 16 lanes (quad swaps, then the mirrored half-row / row: any pairing of the two halves works for an
+    // all-reduce and both lanes of a pair compute the same sum), ds_swizzle for the neighbouring row, v_readlane for the wave halves.
+    template <int CTRL>
+    __device__ static __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false); }
+    template <int CTRL>
+    __device__ static __forceinline__ double dpp_f64(double v)
+    {
+        return __hiloint2double(dpp_i32<CTRL>(__double2hiint(v)), dpp_i32<CTRL>(__double2loint(v)));
+    }
+    template <int GP>
+    __device__ __forceinline__ double group_sum_f64(double v)
+    {
+        if (GP >= 2) v += dpp_f64<0xB1>(v);   // quad_perm [1,0,3,2]
+        if (GP >= 4) v += dpp_f64<0x4E>(v);   // quad_perm [2,3,0,1]
+        if (GP >= 8) v += dpp_f64<0x141>(v);  // row_half_mirror
+        if (GP >= 16) v += dpp_f64<0x140>(v); // row_mirror
+        if (GP >= 32)
+            v += __hiloint2double(__builtin_amdgcn_ds_swizzle(__double2hiint(v), 0x401F), __builtin_amdgcn_ds_swizzle(__double2loint(v), 0x401F));
+        if (GP >= 64) {
+            const double lo = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 0), __builtin_amdgcn_readlane(__double2loint(v), 0));
+            const double hi = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 32), __builtin_amdgcn_readlane(__double2loint(v), 32));
+            v = lo + hi;
+        }
+        return v;
+    }
+    template <int GP>
+    __device__ __forceinline__ int group_max_i32(int v)
+    {
+        auto mx = [](int a, int b) { return a > b ? a : b; };
+        if (GP >= 2) v = mx(v, dpp_i32<0xB1>(v));
+        if (GP >= 4) v = mx(v, dpp_i32<0x4E>(v));
+        if (GP >= 8) v = mx(v, dpp_i32<0x141>(v));
+        if (GP >= 16) v = mx(v, dpp_i32<0x140>(v));
+        if (GP >= 32) v = mx(v, __builtin_amdgcn_ds_swizzle(v, 0x401F));
+        if (GP >= 64) v = mx(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 32));
+        return v;
+    }
     __device__ __forceinline__ int shfl_xor_i32(int v, int m) { return __shfl_xor(v, m, 64); }
     __device__ __forceinline__ double shfl_xor_f64(double v, int m) { return __shfl_xor(v, m, 64); }
     __device__ __forceinline__ void atomic_max_i32(int* p, int v)

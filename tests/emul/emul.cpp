@@ -39,6 +39,21 @@ struct HostCtx {
         return o;
     }
     int shfl_xor_i32(int v, int m) { return (int)shfl_xor_f64((double)v, m); }
+    template <int GP>
+    double group_sum_f64(double v)
+    {
+        for (int m = 1; m < GP; m <<= 1) v += shfl_xor_f64(v, m);
+        return v;
+    }
+    template <int GP>
+    int group_max_i32(int v)
+    {
+        for (int m = 1; m < GP; m <<= 1) {
+            const int o = shfl_xor_i32(v, m);
+            v = o > v ? o : v;
+        }
+        return v;
+    }
     unsigned long long ballot(bool flag)
     {
         wscr_[lane()] = flag ? 1.0 : 0.0;
