@@ -409,13 +409,8 @@ XT_HD void xt_ll_s2_body(const XtKernelArgs& a, Ctx& cx)
             }
         }
         // reduce over the track's NG lanes (all lanes end with the same values)
-        int fe = tot.m != 0.0 ? tot.e : XT_EMIN;
-        for (int m = 1; m < NG; m <<= 1) {
-            const int o = cx.shfl_xor_i32(fe, m);
-            fe = o > fe ? o : fe;
-        }
-        double sum = tot.m != 0.0 ? xt_ldexp(tot.m, tot.e - fe) : 0.0;
-        for (int m = 1; m < NG; m <<= 1) sum += cx.shfl_xor_f64(sum, m);
+        const int fe = cx.template group_max_i32<NG>(tot.m != 0.0 ? tot.e : XT_EMIN);
+        double sum = cx.template group_sum_f64<NG>(tot.m != 0.0 ? xt_ldexp(tot.m, tot.e - fe) : 0.0);
         if (xt_at<int>(lds, XT_F2_NAN_OFF + (wib * 8 + ts) * 4)) sum = NAN;  // NaN input -> NaN likelihood, as in the reference
         if (act && g == 0) {
             if (b.ll_out) b.ll_out[trk] = log(sum) + (double)fe * XT_LN2 + b.ll_const;
