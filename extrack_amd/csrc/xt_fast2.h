@@ -20,6 +20,9 @@
 #include "xt_kernel.h"
 
 #define XT_F2_CHUNK 32  // positions staged per refill
+#ifndef XT_F2_RENORM
+#define XT_F2_RENORM 3  // phases between two re-normalisations of the merged weight (1: every step)
+#endif
 #define XT_F2_WAVES 4   // waves per block (independent of each other; they only share the table copy)
 
 static inline bool xt_use_fast2(int S, int NS, int F, bool preds) { return S == 2 && NS == 1 && F >= 4 && F <= 7 && !preds; }
@@ -93,14 +96,15 @@ struct XtF2State {
 };
 
 // Fixed LDS map of the fast path (bytes).  One array per field over all waves of the block, so that a field is reached
-// from the zm address by a compile-time offset and ze (4-byte elements) by (a >> 1) + constant.
+// from the zm address by a compile-time offset - the exponents ze too: they sit in 8-byte slots (upper half unused), which
+// saves the address arithmetic a packed int array would need in every step.
 #define XT_F2_TAB_BYTES 1024                                   /* model blob: tables (288 B) + T64 exp table (512 B) */
 #define XT_F2_T64_OFF ((XT_BLOB_HDR + XT_NTAB * 4) * 8)   /* the blob's T64 table (xt_tables.h) */
 #define XT_F2_NAN_OFF 832                                      /* int[XT_F2_WAVES][8]: track has a NaN position / sigma */
 #define XT_F2_ARR (XT_F2_WAVES * 128 * 8)                      /* bytes of one double field for all waves */
 #define XT_F2_ZM0 XT_F2_TAB_BYTES
 XT_HD int xt_f2_ze0(int D, int K) { return XT_F2_ZM0 + (1 + D + K) * XT_F2_ARR; }
-XT_HD int xt_f2_pos0(int D, int K) { return xt_f2_ze0(D, K) + XT_F2_WAVES * 128 * 4; }
+XT_HD int xt_f2_pos0(int D, int K) { return xt_f2_ze0(D, K) + XT_F2_ARR; }
 XT_HD int xt_f2_acc0(int D, int K, int KS, int tpw) { return xt_f2_pos0(D, K) + XT_F2_WAVES * tpw * XT_F2_CHUNK * (D + KS) * 8; }
 XT_HD int xt_f2_block_bytes(int D, int K, int KS, int tpw) { return xt_f2_acc0(D, K, KS, tpw) + XT_F2_WAVES * 8 * 3 * 8; }
 
@@ -124,11 +128,11 @@ XT_HD T& xt_at(char* lds, int byte_off)
 template <int F, int D, int K, int H>
 XT_HD void xt_f2_step(char* lds, const XtF2State<F, D, K>& st, const double* c, const double* l2, const double* TT, const double* TD2)
 {
-    constexpr int ZEO = XT_F2_ZM0 + (1 + D + K) * XT_F2_ARR - XT_F2_ZM0 / 2;  // ze address = (a >> 1) + ZEO
+    constexpr int ZEO = (1 + D + K) * XT_F2_ARR;  // ze address = a + ZEO
     const int pk = xt_opaque(st.s01[H]);
     const int a0 = pk & 0xffff, a1 = (int)((unsigned)pk >> 16);
     const double z0 = xt_at<double>(lds, a0), z1 = xt_at<double>(lds, a1);
-    const int e0 = xt_at<int>(lds, (a0 >> 1) + ZEO), e1 = xt_at<int>(lds, (a1 >> 1) + ZEO);
+    const int e0 = xt_at<int>(lds, a0 + ZEO), e1 = xt_at<int>(lds, a1 + ZEO);
     const int emax = e0 > e1 ? e0 : e1;
     const double w0 = xt_ldexp(z0, e0 - emax), w1 = xt_ldexp(z1, e1 - emax);
     const double W = w0 + w1;
@@ -139,8 +143,12 @@ XT_HD void xt_f2_step(char* lds, const XtF2State<F, D, K>& st, const double* c, 
         U[k] = xt_fma(w1, xt_at<double>(lds, a1 + (1 + D + k) * XT_F2_ARR), w0 * xt_at<double>(lds, a0 + (1 + D + k) * XT_F2_ARR));
     const bool live = W > 0.0;
     const double Ws = live ? W : 1.0;
-    const double Wm = xt_frexp_mant(W);  // 0 when W == 0
-    const int We = live ? emax + xt_frexp_exp(W) : XT_EMIN;
+    // The merged weight is re-normalised (mantissa in [0.5, 1), exponent into ze) in every XT_F2_RENORM-th phase only: between two
+    // normalisations a mantissa drifts by at most (2 * max(1, den^(-D/2)))^XT_F2_RENORM - a few tens of binades of fp64's two thousand -
+    // and every expression of the step is homogeneous in W, so nothing else changes.
+    constexpr bool RN = (H % XT_F2_RENORM) == 0;
+    const double Wm = RN ? xt_frexp_mant(W) : W;  // 0 when W == 0
+    const int We = live ? (RN ? emax + xt_frexp_exp(W) : emax) : XT_EMIN;
 
     // Dq[k] = W * den_q[k] = W*(l2 + d2_q) + U
     double Dq[2][K];
@@ -201,7 +209,7 @@ XT_HD void xt_f2_step(char* lds, const XtF2State<F, D, K>& st, const double* c, 
         const int en = We + n[q];
         const double tj = xt_at<double>(lds, XT_F2_T64_OFF + j[q] * 8);
         xt_at<double>(lds, aq) = (Wm * TT[q]) * (gf[q] * tj) * p[q];
-        xt_at<int>(lds, (aq >> 1) + ZEO) = en > XT_EMIN ? en : XT_EMIN;
+        xt_at<int>(lds, aq + ZEO) = en > XT_EMIN ? en : XT_EMIN;
         for (int d = 0; d < D; ++d) xt_at<double>(lds, aq + (1 + d) * XT_F2_ARR) = xt_fma(dmW[d], tt[q][K == 1 ? 0 : d], M[d]) * rW;
         for (int k = 0; k < K; ++k) xt_at<double>(lds, aq + (1 + D + k) * XT_F2_ARR) = l2[k] * tt[q][k];
     }
@@ -244,8 +252,8 @@ XT_HD void xt_ll_s2_body(const XtKernelArgs& a, Ctx& cx)
     double l2g[K];
     for (int k = 0; k < K; ++k) l2g[k] = hdr[k];
 
-    // LDS map (bytes): [tables 1 KiB][zm][m x D][u x K] (each XT_F2_WAVES x 128 doubles) [ze: XT_F2_WAVES x 128 ints][pos][sig]
-    constexpr int ZEO = XT_F2_ZM0 + (1 + D + K) * XT_F2_ARR - XT_F2_ZM0 / 2;
+    // LDS map (bytes): [tables 1 KiB][zm][m x D][u x K] (each XT_F2_WAVES x 128 doubles) [ze: XT_F2_WAVES x 128 ints in 8-byte slots][pos][sig]
+    constexpr int ZEO = (1 + D + K) * XT_F2_ARR;
     const int wave0 = XT_F2_ZM0 + wib * 128 * 8;  // byte address of this wave's zm[0]
     double* pos = (double*)(lds + xt_f2_pos0(D, K)) + wib * TPW * XT_F2_CHUNK * (D + KS);  // [TPW][CHUNK][D]
     double* sig = pos + TPW * XT_F2_CHUNK * D;                                             // [TPW][CHUNK][KS]
@@ -353,7 +361,7 @@ XT_HD void xt_ll_s2_body(const XtKernelArgs& a, Ctx& cx)
                     const int idx = w - ts * E;
                     const int aq = wave0 + xt_f2_swz<F>(w) * 8;
                     xt_at<double>(lds, aq) = idx < 2 ? hdr[8 + idx] : 0.0;  // initial fractions F0, F1
-                    xt_at<int>(lds, (aq >> 1) + ZEO) = idx < 2 ? 0 : XT_EMIN;
+                    xt_at<int>(lds, aq + ZEO) = idx < 2 ? 0 : XT_EMIN;
                     for (int d = 0; d < D; ++d) xt_at<double>(lds, aq + (1 + d) * XT_F2_ARR) = c0[d];
                     for (int k = 0; k < K; ++k) xt_at<double>(lds, aq + (1 + D + k) * XT_F2_ARR) = l20[k];
                 }
@@ -378,7 +386,7 @@ XT_HD void xt_ll_s2_body(const XtKernelArgs& a, Ctx& cx)
             for (int Q = 0; Q < 2; ++Q) {
                 const int aq = Q ? a1 : a0;
                 const double zq = xt_at<double>(lds, aq);
-                const int eq = xt_at<int>(lds, (aq >> 1) + ZEO);
+                const int eq = xt_at<int>(lds, aq + ZEO);
                 double dq[D], dsq = 0.0;
                 for (int d = 0; d < D; ++d) {
                     dq[d] = cl[d] - xt_at<double>(lds, aq + (1 + d) * XT_F2_ARR);
