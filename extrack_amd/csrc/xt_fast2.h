@@ -56,8 +56,8 @@ XT_HD int xt_f2_swz(int w)
 // exp(x), x <= 0, table-driven: x = (64 e + j) ln2/64 + r, |r| <= ln2/128, exp(x) = 2^e * T64[j] * P5(r).
 // Two independent evaluations are interleaved instruction by instruction (a wave alone can only issue a DEPENDENT
 // fp64 FMA every few issue slots).  Returns p (without the table factor), the table index j and the exponent e.
-// |rel err| < 3e-16 (truncation r^6/720 < 4e-17).  Clamp: x >= -3e7 keeps 64x/ln2 inside int32.
-#define XT_F2_XCLAMP (-3.0e7)
+// |rel err| < 3e-16 (truncation r^6/720 < 4e-17).  Clamp: see XT_TCLAMP (xt_math.h).
+#define XT_F2_XCLAMP XT_TCLAMP
 XT_HD void xt_exp_tab_x2(double x0, double x1, double& p0, double& p1, int& j0, int& j1, int& e0, int& e1)
 {
     x0 = x0 > XT_F2_XCLAMP ? x0 : XT_F2_XCLAMP;

@@ -73,7 +73,10 @@ XT_HD int xt_lo32(double t)
 
 // exp(x), x <= 0, table-driven: x = (64 e + j) ln2/64 + r, |r| <= ln2/128, exp(x) = 2^e * T64[j] * p with p = P5(r).
 // T64[j] = 2^(j/64) is part of the model blob (xt_tables.h).  |rel err| < 3e-16.  A NaN argument stays NaN.
-#define XT_TCLAMP (-3.0e7)  // keeps 64 x / ln2 inside int32
+// Clamp of the exponent argument: n = 64 x / ln2 must fit int32 AND the sum of a sequence's exponent (>= XT_EMIN = -2^30) and n
+// must not wrap: |n| < 2^30 <=> x > -1.16e7.  A Gaussian exponent below -1.1e7 is a jump of more than 4 600 standard deviations
+// in one frame; such a sequence's weight is 2^(-1.5e7) instead of its true (even smaller) value.
+#define XT_TCLAMP (-1.1e7)
 XT_HD void xt_exp_tab(double x, double& p, int& j, int& e)
 {
     x = x < XT_TCLAMP ? XT_TCLAMP : x;

@@ -76,6 +76,33 @@ def test_fast2_multi_chunk_tracks(F, L, N, monkeypatch):
     assert abs(tot - ref.sum()) < 1e-9
 
 
+@pytest.mark.parametrize("generic", [False, True])
+def test_absurd_jump_stays_a_tiny_weight(generic, monkeypatch):
+    """A jump of thousands of localisation errors in one frame: the Gaussian exponent leaves the range of the table-driven exp.  The
+    sequence's weight must clamp to (practically) zero - not wrap around the int32 exponent into a huge one (found in round 2: the
+    clamp was -3e7 while 64 x / ln2 only fits int32 down to -2.3e7).  Jumps inside the range stay exact."""
+    if generic:
+        monkeypatch.setenv("XT_EMUL_GENERIC", "1")
+    else:
+        monkeypatch.delenv("XT_EMUL_GENERIC", raising=False)
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "emul"))
+    import run_emul as E
+    rng = np.random.default_rng(8)
+    N, L = 6, 12
+    Cs = np.cumsum(rng.normal(0, 0.05, (N, L, 2)), 1)
+    Cs[1, 6:] += 750.0   # Gaussian exponent ~ -2.6e7 for the mobile state: beyond the clamp (and in the range that used to wrap)
+    Cs[2, 6:] += 60.0    # ~ -1.7e5: inside
+    ds, Fs, T = np.array([0.01, 0.1]), np.array([.4, .6]), np.array([[.9, .1], [.2, .8]])
+    LE = np.array([[[0.02]]])
+    ps = O.p_stay_table(ds, 2, 1, [1.0])
+    ref = O.proba_cs(Cs, LE, ds, Fs, T, 0.1, 1, [1.0], 1, 6, 3)
+    ll, _, tot, _ = E.run(Cs, LE, ds, Fs, T, 0.1, 1, ps, 1, 6, 3, nblocks=1)
+    ok = np.array([0, 2, 3, 4, 5])
+    assert (np.abs(ll[ok] - ref[ok]) < 1e-10 + 1e-12 * np.abs(ref[ok])).all(), (ll, ref)
+    assert np.isfinite(ll[1]) and ll[1] < -7e6 and ref[1] < -7e6, (ll[1], ref[1])   # clamped: hugely negative, not garbage
+
+
 @pytest.mark.parametrize("S,ns,F,L,N,pred", [(3, 1, 3, 40, 7, True), (2, 1, 4, 70, 9, True), (2, 2, 3, 66, 5, False), (3, 1, 4, 33, 4, True)])
 def test_generic_body_multi_chunk_and_per_peak(S, ns, F, L, N, pred, monkeypatch):
     """General kernel body with tracks longer than one 32-position staging chunk, per-peak localisation errors,

@@ -275,6 +275,27 @@ def test_extreme_displacements_do_not_underflow(S, F):
     np.testing.assert_allclose(got, ref, rtol=1e-13, atol=1e-10)
 
 
+@pytest.mark.parametrize("S,F", [(2, 6), (3, 4)])
+def test_absurd_jump_clamps_instead_of_wrapping(S, F):
+    """A jump of tens of thousands of localisation errors (Gaussian exponent below -1.1e7, the clamp of the table-driven exp): the
+    weight must become (practically) zero, not wrap around the int32 exponent.  Other tracks of the launch are unaffected."""
+    from extrack_amd import synth, tracking as T
+    from oracle import oracle_np as O
+    Ds = [0.0, 0.25, 1.0][:S]
+    Tm = np.full((S, S), 0.1)
+    Tm[np.arange(S), np.arange(S)] = 1 - 0.1 * (S - 1)
+    Fs = np.full(S, 1.0 / S)
+    Cs = synth.brownian_tracks(12, 15, Ds, Tm, Fs, seed=6)
+    Cs[3, 7:] += 3000.0
+    ds = np.sqrt(2 * np.array(Ds) * 0.02) + 1e-4
+    LE = np.array([[[0.02]]])
+    ref = O.proba_cs(Cs, LE, ds, Fs, Tm, 0.1, 1, [1.0], 1, F, 3)
+    got = T.Proba_Cs(Cs, LE, ds, Fs, Tm, 0.1, 1, [1.0], 1, F, 3)
+    ok = np.arange(12) != 3
+    np.testing.assert_allclose(got[ok], ref[ok], rtol=1e-13, atol=1e-10)
+    assert np.isfinite(got[3]) and got[3] < -7e6 and ref[3] < -7e6, (got[3], ref[3])
+
+
 def test_large_coordinate_offsets():
     """Positions around 1e4 um (pixel-like coordinates): both implementations difference nearby fp64 numbers; parity must hold to the
     conditioning of the problem (|c| * eps / sigma^2 ~ 1e-12 * 1e4 / 4e-4 per step)."""
