@@ -1580,7 +1580,7 @@ extern "C" int extrack_refine_positions(extrack_ctx* ctx, const extrack_model* m
     if (m->frame_len <= 1 || m->frame_len > 15) return xt_fail(ctx, EXTRACK_E_INVALID, "frame_len must be in (1, 15]");
     XtBucket& b = ctx->buckets[bucket_id];
     const int S = m->n_states, L = b.L, D = b.D;
-    if (L < 3) return xt_fail(ctx, EXTRACK_E_INVALID, "position refinement needs tracks of at least 3 positions");
+    if (L < 2) return xt_fail(ctx, EXTRACK_E_INVALID, "position refinement needs tracks of at least 2 positions");
     XT_HIP(ctx, hipSetDevice(ctx->device));
     // time-reversed copy of the bucket for the pass "from the future" (made on the host: the tracks are small next to the records)
     const size_t nel = (size_t)b.N * L * D;

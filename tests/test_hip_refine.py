@@ -54,5 +54,11 @@ def test_position_refinement_larger_bucket_vs_oracle_and_errors():
     assert sigs[str(L)].shape == (N, L) and np.all(sigs[str(L)] > 0) and np.all(sigs[str(L)] < 0.03)
     with pytest.raises(NotImplementedError):
         RL.position_refinement({str(L): Cs}, {str(L): np.full((N, L, 1), 0.03)}, ds, Fs, Tm)
+    # two-position tracks (the reference handles them: both positions are end positions); a mixed dataset incl. a one-track bucket
+    short = {"2": Cs[:40, :2], "3": Cs[40:41, :3], "5": Cs[41:75, :5]}
+    mus, sigs = RL.position_refinement(short, 0.03, ds, Fs, Tm, frame_len=6, threshold=0.1, max_nb_states=100)
+    ref_mu, ref_sig = OR.position_refinement(short, 0.03, ds, Fs, Tm, 6, 0.1, 100)
+    for k in short:
+        assert np.abs(mus[k] - ref_mu[k]).max() < 1e-9 and np.abs(sigs[k] - ref_sig[k]).max() < 1e-9, k
     with pytest.raises(Exception):
-        RL.position_refinement({"2": Cs[:, :2]}, 0.03, ds, Fs, Tm)
+        RL.position_refinement({"1": Cs[:, :1]}, 0.03, ds, Fs, Tm)
