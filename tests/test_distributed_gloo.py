@@ -74,6 +74,29 @@ class OracleContext:
                                       max_nb_states).sum()
         return tot
 
+    def loglik_grad(self, model, tangents):
+        """sum LL and its derivative along every model tangent: central differences of the oracle (test stand-in; the kernel's own
+        derivative is checked on the GPU, tests/test_hip_grad.py).  Additive over tracks, like the kernel's result."""
+        from oracle import oracle_np as O
+        le, ds, Fs, T, pBL, ns, F, lo, hi = self._model(model)
+
+        def total(ds_, Fs_, T_, pBL_, le_):
+            return sum(O.proba_cs(b, le_, ds_, Fs_, T_, pBL_, 0 if b.shape[1] == hi else 1, CELL, ns, F, lo).sum() for b in self.data)
+        h = 1e-6
+        g = []
+        for t in tangents:
+            def at(sg):
+                return total(np.sqrt(ds ** 2 + sg * h * np.asarray(t["ds2"])), Fs + sg * h * np.asarray(t["Fs"]), T + sg * h * np.asarray(t["TrMat"]),
+                             pBL + sg * h * t["pBL"], le + sg * h * np.asarray(t.get("locerr", 0.0)))
+            g.append((at(+1) - at(-1)) / (2 * h))
+        return total(ds, Fs, T, pBL, le), np.array(g)
+
+    def segment_len_hist(self, model, bucket_id, max_nb_states=500):
+        from oracle import oracle_hist as OH
+        le, ds, Fs, T, pBL, ns, F, lo, hi = self._model(model)
+        b = self.data[bucket_id]
+        return OH.p_segment_len(b, le, ds, Fs, T, lo, pBL, 0 if b.shape[1] == hi else 1, CELL, 1, max_nb_states)
+
     def predict(self, model, bucket_id):
         from oracle import oracle_np as O
         le, ds, Fs, T, pBL, ns, F, lo, hi = self._model(model)
@@ -141,6 +164,22 @@ def _worker(rank, world, port, q, scenario):
             out.update(th_dt=th_dt, th_dt_ref=OT.cum_proba_cs_th(vals, tracks, {k: d for k, d in zip(keys, dts)}, CELL, None, 1, 6, 1, 0.2, 120,
                                                                   chunk=chunk))
             ts.close()
+            # objective + gradient: the (1 + nvar) vector is all-reduced; state-duration histograms: the small array is all-reduced
+            from extrack_amd import gradient
+            from extrack_amd.histograms import len_hist
+            from oracle import oracle_hist as OH
+            pg = T.generate_params(nb_states=2, LocErr_type=1, estimated_Ds=[1e-3, 0.25], estimated_LocErr=[0.02], estimated_Fs=[0.6],
+                                   estimated_transition_rates=0.1)
+            ts = comm.shard_trackset(lst)
+            gv, gg = gradient.objective_and_gradient(pg, ts, 0.02, CELL, 2, 1, 4, comm=comm)
+            ts.close()
+            full = T.TrackSet(lst, device=0)  # the whole dataset on one stand-in context: what a single rank would compute
+            gv1, gg1 = gradient.objective_and_gradient(pg, full, 0.02, CELL, 2, 1, 4)
+            full.close()
+            out.update(gv=gv, gg=gg.tolist(), gv1=gv1, gg1=gg1.tolist())
+            with contextlib.redirect_stdout(io.StringIO()):
+                hh = len_hist(tracks, p, 0.02, cell_dims=CELL, nb_states=2, max_nb_states=30, comm=comm)
+            out.update(hist_err=float(np.abs(hh - OH.len_hist(vals, tracks, 0.02, CELL, 30)).max()), hist_sum=float(hh.sum()))
             # posteriors: per-rank row ranges, ordered gather on rank 0
             pr = T.predict_Bs(tracks, 0.02, p, cell_dims=CELL, nb_states=2, frame_len=5, comm=comm)
             if rank == 0:
@@ -197,6 +236,8 @@ def test_two_rank_product_path_matches_unsharded():
         assert abs(r["got_list"] - r["ref"]) < 1e-12 * abs(r["ref"]), r
         assert abs(r["th"] - r["th_ref"]) < 1e-12 * abs(r["th_ref"]), r
         assert abs(r["th_dt"] - r["th_dt_ref"]) < 1e-12 * abs(r["th_dt_ref"]), r
+        assert abs(r["gv"] - r["gv1"]) < 1e-10 * abs(r["gv1"]) and np.allclose(r["gg"], r["gg1"], rtol=1e-6, atol=1e-4), (r["gg"], r["gg1"])
+        assert r["hist_err"] < 1e-10 and r["hist_sum"] > 1.0, r
         assert r["ranges"] == [(0, 21), (21, 41)] and r["ranges_chunk"] == [(0, 32), (32, 41)]
     assert res[0]["got"] == res[1]["got"] and res[0]["th"] == res[1]["th"]  # every rank sees the same reduced scalar
     assert sorted(r["has12"] for r in res) == [False, True]
