@@ -114,6 +114,8 @@ extern "C" int extrack_create(int device_id, extrack_ctx** out)
         }
     }
     if (const char* ev = getenv("EXTRACK_TH_PLAN_BS")) c->th_plan_bs = atoi(ev);
+    if (const char* ev = getenv("EXTRACK_TH_NO_SPLIT")) c->th_no_split = atoi(ev) != 0;
+    if (const char* ev = getenv("EXTRACK_TH_SPLIT_PCT")) c->th_split_pct = atoi(ev);
     if (const char* ev = getenv("EXTRACK_TH_STAGE_LDS")) c->th_stage_in_lds_mode = atoi(ev) != 0;
     if (const char* ev = getenv("EXTRACK_TH_NO_GEN_SINGLE")) c->th_no_gen_single = atoi(ev) != 0;
     if (const char* ev = getenv("EXTRACK_TH_PAIR_LANES")) c->th_pair_lanes = atoi(ev);
@@ -177,6 +179,15 @@ extern "C" void extrack_destroy(extrack_ctx* ctx)
     extrack_clear_buckets(ctx);
     if (ctx->d_base_tab) (void)hipFree(ctx->d_base_tab);
     if (ctx->d_off_tab) (void)hipFree(ctx->d_off_tab);
+    if (ctx->alt_d_th_ws) (void)hipFree(ctx->alt_d_th_ws);
+    if (ctx->alt_h_th_status) (void)hipHostFree(ctx->alt_h_th_status);
+    if (ctx->alt_d_th_status) (void)hipFree(ctx->alt_d_th_status);
+    if (ctx->alt_d_th_desc) (void)hipFree(ctx->alt_d_th_desc);
+    if (ctx->alt_d_th_cend) (void)hipFree(ctx->alt_d_th_cend);
+    for (int i = 0; i < 2; ++i)
+        if (ctx->th_streams[i]) (void)hipStreamDestroy(ctx->th_streams[i]);
+    for (int i = 0; i < 3; ++i)
+        if (ctx->th_ev[i]) (void)hipEventDestroy(ctx->th_ev[i]);
     if (ctx->d_th_ws) (void)hipFree(ctx->d_th_ws);
     if (ctx->h_th_status) (void)hipHostFree(ctx->h_th_status);
     if (ctx->d_th_status) (void)hipFree(ctx->d_th_status);
@@ -805,8 +816,34 @@ static int xt_th_chunk_blobs(extrack_ctx* ctx, const extrack_model* m, const std
 // One launch group of a threshold-fusion evaluation: all buckets that share (dims, sigma dims) are served by ONE plan launch
 // and ONE apply launch through a device table of bucket descriptors (a real dataset has one bucket per track length; the plan
 // kernel of a single small bucket could not fill the GPU and its latency would add up bucket after bucket).
+// Two sets of per-launch buffers (chunk status, bucket descriptors, chunk prefix, plan workspace) and two side streams, for evaluations
+// that run two launch groups concurrently: swap = make the other set the current one.
+static void xt_th_swap_slot(extrack_ctx* ctx)
+{
+    std::swap(ctx->h_th_status, ctx->alt_h_th_status);
+    std::swap(ctx->d_th_status, ctx->alt_d_th_status);
+    std::swap(ctx->th_status_cap, ctx->alt_th_status_cap);
+    std::swap(ctx->d_th_desc, ctx->alt_d_th_desc);
+    std::swap(ctx->th_desc_cap, ctx->alt_th_desc_cap);
+    std::swap(ctx->d_th_cend, ctx->alt_d_th_cend);
+    std::swap(ctx->th_cend_cap, ctx->alt_th_cend_cap);
+    std::swap(ctx->d_th_ws, ctx->alt_d_th_ws);
+    std::swap(ctx->th_ws_cap, ctx->alt_th_ws_cap);
+}
+static int xt_th_split_streams(extrack_ctx* ctx)
+{
+    if (ctx->th_streams[0]) return EXTRACK_OK;
+    for (int i = 0; i < 2; ++i) XT_HIP(ctx, hipStreamCreateWithFlags(&ctx->th_streams[i], hipStreamNonBlocking));
+    for (int i = 0; i < 3; ++i) XT_HIP(ctx, hipEventCreateWithFlags(&ctx->th_ev[i], hipEventDisableTiming));
+    return EXTRACK_OK;
+}
+
+// `between`: called once, after the plan kernel of this group has been launched and before the host waits for it - the caller uses it to
+// run ANOTHER group (on another stream, with the other set of launch buffers) while this group's plan - a serial walk over the positions
+// of its longest chunk - is in flight.
 static int xt_th_run_group(extrack_ctx* ctx, const extrack_model* m, const std::vector<XtBucket*>& bks, double threshold, int32_t max_nb_states,
-                           int32_t chunk, int G, bool per_track, size_t& poff, const std::vector<int64_t>* chunk_base)
+                           int32_t chunk, int G, bool per_track, size_t& poff, const std::vector<int64_t>* chunk_base,
+                           const std::function<int()>* between = nullptr)
 {
     const int S = m->n_states, NS = m->nb_substeps, F = m->frame_len;
     const XtBucket& b0 = *bks[0];
@@ -968,6 +1005,11 @@ static int xt_th_run_group(extrack_ctx* ctx, const extrack_model* m, const std::
 #undef XT_TH_PLAN_CALL
         if (e != hipSuccess) return xt_fail(ctx, EXTRACK_E_HIP, std::string("plan kernel launch: ") + hipGetErrorString(e));
         XT_HIP(ctx, hipMemcpyAsync(ctx->h_th_status, ctx->d_th_status, (size_t)a.nchunks * 4 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+        if (between) {
+            const std::function<int()>* f = between;
+            between = nullptr;
+            if ((rc = (*f)())) return rc;
+        }
         XT_HIP(ctx, hipStreamSynchronize(ctx->stream));
         int over = 0, maxE = 0;
         maxG = sumE = 0;
@@ -978,8 +1020,11 @@ static int xt_th_run_group(extrack_ctx* ctx, const extrack_model* m, const std::
             sumE = std::max(sumE, ctx->h_th_status[(size_t)c * 4 + 3]);
         }
         if (!over) {
-            ctx->th_learnP = maxG + maxG / 4 + 2;
-            ctx->th_learnE = maxE + maxE / 4 + 2;
+            const int lp = maxG + maxG / 4 + 2, le = maxE + maxE / 4 + 2;
+            ctx->th_learnP = ctx->th_split_active ? std::max(ctx->th_learnP_split, lp) : lp;
+            ctx->th_learnE = ctx->th_split_active ? std::max(ctx->th_learnE_split, le) : le;
+            ctx->th_learnP_split = ctx->th_learnP;
+            ctx->th_learnE_split = ctx->th_learnE;
             break;
         }
         if (lds_mode) {  // the learned LDS capacities were too small for these parameters: redo with the global workspace
@@ -1132,7 +1177,51 @@ static int xt_loglik_th_enqueue(extrack_ctx* ctx, const extrack_model* m, double
         size_t jn = i;
         std::vector<XtBucket*> grp;
         while (jn < order.size() && order[jn]->D == order[i]->D && order[jn]->KS == order[i]->KS) grp.push_back(order[jn++]);
-        if ((rc = xt_th_run_group(ctx, m, grp, threshold, max_nb_states, chunk, G, per_track, poff, dt_mode ? &chunk_base : nullptr))) return rc;
+        // Large multi-bucket group in steady state (capacities learned, buffers allocated): the long buckets' plan - whose critical path is
+        // the serial walk over the longest chunk, during which most of the chip idles - runs on one stream while the short buckets are
+        // planned AND applied on a second one.
+        int64_t gchunks = 0;
+        for (XtBucket* b : grp) gchunks += (b->N + chunk - 1) / chunk;
+        size_t nlong = 0;
+        while (nlong < grp.size() && grp[nlong]->L * 100 > grp[0]->L * ctx->th_split_pct) ++nlong;
+        const bool split = !ctx->th_no_split && !dt_mode && grp.size() >= 4 && nlong >= 1 && nlong < grp.size() && gchunks >= ctx->n_cu &&
+                           ctx->th_learnE > 0;
+        if (!split) {
+            if ((rc = xt_th_run_group(ctx, m, grp, threshold, max_nb_states, chunk, G, per_track, poff, dt_mode ? &chunk_base : nullptr))) return rc;
+        } else {
+            if ((rc = xt_th_split_streams(ctx))) return rc;
+            // partial sums of both apply launches: reserved up front (a reallocation while the other stream's kernel writes would be fatal)
+            if ((rc = xt_grow_partials(ctx, poff + (size_t)gchunks + 2 * (size_t)ctx->n_cu * 8 * ctx->th_oversub * 2 + 64))) return rc;
+            std::vector<XtBucket*> lg(grp.begin(), grp.begin() + nlong), sg(grp.begin() + nlong, grp.end());
+            hipStream_t main_stream = ctx->stream;
+            XT_HIP(ctx, hipEventRecord(ctx->th_ev[0], main_stream));
+            XT_HIP(ctx, hipStreamWaitEvent(ctx->th_streams[0], ctx->th_ev[0], 0));
+            XT_HIP(ctx, hipStreamWaitEvent(ctx->th_streams[1], ctx->th_ev[0], 0));
+            ctx->th_split_active = true;
+            ctx->th_learnP_split = ctx->th_learnE_split = 0;
+            const std::function<int()> other = [&]() -> int {
+                xt_th_swap_slot(ctx);
+                ctx->stream = ctx->th_streams[1];
+                const int r2 = xt_th_run_group(ctx, m, sg, threshold, max_nb_states, chunk, G, per_track, poff, nullptr);
+                ctx->stream = ctx->th_streams[0];
+                xt_th_swap_slot(ctx);
+                return r2;
+            };
+            ctx->stream = ctx->th_streams[0];
+            rc = xt_th_run_group(ctx, m, lg, threshold, max_nb_states, chunk, G, per_track, poff, nullptr, &other);
+            ctx->stream = main_stream;
+            ctx->th_split_active = false;
+            // join (also after a failure: nothing may be left running on the side streams)
+            (void)hipEventRecord(ctx->th_ev[1], ctx->th_streams[0]);
+            (void)hipEventRecord(ctx->th_ev[2], ctx->th_streams[1]);
+            (void)hipStreamWaitEvent(main_stream, ctx->th_ev[1], 0);
+            (void)hipStreamWaitEvent(main_stream, ctx->th_ev[2], 0);
+            if (rc) {
+                (void)hipStreamSynchronize(ctx->th_streams[0]);
+                (void)hipStreamSynchronize(ctx->th_streams[1]);
+                return rc;
+            }
+        }
         i = jn;
     }
     XT_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
