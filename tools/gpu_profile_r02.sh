@@ -50,5 +50,5 @@ for f in glob.glob(root + "/trace/**/*kernel_trace.csv", recursive=True):
         out.write("  all (us): " + " ".join("%.0f" % (d / 1e3) for d in big) + "\n")
 PY
 cp $OUT/trace/*/*kernel_stats.csv $OUT/kernel_stats.csv 2>/dev/null || cp $(find $OUT/trace -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
-tail -1 $OUT/bench_trace.log > $OUT/bench_line.json
+grep "^{" $OUT/bench_trace.log | tail -1 > $OUT/bench_line.json
 cat $OUT/headline_timed_launches.txt; head -14 $OUT/kernel_stats.csv
