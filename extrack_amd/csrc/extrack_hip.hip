@@ -115,7 +115,14 @@ extern "C" int extrack_create(int device_id, extrack_ctx** out)
     }
     if (const char* ev = getenv("EXTRACK_TH_PLAN_BS")) c->th_plan_bs = atoi(ev);
     if (const char* ev = getenv("EXTRACK_TH_NO_SPLIT")) c->th_no_split = atoi(ev) != 0;
-    if (const char* ev = getenv("EXTRACK_TH_SPLIT_PCT")) c->th_split_pct = atoi(ev);
+    if (const char* ev = getenv("EXTRACK_TH_SPLIT_PCT")) {
+        int hi = 0, lo = 0;
+        const int n = sscanf(ev, "%d,%d", &hi, &lo);
+        if (n >= 1 && hi > 0 && hi < 100) {
+            c->th_split_pct[0] = hi;
+            c->th_split_pct[1] = (n == 2 && lo > 0 && lo < hi) ? lo : 0;
+        }
+    }
     if (const char* ev = getenv("EXTRACK_TH_STAGE_LDS")) c->th_stage_in_lds_mode = atoi(ev) != 0;
     if (const char* ev = getenv("EXTRACK_TH_NO_GEN_SINGLE")) c->th_no_gen_single = atoi(ev) != 0;
     if (const char* ev = getenv("EXTRACK_TH_PAIR_LANES")) c->th_pair_lanes = atoi(ev);
@@ -179,14 +186,18 @@ extern "C" void extrack_destroy(extrack_ctx* ctx)
     extrack_clear_buckets(ctx);
     if (ctx->d_base_tab) (void)hipFree(ctx->d_base_tab);
     if (ctx->d_off_tab) (void)hipFree(ctx->d_off_tab);
-    if (ctx->alt_d_th_ws) (void)hipFree(ctx->alt_d_th_ws);
-    if (ctx->alt_h_th_status) (void)hipHostFree(ctx->alt_h_th_status);
-    if (ctx->alt_d_th_status) (void)hipFree(ctx->alt_d_th_status);
-    if (ctx->alt_d_th_desc) (void)hipFree(ctx->alt_d_th_desc);
-    if (ctx->alt_d_th_cend) (void)hipFree(ctx->alt_d_th_cend);
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < extrack_ctx::TH_SLOTS; ++i) {
+        if (i == ctx->th_cur_slot) continue;  // the current set lives in the fields freed below
+        extrack_ctx::ThSlot& sl = ctx->th_slot[i];
+        if (sl.d_ws) (void)hipFree(sl.d_ws);
+        if (sl.h_status) (void)hipHostFree(sl.h_status);
+        if (sl.d_status) (void)hipFree(sl.d_status);
+        if (sl.d_desc) (void)hipFree(sl.d_desc);
+        if (sl.d_cend) (void)hipFree(sl.d_cend);
+    }
+    for (int i = 0; i < extrack_ctx::TH_SLOTS; ++i)
         if (ctx->th_streams[i]) (void)hipStreamDestroy(ctx->th_streams[i]);
-    for (int i = 0; i < 3; ++i)
+    for (int i = 0; i < extrack_ctx::TH_SLOTS + 1; ++i)
         if (ctx->th_ev[i]) (void)hipEventDestroy(ctx->th_ev[i]);
     if (ctx->d_th_ws) (void)hipFree(ctx->d_th_ws);
     if (ctx->h_th_status) (void)hipHostFree(ctx->h_th_status);
@@ -816,25 +827,38 @@ static int xt_th_chunk_blobs(extrack_ctx* ctx, const extrack_model* m, const std
 // One launch group of a threshold-fusion evaluation: all buckets that share (dims, sigma dims) are served by ONE plan launch
 // and ONE apply launch through a device table of bucket descriptors (a real dataset has one bucket per track length; the plan
 // kernel of a single small bucket could not fill the GPU and its latency would add up bucket after bucket).
-// Two sets of per-launch buffers (chunk status, bucket descriptors, chunk prefix, plan workspace) and two side streams, for evaluations
-// that run two launch groups concurrently: swap = make the other set the current one.
-static void xt_th_swap_slot(extrack_ctx* ctx)
+// Several sets of per-launch buffers (chunk status, bucket descriptors, chunk prefix, plan workspace) and side streams, for evaluations
+// that run several launch groups concurrently: xt_th_use_slot parks the current set and makes set j (and its stream) the current one.
+static void xt_th_use_slot(extrack_ctx* ctx, int j)
 {
-    std::swap(ctx->h_th_status, ctx->alt_h_th_status);
-    std::swap(ctx->d_th_status, ctx->alt_d_th_status);
-    std::swap(ctx->th_status_cap, ctx->alt_th_status_cap);
-    std::swap(ctx->d_th_desc, ctx->alt_d_th_desc);
-    std::swap(ctx->th_desc_cap, ctx->alt_th_desc_cap);
-    std::swap(ctx->d_th_cend, ctx->alt_d_th_cend);
-    std::swap(ctx->th_cend_cap, ctx->alt_th_cend_cap);
-    std::swap(ctx->d_th_ws, ctx->alt_d_th_ws);
-    std::swap(ctx->th_ws_cap, ctx->alt_th_ws_cap);
+    extrack_ctx::ThSlot& cur = ctx->th_slot[ctx->th_cur_slot];
+    cur.h_status = ctx->h_th_status;
+    cur.d_status = ctx->d_th_status;
+    cur.status_cap = ctx->th_status_cap;
+    cur.d_desc = ctx->d_th_desc;
+    cur.desc_cap = ctx->th_desc_cap;
+    cur.d_cend = ctx->d_th_cend;
+    cur.cend_cap = ctx->th_cend_cap;
+    cur.d_ws = ctx->d_th_ws;
+    cur.ws_cap = ctx->th_ws_cap;
+    const extrack_ctx::ThSlot& nx = ctx->th_slot[j];
+    ctx->h_th_status = nx.h_status;
+    ctx->d_th_status = nx.d_status;
+    ctx->th_status_cap = nx.status_cap;
+    ctx->d_th_desc = nx.d_desc;
+    ctx->th_desc_cap = nx.desc_cap;
+    ctx->d_th_cend = nx.d_cend;
+    ctx->th_cend_cap = nx.cend_cap;
+    ctx->d_th_ws = nx.d_ws;
+    ctx->th_ws_cap = nx.ws_cap;
+    ctx->th_cur_slot = j;
+    ctx->stream = ctx->th_streams[j];
 }
 static int xt_th_split_streams(extrack_ctx* ctx)
 {
     if (ctx->th_streams[0]) return EXTRACK_OK;
-    for (int i = 0; i < 2; ++i) XT_HIP(ctx, hipStreamCreateWithFlags(&ctx->th_streams[i], hipStreamNonBlocking));
-    for (int i = 0; i < 3; ++i) XT_HIP(ctx, hipEventCreateWithFlags(&ctx->th_ev[i], hipEventDisableTiming));
+    for (int i = 0; i < extrack_ctx::TH_SLOTS; ++i) XT_HIP(ctx, hipStreamCreateWithFlags(&ctx->th_streams[i], hipStreamNonBlocking));
+    for (int i = 0; i < extrack_ctx::TH_SLOTS + 1; ++i) XT_HIP(ctx, hipEventCreateWithFlags(&ctx->th_ev[i], hipEventDisableTiming));
     return EXTRACK_OK;
 }
 
@@ -1182,43 +1206,52 @@ static int xt_loglik_th_enqueue(extrack_ctx* ctx, const extrack_model* m, double
         // planned AND applied on a second one.
         int64_t gchunks = 0;
         for (XtBucket* b : grp) gchunks += (b->N + chunk - 1) / chunk;
-        size_t nlong = 0;
-        while (nlong < grp.size() && grp[nlong]->L * 100 > grp[0]->L * ctx->th_split_pct) ++nlong;
-        const bool split = !ctx->th_no_split && !dt_mode && grp.size() >= 4 && nlong >= 1 && nlong < grp.size() && gchunks >= ctx->n_cu &&
-                           ctx->th_learnE > 0;
+        // segments by track length (the group is sorted longest first)
+        std::vector<std::vector<XtBucket*>> seg;
+        {
+            size_t k0 = 0;
+            for (int t = 0; t < 2 && ctx->th_split_pct[t] > 0; ++t) {
+                size_t k1 = k0;
+                while (k1 < grp.size() && grp[k1]->L * 100 > grp[0]->L * ctx->th_split_pct[t]) ++k1;
+                if (k1 > k0) seg.emplace_back(grp.begin() + k0, grp.begin() + k1);
+                k0 = k1;
+            }
+            if (k0 < grp.size()) seg.emplace_back(grp.begin() + k0, grp.end());
+        }
+        const bool split = !ctx->th_no_split && !dt_mode && grp.size() >= 4 && seg.size() >= 2 && gchunks >= ctx->n_cu && ctx->th_learnE > 0;
         if (!split) {
             if ((rc = xt_th_run_group(ctx, m, grp, threshold, max_nb_states, chunk, G, per_track, poff, dt_mode ? &chunk_base : nullptr))) return rc;
         } else {
             if ((rc = xt_th_split_streams(ctx))) return rc;
-            // partial sums of both apply launches: reserved up front (a reallocation while the other stream's kernel writes would be fatal)
-            if ((rc = xt_grow_partials(ctx, poff + (size_t)gchunks + 2 * (size_t)ctx->n_cu * 8 * ctx->th_oversub * 2 + 64))) return rc;
-            std::vector<XtBucket*> lg(grp.begin(), grp.begin() + nlong), sg(grp.begin() + nlong, grp.end());
+            const int nseg = (int)seg.size();
+            // partial sums of all apply launches: reserved up front (a reallocation while another stream's kernel writes would be fatal)
+            if ((rc = xt_grow_partials(ctx, poff + (size_t)gchunks + (size_t)nseg * ((size_t)ctx->n_cu * 8 * ctx->th_oversub * 2 + 64)))) return rc;
             hipStream_t main_stream = ctx->stream;
-            XT_HIP(ctx, hipEventRecord(ctx->th_ev[0], main_stream));
-            XT_HIP(ctx, hipStreamWaitEvent(ctx->th_streams[0], ctx->th_ev[0], 0));
-            XT_HIP(ctx, hipStreamWaitEvent(ctx->th_streams[1], ctx->th_ev[0], 0));
+            XT_HIP(ctx, hipEventRecord(ctx->th_ev[extrack_ctx::TH_SLOTS], main_stream));
+            for (int j = 0; j < nseg; ++j) XT_HIP(ctx, hipStreamWaitEvent(ctx->th_streams[j], ctx->th_ev[extrack_ctx::TH_SLOTS], 0));
             ctx->th_split_active = true;
             ctx->th_learnP_split = ctx->th_learnE_split = 0;
-            const std::function<int()> other = [&]() -> int {
-                xt_th_swap_slot(ctx);
-                ctx->stream = ctx->th_streams[1];
-                const int r2 = xt_th_run_group(ctx, m, sg, threshold, max_nb_states, chunk, G, per_track, poff, nullptr);
-                ctx->stream = ctx->th_streams[0];
-                xt_th_swap_slot(ctx);
-                return r2;
+            // segment j on stream j with buffer set j; while its plan is in flight, segment j + 1 (and so on) is planned and applied
+            std::function<int(int)> run_seg = [&](int j) -> int {
+                xt_th_use_slot(ctx, j);
+                const std::function<int()> next = [&, j]() -> int {
+                    const int r2 = run_seg(j + 1);
+                    xt_th_use_slot(ctx, j);
+                    return r2;
+                };
+                return xt_th_run_group(ctx, m, seg[j], threshold, max_nb_states, chunk, G, per_track, poff, nullptr, j + 1 < nseg ? &next : nullptr);
             };
-            ctx->stream = ctx->th_streams[0];
-            rc = xt_th_run_group(ctx, m, lg, threshold, max_nb_states, chunk, G, per_track, poff, nullptr, &other);
+            rc = run_seg(0);
+            xt_th_use_slot(ctx, 0);
             ctx->stream = main_stream;
             ctx->th_split_active = false;
             // join (also after a failure: nothing may be left running on the side streams)
-            (void)hipEventRecord(ctx->th_ev[1], ctx->th_streams[0]);
-            (void)hipEventRecord(ctx->th_ev[2], ctx->th_streams[1]);
-            (void)hipStreamWaitEvent(main_stream, ctx->th_ev[1], 0);
-            (void)hipStreamWaitEvent(main_stream, ctx->th_ev[2], 0);
+            for (int j = 0; j < nseg; ++j) {
+                (void)hipEventRecord(ctx->th_ev[j], ctx->th_streams[j]);
+                (void)hipStreamWaitEvent(main_stream, ctx->th_ev[j], 0);
+            }
             if (rc) {
-                (void)hipStreamSynchronize(ctx->th_streams[0]);
-                (void)hipStreamSynchronize(ctx->th_streams[1]);
+                for (int j = 0; j < nseg; ++j) (void)hipStreamSynchronize(ctx->th_streams[j]);
                 return rc;
             }
         }

@@ -180,21 +180,28 @@ struct extrack_ctx {
     size_t th_desc_cap = 0;
     int32_t* d_th_cend = nullptr;     // chunk prefix of a launch group
     size_t th_cend_cap = 0;
-    // second set of the per-launch buffers above + side streams: two launch groups of one evaluation in flight (xt_th_swap_slot)
-    int32_t* alt_h_th_status = nullptr;
-    int32_t* alt_d_th_status = nullptr;
-    size_t alt_th_status_cap = 0;
-    XtThBucket* alt_d_th_desc = nullptr;
-    size_t alt_th_desc_cap = 0;
-    int32_t* alt_d_th_cend = nullptr;
-    size_t alt_th_cend_cap = 0;
-    double* alt_d_th_ws = nullptr;
-    size_t alt_th_ws_cap = 0;
-    hipStream_t th_streams[2] = {nullptr, nullptr};
-    hipEvent_t th_ev[3] = {nullptr, nullptr, nullptr};
-    bool th_split_active = false, th_no_split = false;  // EXTRACK_TH_NO_SPLIT=1: never run two launch groups concurrently
+    // more sets of the per-launch buffers above + side streams: several launch groups of one evaluation in flight (xt_th_use_slot)
+    struct ThSlot {
+        int32_t* h_status = nullptr;
+        int32_t* d_status = nullptr;
+        size_t status_cap = 0;
+        XtThBucket* d_desc = nullptr;
+        size_t desc_cap = 0;
+        int32_t* d_cend = nullptr;
+        size_t cend_cap = 0;
+        double* d_ws = nullptr;
+        size_t ws_cap = 0;
+    };
+    static constexpr int TH_SLOTS = 3;
+    ThSlot th_slot[TH_SLOTS];   // parked sets; the current one lives in the fields above
+    int th_cur_slot = 0;
+    hipStream_t th_streams[TH_SLOTS] = {nullptr, nullptr, nullptr};
+    hipEvent_t th_ev[TH_SLOTS + 1] = {nullptr, nullptr, nullptr, nullptr};
+    bool th_split_active = false, th_no_split = false;  // EXTRACK_TH_NO_SPLIT=1: never run several launch groups concurrently
     int th_learnP_split = 0, th_learnE_split = 0;
-    int th_split_pct = 50;  // buckets longer than this percentage of the longest track length form the 'long' group (EXTRACK_TH_SPLIT_PCT)
+    // buckets longer than th_split_pct[0] % of the longest track length form the first group, longer than th_split_pct[1] % the second
+    // (0: no third group), the rest the last (EXTRACK_TH_SPLIT_PCT="hi,lo")
+    int th_split_pct[2] = {50, 25};
     float th_plan_ms = 0.f;
     int th_force_single = 0;
     int th_pair_lanes = 4;  // EXTRACK_TH_PAIR_LANES
