@@ -1,17 +1,21 @@
 #!/bin/bash
-# Rebuild libextrack_hip.so with the resource-usage remarks and print a table of the fast-path kernels.
-cd /root/repo/extrack_amd/csrc || exit 1
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Xclang -target-feature -Xclang -load-store-opt -o ../libextrack_hip.so extrack_hip.hip -Rpass-analysis=kernel-resource-usage 2> /tmp/build.log
-rc=$?
-grep -E " error" /tmp/build.log | head -10
+# Register / scratch / occupancy table of the kernels (compiler remarks); compiles into /tmp, the in-tree library is not touched.
+#   tools/build_report.sh [regex on the mangled kernel name]      e.g.  tools/build_report.sh 'xt_th_apply'
+cd "$(dirname "$0")/../extrack_amd/csrc" || exit 1
+for u in extrack_hip extrack_grad extrack_hist; do
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c -o /tmp/xt_report_$u.o $u.hip -Rpass-analysis=kernel-resource-usage 2> /tmp/xt_report_$u.log &
+done
+wait
 python3 - "$@" <<'PY'
 import re, sys
-pat = sys.argv[1] if len(sys.argv) > 1 else r'_Z15xt_ll_s2_kernelILi(\d)ELi2ELi(\d)EE'
-txt = open('/tmp/build.log').read()
-for b in txt.split('Function Name:')[1:]:
-    name = b.split()[0]
-    if not re.match(pat, name): continue
-    g = lambda k: re.search(k + r':\s*(\d+)', b).group(1)
-    print(name[:60].ljust(60), 'VGPR', g('VGPRs'), 'SGPR', g('SGPRs'), 'scratch', g(r'ScratchSize \[bytes/lane\]'), 'occ', g(r'Occupancy \[waves/SIMD\]'))
+pat = sys.argv[1] if len(sys.argv) > 1 else r'xt_ll_s2_kernelILi6ELi2ELi1|xt_th_|xt_grad|xt_hist|xt_entry_kernelILi64ELi2ELi1ELi256'
+for u in ("extrack_hip", "extrack_grad", "extrack_hist"):
+    txt = open('/tmp/xt_report_%s.log' % u).read()
+    for b in txt.split('Function Name:')[1:]:
+        name = b.split()[0]
+        if not re.search(pat, name):
+            continue
+        g = lambda k: re.search(k + r':\s*(\d+)', b).group(1)
+        print(name[:72].ljust(72), 'VGPR', g('VGPRs'), 'AGPR', g('AGPRs'), 'SGPR spill', g('SGPRs Spill'), 'scratch', g(r'ScratchSize \[bytes/lane\]'),
+              'occ', g(r'Occupancy \[waves/SIMD\]'))
 PY
-exit $rc
