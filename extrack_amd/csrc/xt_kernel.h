@@ -354,10 +354,30 @@ XT_HD void xt_track_body(const XtKernelArgs& a, Ctx& cx)
             }
             cx.sync();
             if (PREDS && do_pred) {
-                if (act) {
-                    const int pem = pe[par];
+                const int pem = act ? pe[par] : 0;
+                if ((NG & (NG - 1)) == 0 && NG >= 2) {
+                    // a track's groups are an aligned power-of-two range of lanes (or whole wavefronts): sum inside the range first, ONE
+                    // LDS atomic per range and state instead of one per thread (hundreds of threads hammering S addresses serialise in
+                    // the LDS).  Every thread of the workgroup takes part in the lane exchange; idle slots contribute zeros.
+                    const int gl = NG >= 64 ? 64 : NG;
+                    for (int Q = 0; Q < G; ++Q) {
+                        const double v = (act && pq[Q].m != 0.0) ? xt_ldexp(pq[Q].m, pq[Q].e - pem) : 0.0;
+                        double sQ;
+                        switch (gl) {
+                            case 64: sQ = cx.template group_sum_f64<64>(v); break;
+                            case 32: sQ = cx.template group_sum_f64<32>(v); break;
+                            case 16: sQ = cx.template group_sum_f64<16>(v); break;
+                            case 8: sQ = cx.template group_sum_f64<8>(v); break;
+                            case 4: sQ = cx.template group_sum_f64<4>(v); break;
+                            default: sQ = cx.template group_sum_f64<2>(v); break;
+                        }
+                        if (act && (g & (gl - 1)) == 0 && sQ != 0.0) cx.atomic_add_f64(&pacc[par * S + Q], sQ);
+                    }
+                } else if (act) {
                     for (int Q = 0; Q < G; ++Q)
                         if (pq[Q].m != 0.0) cx.atomic_add_f64(&pacc[par * S + Q], xt_ldexp(pq[Q].m, pq[Q].e - pem));
+                }
+                if (act) {
                     if (g < S) pacc[(par ^ 1) * S + g] = 0.0;
                     if (g == 0) pe[par ^ 1] = XT_EMIN;
                 }

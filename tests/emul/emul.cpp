@@ -165,18 +165,26 @@ struct EmulLauncher {
     template <int G_, int D, int K, bool PREDS>
     bool run()
     {
+        const int nw = (threads + 63) / 64;
+        if (threads % 64) return false;  // the posterior read-out exchanges values between the lanes of a wavefront
         for (int b = 0; b < nblocks; ++b) {
             std::vector<double> smem(lds_bytes / 8 + 16, 0.0);
             pthread_barrier_t bar;
             pthread_barrier_init(&bar, nullptr, threads);
+            std::vector<pthread_barrier_t> wb(nw);
+            std::vector<std::vector<double>> ws(nw, std::vector<double>(64, 0.0));
+            for (auto& x : wb) pthread_barrier_init(&x, nullptr, 64);
             std::vector<std::thread> th;
             for (int t = 0; t < threads; ++t)
                 th.emplace_back([&, t]() {
                     HostCtx cx{t, threads, b, nblocks, smem.data(), &bar};
+                    cx.wbar_ = &wb[t >> 6];
+                    cx.wscr_ = ws[t >> 6].data();
                     xt_track_body<G_, D, K, PREDS>(a, cx);
                 });
             for (auto& x : th) x.join();
             pthread_barrier_destroy(&bar);
+            for (auto& x : wb) pthread_barrier_destroy(&x);
         }
         return true;
     }
