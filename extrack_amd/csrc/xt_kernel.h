@@ -157,6 +157,21 @@ XT_HD void xt_track_body(const XtKernelArgs& a, Ctx& cx)
     const int stay_from = a.min_len > 2 ? a.min_len : 2;
 
     double block_ll = 0.0;  // meaningful in thread g == 0 of each slot
+    // Posterior sums: when a track's groups are an aligned power-of-two range of lanes (or whole wavefronts) the per-thread terms are
+    // summed inside that range first (DevCtx::group_sum_f64) and ONE thread per range issues the LDS atomic - hundreds of threads
+    // hammering S addresses serialise in the LDS.  Every thread of the workgroup takes part in the lane exchange (idle slots add zeros).
+    const bool lane_sums = PREDS && (NG & (NG - 1)) == 0 && NG >= 2;
+    const int gl = NG >= 64 ? 64 : NG;
+    auto lane_sum = [&](double v) -> double {
+        switch (gl) {
+            case 64: return cx.template group_sum_f64<64>(v);
+            case 32: return cx.template group_sum_f64<32>(v);
+            case 16: return cx.template group_sum_f64<16>(v);
+            case 8: return cx.template group_sum_f64<8>(v);
+            case 4: return cx.template group_sum_f64<4>(v);
+            default: return cx.template group_sum_f64<2>(v);
+        }
+    };
     const int64_t nbatch = (b.N + a.TPB - 1) / a.TPB;
     if (tvalid && g == 0) red_e[1] = 0;
     cx.sync();
@@ -355,22 +370,9 @@ XT_HD void xt_track_body(const XtKernelArgs& a, Ctx& cx)
             cx.sync();
             if (PREDS && do_pred) {
                 const int pem = act ? pe[par] : 0;
-                if ((NG & (NG - 1)) == 0 && NG >= 2) {
-                    // a track's groups are an aligned power-of-two range of lanes (or whole wavefronts): sum inside the range first, ONE
-                    // LDS atomic per range and state instead of one per thread (hundreds of threads hammering S addresses serialise in
-                    // the LDS).  Every thread of the workgroup takes part in the lane exchange; idle slots contribute zeros.
-                    const int gl = NG >= 64 ? 64 : NG;
+                if (lane_sums) {
                     for (int Q = 0; Q < G; ++Q) {
-                        const double v = (act && pq[Q].m != 0.0) ? xt_ldexp(pq[Q].m, pq[Q].e - pem) : 0.0;
-                        double sQ;
-                        switch (gl) {
-                            case 64: sQ = cx.template group_sum_f64<64>(v); break;
-                            case 32: sQ = cx.template group_sum_f64<32>(v); break;
-                            case 16: sQ = cx.template group_sum_f64<16>(v); break;
-                            case 8: sQ = cx.template group_sum_f64<8>(v); break;
-                            case 4: sQ = cx.template group_sum_f64<4>(v); break;
-                            default: sQ = cx.template group_sum_f64<2>(v); break;
-                        }
+                        const double sQ = lane_sum((act && pq[Q].m != 0.0) ? xt_ldexp(pq[Q].m, pq[Q].e - pem) : 0.0);
                         if (act && (g & (gl - 1)) == 0 && sQ != 0.0) cx.atomic_add_f64(&pacc[par * S + Q], sQ);
                     }
                 } else if (act) {
@@ -453,16 +455,28 @@ XT_HD void xt_track_body(const XtKernelArgs& a, Ctx& cx)
         }
         cx.sync();  // all reads of the state are done: zm can be reused as reduction scratch
         int fe = XT_EMIN;
+        if (act) fe = red_e[0];
+        if (lane_sums) {
+            // column 0 = newest digit q; column F = fused slot digit Q: the same S addresses for every thread of the track
+            for (int q = 0; q < G; ++q) {
+                const double s0 = lane_sum((act && accq[q].m != 0.0) ? xt_ldexp(accq[q].m, accq[q].e - fe) : 0.0);
+                const double sF = lane_sum((act && L - 1 >= F && accQ[q].m != 0.0) ? xt_ldexp(accQ[q].m, accQ[q].e - fe) : 0.0);
+                if (act && (g & (gl - 1)) == 0) {
+                    if (s0 != 0.0) cx.atomic_add_f64(&facc[0 * S + q], s0);
+                    if (sF != 0.0) cx.atomic_add_f64(&facc[F * S + q], sF);
+                }
+            }
+        }
         if (act) {
-            fe = red_e[0];
             zm[g] = tot.m != 0.0 ? xt_ldexp(tot.m, tot.e - fe) : 0.0;
             if (PREDS) {
                 const double al = zm[g];
-                // column 0 = newest digit q; column F = fused slot digit Q; columns 1..F-1 = digits of g
-                for (int q = 0; q < G; ++q) {
-                    if (accq[q].m != 0.0) cx.atomic_add_f64(&facc[0 * S + q], xt_ldexp(accq[q].m, accq[q].e - fe));
-                    if (L - 1 >= F && accQ[q].m != 0.0) cx.atomic_add_f64(&facc[F * S + q], xt_ldexp(accQ[q].m, accQ[q].e - fe));
-                }
+                // columns 1..F-1 = digits of g
+                if (!lane_sums)
+                    for (int q = 0; q < G; ++q) {
+                        if (accq[q].m != 0.0) cx.atomic_add_f64(&facc[0 * S + q], xt_ldexp(accq[q].m, accq[q].e - fe));
+                        if (L - 1 >= F && accQ[q].m != 0.0) cx.atomic_add_f64(&facc[F * S + q], xt_ldexp(accQ[q].m, accQ[q].e - fe));
+                    }
                 if (al != 0.0)
                     for (int j = 1; j <= F - 1 && j <= L - 1; ++j) {
                         const int dig = (g / a.pw[F - j - 1]) % S;
