@@ -248,27 +248,40 @@ XT_HD void xt_hist_body(const XtHistArgs& a, Ctx& cx)
             if (prune) {
                 int NS2 = 1;
                 while (NS2 < nc) NS2 <<= 1;
-                for (int k2 = 2; k2 <= NS2; k2 <<= 1)
-                    for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
-                        for (int t = tid; t < NS2; t += nt) {
-                            const int u = t ^ j2;
-                            if (u > t) {
-                                const bool desc = (t & k2) == 0;
-                                const double ka = key[t], kb = key[u];
-                                const int ia = idx[t], ib = idx[u];
-                                // order: key descending, equal keys by candidate index ascending (a total order: the result does
-                                // not depend on the sorting network)
-                                const bool a_first = ka > kb || (ka == kb && ia < ib);
-                                if (desc ? !a_first : a_first) {
-                                    key[t] = kb;
-                                    key[u] = ka;
-                                    idx[t] = ib;
-                                    idx[u] = ia;
-                                }
-                            }
-                        }
+                // One compare-exchange per thread and pair (pair p of a stage with partner distance j2: elements t and t + j2, t = p with a
+                // zero bit inserted at j2).  Stages with j2 <= 64 stay inside a 128-element block that ONE wavefront owns (64 consecutive
+                // pairs), so they need no workgroup barrier - LDS operations of a wavefront execute in order; only the few stages with a
+                // larger distance (and the hand-over to them) synchronise the workgroup: 9 barriers instead of 55 for 1024 candidates.
+                const int NP2 = NS2 >> 1;
+                auto cmpx = [&](int pp, int j2, int k2) {
+                    const int t = ((pp & ~(j2 - 1)) << 1) | (pp & (j2 - 1)), u = t + j2;
+                    const bool desc = (t & k2) == 0;
+                    const double ka = key[t], kb = key[u];
+                    const int ia = idx[t], ib = idx[u];
+                    // order: key descending, equal keys by candidate index ascending (a total order: the result does not depend on
+                    // the sorting network)
+                    const bool a_first = ka > kb || (ka == kb && ia < ib);
+                    if (desc ? !a_first : a_first) {
+                        key[t] = kb;
+                        key[u] = ka;
+                        idx[t] = ib;
+                        idx[u] = ia;
+                    }
+                };
+                for (int k2 = 2; k2 <= NS2; k2 <<= 1) {
+                    int j2 = k2 >> 1;
+                    for (; j2 > 64; j2 >>= 1) {
+                        for (int pp = tid; pp < NP2; pp += nt) cmpx(pp, j2, k2);
                         cx.sync();
                     }
+                    for (int p0 = 0; p0 < NP2; p0 += nt)
+                        for (int jj = j2; jj > 0; jj >>= 1) {
+                            if (p0 + tid < NP2) cmpx(p0 + tid, jj, k2);
+                            cx.wave_sync();
+                        }
+                    if (k2 >= 128) cx.sync();
+                }
+                cx.sync();
                 nnew = a.K;
             }
             // D: gather into the other buffer

@@ -801,19 +801,7 @@ extern "C" int xt_emul_grad(const double* tracks, const double* sigma, long long
 template <int D, int K>
 static void emul_hist_run(const XtHistArgs& a, int nblocks, int threads, size_t lds_doubles)
 {
-    for (int b = 0; b < nblocks; ++b) {
-        std::vector<double> smem(lds_doubles + 16, 0.0);
-        pthread_barrier_t bar;
-        pthread_barrier_init(&bar, nullptr, threads);
-        std::vector<std::thread> th;
-        for (int t = 0; t < threads; ++t)
-            th.emplace_back([&, t]() {
-                HostCtx cx{t, threads, b, nblocks, smem.data(), &bar};
-                xt_hist_body<D, K>(a, cx);
-            });
-        for (auto& x : th) x.join();
-        pthread_barrier_destroy(&bar);
-    }
+    th_emul_blocks(nblocks, threads, lds_doubles, [&](HostCtx& cx) { xt_hist_body<D, K>(a, cx); });  // with per-wavefront barriers
 }
 
 extern "C" int xt_emul_hist(const double* tracks, const double* sigma, long long N, int L, int D, int KS, int S, int isBL, int min_l,
