@@ -27,11 +27,11 @@ __global__ void __launch_bounds__(MAXT) xt_entry_kernel(XtKernelArgs a)
     xt_entry_body<GP, D, K>(a, cx);
 }
 
-template <int D, int K, bool PREDS>
+template <int D, int K, bool PREDS, int WS = -1>
 __global__ void __launch_bounds__(1024) xt_th_plan_kernel(XtThArgs a)
 {
     DevCtx cx;
-    xt_th_plan_body<D, K, PREDS>(a, cx);
+    xt_th_plan_body<D, K, PREDS, WS>(a, cx);
 }
 
 template <int D, int K, bool UNI, bool SINGLE, bool DT>
@@ -692,9 +692,16 @@ static hipError_t xt_th_set_lds(extrack_ctx* ctx, KernT kern, size_t lds)
 template <int D, int K>
 static hipError_t xt_th_launch_plan(extrack_ctx* ctx, const XtThArgs& a, int grid, int threads, size_t lds, hipStream_t stream)
 {
-    hipError_t e = xt_th_set_lds(ctx, xt_th_plan_kernel<D, K, false>, lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((xt_th_plan_kernel<D, K, false>), dim3(grid), dim3(threads), lds, stream, a);
+    // pilot-track state in LDS / in the global workspace: two instantiations, so that the state pointers have a known address space
+    if (a.ws_lds) {
+        hipError_t e = xt_th_set_lds(ctx, xt_th_plan_kernel<D, K, false, 1>, lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((xt_th_plan_kernel<D, K, false, 1>), dim3(grid), dim3(threads), lds, stream, a);
+    } else {
+        hipError_t e = xt_th_set_lds(ctx, xt_th_plan_kernel<D, K, false, 0>, lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((xt_th_plan_kernel<D, K, false, 0>), dim3(grid), dim3(threads), lds, stream, a);
+    }
     return hipGetLastError();
 }
 

@@ -450,9 +450,12 @@ XT_HD double xt_th_l2_from_sigma(double s, int mode, const double* hdr)
 // ------------------------------------------------------------------------------------------------------------------
 // PLAN kernel body: one workgroup per chunk.
 // ------------------------------------------------------------------------------------------------------------------
-template <int D, int K, bool PREDS, class Ctx>
+// WS: where the pilot-track state lives - 1 = LDS, 0 = global workspace, -1 = decided at run time (a.ws_lds).  With a compile-time
+// WS the state pointers have a known address space (LDS loads / stores instead of flat ones in the LDS case).
+template <int D, int K, bool PREDS, int WS = -1, class Ctx>
 XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
 {
+    const bool ws_lds = WS < 0 ? (a.ws_lds != 0) : (WS == 1);
     const int S = a.S, G = a.G, NS = a.NS, F = a.F, L = a.L, capE = a.capE;
     const int tid = cx.tid(), nt = cx.nthreads();
     const int HM = xt_th_hm(F, NS);                 // history entries kept per sequence
@@ -482,10 +485,10 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
     // staging copy: after the LDS-resident state when that is in LDS too (then it only serves to give the compiler LDS-typed
     // addresses instead of flat ones for the hot pair loop)
     double* stM = smem + xt_th_plan_lds_doubles(S, G, capE, D, K, cmw) +
-                  (a.ws_lds ? xt_th_ws_doubles(wsP, wsE, D, K, F, NS, S, a.pcap, PREDS) : 0);  // [PC][stP][D]
+                  (ws_lds ? xt_th_ws_doubles(wsP, wsE, D, K, F, NS, S, a.pcap, PREDS) : 0);  // [PC][stP][D]
     double* stS = stM + (int64_t)a.pcap * stP * D;                  // [PC][stE][K]
     double* wh = a.ws + (int64_t)cx.block() * a.ws_stride;  // history part (prediction mode), then the state part unless it is in LDS
-    double* w = a.ws_lds ? smem + xt_th_plan_lds_doubles(S, G, capE, D, K, cmw) : wh + xt_th_hist_doubles(wsE, a.pcap, PREDS, L);
+    double* w = ws_lds ? smem + xt_th_plan_lds_doubles(S, G, capE, D, K, cmw) : wh + xt_th_hist_doubles(wsE, a.pcap, PREDS, L);
     const int plane = PC * wsE;  // sE plane
     typedef XtThView<D, K, false> View;
     View A, B;
