@@ -240,6 +240,48 @@ def other_configs(device):
         out["c5_loglik_ns3_F4"]["cpu_port_c"] = {"tracks_per_s": len(smp) / dtc, "cores": cores, "sample": "%d tracks" % len(smp)}
     except Exception as e:
         out["c5_loglik_ns3_F4"]["cpu_port_c"] = {"error": str(e)}
+    # ---- configs[0]-size dataset (a real experiment: ~7 000 tracks in 16 length buckets): one evaluation of both objectives and a whole fit
+    import contextlib
+    import io
+    Ds2, Tm2, Fs2 = [0.0, 0.25], [[0.9, 0.1], [0.1, 0.9]], [0.6, 0.4]
+    sizes = synth.bucket_sizes_geometric(6730, list(range(5, 21)), 0.85)
+    small = {str(L): synth.brownian_tracks(n, L, Ds2, Tm2, Fs2, seed=L) for L, n in sizes.items() if n > 0}
+    _, lst, _ = tracking.engine.sort_buckets(small)
+    ts = tracking.TrackSet(lst, device=device)
+    v2 = dict(D0=1e-3, D1=0.25, LocErr=0.02, F0=0.6, F1=0.4, p01=0.1, p10=0.1, pBL=0.1)
+    model = tracking._objective_model(P(v2), ts, DT, CELL, None, 2, 1, 6, 1)
+    w_win, k_win, _ = timed(lambda: ts.loglik(model), 50, warm=2)
+    w_th, k_th, _ = timed(lambda: ts.loglik_th(model, 0.2, 120, 2000), 50, warm=2)
+    ts.close()
+    fits = {}
+    for grad in ("analytic", "fd"):
+        with contextlib.redirect_stdout(io.StringIO()):
+            t0 = time.perf_counter()
+            r = tracking.param_fitting(small, DT, nb_states=2, frame_len=6, cell_dims=CELL, verbose=0, gradient=grad, device=device)
+            fits[grad] = {"seconds": time.perf_counter() - t0, "objective_calls": int(r.nfev), "neg_loglik": float(r.residual[0])}
+    out["c1_like_small_dataset"] = {"what": "6 730 tracks in 16 length buckets (5-20 positions), 2 states, frame_len 6: one evaluation, and param_fitting from the "
+                                            "default start with the exact gradient / with finite differences",
+                                    "window_ms_per_eval": w_win * 1e3, "window_kernel_ms": k_win, "threshold_ms_per_eval": w_th * 1e3,
+                                    "threshold_kernels_ms": k_th, "fit": fits}
+    # ---- state-duration histograms and position refinement on 1e5 tracks x 30
+    from extrack_amd.histograms import len_hist
+    from extrack_amd.refined_localization import position_refinement
+    big = {"30": synth.brownian_tracks(100000, 30, Ds2, Tm2, Fs2, seed=1)}
+    pp = P(v2)
+    with contextlib.redirect_stdout(io.StringIO()):
+        len_hist(big, pp, DT, cell_dims=CELL, nb_states=2, max_nb_states=500, device=device)
+        t0 = time.perf_counter()
+        h = len_hist(big, pp, DT, cell_dims=CELL, nb_states=2, max_nb_states=500, device=device)
+        t_h = time.perf_counter() - t0
+        dsr = np.sqrt(2 * np.array([1e-3, 0.25]) * DT)
+        position_refinement(big, 0.02, dsr, np.array(Fs2), np.array(Tm2), frame_len=6, device=device)
+        t0 = time.perf_counter()
+        mu, sg = position_refinement(big, 0.02, dsr, np.array(Fs2), np.array(Tm2), frame_len=6, device=device)
+        t_r = time.perf_counter() - t0
+    out["len_hist_1e5x30"] = {"what": "histograms.len_hist, 1e5 tracks x 30, 2 states, max_nb_states 500 (the reference's default)", "seconds": t_h,
+                              "tracks_per_s": 1e5 / t_h, "hist_sum": float(h.sum())}
+    out["position_refinement_1e5x30"] = {"what": "refined_localization.position_refinement, 1e5 tracks x 30, 2 states, frame_len 6, threshold 0.1",
+                                         "seconds": t_r, "tracks_per_s": 1e5 / t_r, "mean_sigma": float(sg["30"].mean())}
     return out
 
 
