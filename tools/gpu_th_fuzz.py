@@ -57,6 +57,9 @@ for case in range(ncases):
             ref = np.concatenate([OT.proba_cs_th(Cs[a:a + chunk], le if sg is None else sg[a:a + chunk], ds, Fs, Tm, pBL, isBL, cell, ns, F,
                                                  min_len, thr, mx) for a in range(0, N, chunk)])
             d = np.abs(ll - ref).max()
+            # second evaluation on the same context: learned capacities (LDS-resident pilot state, larger workgroups, ...)
+            _, ll2 = ts.loglik_th(model, thr, mx, chunk=chunk, per_track=True)
+            d = max(d, np.abs(ll2 - ref).max())
             worst_ll = max(worst_ll, d)
             if not d < 1e-10:
                 bad += 1
