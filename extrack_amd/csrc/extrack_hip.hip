@@ -683,7 +683,7 @@ extern "C" int extrack_predict(extrack_ctx* ctx, const extrack_model* m, int32_t
 // threshold-fusion variant (xt_th.h): plan kernel + apply kernel per bucket
 // ------------------------------------------------------------------------------------------------
 template <class KernT>
-static hipError_t xt_th_set_lds(extrack_ctx* ctx, KernT kern, size_t lds)
+static hipError_t xt_th_set_lds(extrack_ctx* /*ctx*/, KernT kern, size_t lds)
 {
     if (lds <= 64 * 1024) return hipSuccess;
     return hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -974,7 +974,7 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
                         const int g2 = q / (Hn * S), hs = q - g2 * (Hn * S), h = hs / S, s2 = hs - h * S;
                         const int k0 = gst[g2], k1 = gst[g2 + 1];
                         auto val = [&](int jj) -> double {
-                            const int g = jj / G, r = jj - g * G;
+                            const int g = jj / G;
                             if (h < NS) return ((t == 1 ? (jj / pwS[h]) % S : xt_th_cat_digit(jj / pwS[h], S)) == s2) ? 1.0 : 0.0;
                             return ctA[x * cstride + (g * HM + (h - NS)) * S + s2];
                         };
@@ -992,7 +992,7 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
                     const int g2 = i / (Hn * S), hs = i - g2 * (Hn * S), h = hs / S, s = hs - h * S;
                     const int k0 = gst[g2], k1 = gst[g2 + 1];
                     auto val = [&](int j) -> double {
-                        const int g = j / G, r = j - g * G;
+                        const int g = j / G;
                         if (h < NS) return ((t == 1 ? (j / pwS[h]) % S : xt_th_cat_digit(j / pwS[h], S)) == s) ? 1.0 : 0.0;
                         return ctA[(g * HM + (h - NS)) * S + s];
                     };
