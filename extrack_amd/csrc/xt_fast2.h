@@ -125,7 +125,10 @@ XT_HD T& xt_at(char* lds, int byte_off)
 }
 
 // One recursion step at compile-time phase H.  c: position, l2: localisation variance(s), TT: transition row in use.
-template <int F, int D, int K, int H>
+// ZF ("zero free"): every sequence of the window has a positive weight (well-scaled model, all slots populated): the zero-weight special
+// case (compare + three selects per step) is compiled out.  LAZY: the merged weight is re-normalised in every XT_F2_RENORM-th phase only
+// (well-scaled models, see xt_build_blob); otherwise in every step.
+template <int F, int D, int K, int H, bool ZF = false, bool LAZY = false>
 XT_HD void xt_f2_step(char* lds, const XtF2State<F, D, K>& st, const double* c, const double* l2, const double* TT, const double* TD2)
 {
     constexpr int ZEO = (1 + D + K) * XT_F2_ARR;  // ze address = a + ZEO
@@ -141,12 +144,12 @@ XT_HD void xt_f2_step(char* lds, const XtF2State<F, D, K>& st, const double* c, 
         M[d] = xt_fma(w1, xt_at<double>(lds, a1 + (1 + d) * XT_F2_ARR), w0 * xt_at<double>(lds, a0 + (1 + d) * XT_F2_ARR));
     for (int k = 0; k < K; ++k)
         U[k] = xt_fma(w1, xt_at<double>(lds, a1 + (1 + D + k) * XT_F2_ARR), w0 * xt_at<double>(lds, a0 + (1 + D + k) * XT_F2_ARR));
-    const bool live = W > 0.0;
-    const double Ws = live ? W : 1.0;
-    // The merged weight is re-normalised (mantissa in [0.5, 1), exponent into ze) in every XT_F2_RENORM-th phase only: between two
-    // normalisations a mantissa drifts by at most (2 * max(1, den^(-D/2)))^XT_F2_RENORM - a few tens of binades of fp64's two thousand -
-    // and every expression of the step is homogeneous in W, so nothing else changes.
-    constexpr bool RN = (H % XT_F2_RENORM) == 0;
+    const bool live = ZF ? true : W > 0.0;
+    const double Ws = ZF ? W : (live ? W : 1.0);
+    // LAZY: the merged weight is re-normalised (mantissa in [0.5, 1), exponent into ze) in every XT_F2_RENORM-th phase only; every
+    // expression of the step is homogeneous in W, and for a well-scaled model the drift between two normalisations stays far inside
+    // the fp64 range (bounds in xt_build_blob).
+    constexpr bool RN = !LAZY || (H % XT_F2_RENORM) == 0;
     const double Wm = RN ? xt_frexp_mant(W) : W;  // 0 when W == 0
     const int We = live ? (RN ? emax + xt_frexp_exp(W) : emax) : XT_EMIN;
 
@@ -206,9 +209,16 @@ XT_HD void xt_f2_step(char* lds, const XtF2State<F, D, K>& st, const double* c, 
     xt_exp_tab_x2(x[0], x[1], p[0], p[1], j[0], j[1], n[0], n[1]);
     for (int q = 0; q < 2; ++q) {
         const int aq = q ? a1 : a0;
-        const int en = We + n[q];
+        int en = We + n[q];
         const double tj = xt_at<double>(lds, XT_F2_T64_OFF + j[q] * 8);
-        xt_at<double>(lds, aq) = (Wm * TT[q]) * (gf[q] * tj) * p[q];
+        double zn = (Wm * TT[q]) * (gf[q] * tj) * p[q];
+        if (!LAZY) {
+            // guarded steps (models outside the well-scaled bounds, e.g. a transition probability of 1e-200): the stored mantissa is
+            // normalised too, so that the next step's W^3-sized products cannot leave the fp64 range
+            en += xt_frexp_exp(zn);
+            zn = xt_frexp_mant(zn);
+        }
+        xt_at<double>(lds, aq) = zn;
         xt_at<int>(lds, aq + ZEO) = en > XT_EMIN ? en : XT_EMIN;
         for (int d = 0; d < D; ++d) xt_at<double>(lds, aq + (1 + d) * XT_F2_ARR) = xt_fma(dmW[d], tt[q][K == 1 ? 0 : d], M[d]) * rW;
         for (int k = 0; k < K; ++k) xt_at<double>(lds, aq + (1 + D + k) * XT_F2_ARR) = l2[k] * tt[q][k];
@@ -251,6 +261,7 @@ XT_HD void xt_ll_s2_body(const XtKernelArgs& a, Ctx& cx)
     }
     double l2g[K];
     for (int k = 0; k < K; ++k) l2g[k] = hdr[k];
+    const bool well_scaled = hdr[5] != 0.0 && a.locerr_mode == 0;  // model flag (xt_build_blob); per-peak errors are not bounded there
 
     // LDS map (bytes): [tables 1 KiB][zm][m x D][u x K] (each XT_F2_WAVES x 128 doubles) [ze: XT_F2_WAVES x 128 ints in 8-byte slots][pos][sig]
     constexpr int ZEO = (1 + D + K) * XT_F2_ARR;
@@ -324,26 +335,37 @@ XT_HD void xt_ll_s2_body(const XtKernelArgs& a, Ctx& cx)
         };
         // steps t .. tend with transition row TT (the F phases of the circular digit buffer unrolled: every LDS
         // address is a register, phase h = t mod F)
-        auto run_steps = [&](int& t, int tend, const double* TT) {
-            while (t <= tend) {
-#define XT_F2_PHASE(H)                                                                 \
-    if (F > (H) && t <= tend && (t % F) == (H)) {                                      \
+#define XT_F2_PHASE(H, ZF_, LAZY_)                                                     \
+    if (F > (H) && t <= tend2 && (t % F) == (H)) {                                     \
         double c[D], l2[K];                                                            \
         getpos(t, c, l2);                                                              \
-        xt_f2_step<F, D, K, ((H) < F ? (H) : 0)>(lds, st, c, l2, TT, TD2);             \
+        xt_f2_step<F, D, K, ((H) < F ? (H) : 0), ZF_, LAZY_>(lds, st, c, l2, TT, TD2); \
         cx.wave_sync();                                                                \
         ++t;                                                                           \
     }
-                XT_F2_PHASE(1)
-                XT_F2_PHASE(2)
-                XT_F2_PHASE(3)
-                XT_F2_PHASE(4)
-                XT_F2_PHASE(5)
-                XT_F2_PHASE(6)
-                XT_F2_PHASE(0)
-#undef XT_F2_PHASE
+#define XT_F2_PHASES(ZF_, LAZY_)  \
+    XT_F2_PHASE(1, ZF_, LAZY_)    \
+    XT_F2_PHASE(2, ZF_, LAZY_)    \
+    XT_F2_PHASE(3, ZF_, LAZY_)    \
+    XT_F2_PHASE(4, ZF_, LAZY_)    \
+    XT_F2_PHASE(5, ZF_, LAZY_)    \
+    XT_F2_PHASE(6, ZF_, LAZY_)    \
+    XT_F2_PHASE(0, ZF_, LAZY_)
+        auto run_steps = [&](int& t, int tend, const double* TT) {
+            if (!well_scaled) {  // fully guarded steps: zero weights handled, re-normalisation in every step
+                const int tend2 = tend;
+                while (t <= tend2) { XT_F2_PHASES(false, false) }
+                return;
             }
+            {   // steps t < F may meet slots that are not populated yet (zero weight)
+                const int tend2 = tend < F - 1 ? tend : F - 1;
+                while (t <= tend2) { XT_F2_PHASES(false, true) }
+            }
+            const int tend2 = tend;
+            while (t <= tend2) { XT_F2_PHASES(true, true) }
         };
+#undef XT_F2_PHASES
+#undef XT_F2_PHASE
 
         XtAcc tot;
         tot.clear();

@@ -76,6 +76,28 @@ def test_fast2_multi_chunk_tracks(F, L, N, monkeypatch):
     assert abs(tot - ref.sum()) < 1e-9
 
 
+def test_fast2_tiny_and_zero_transition_probabilities(monkeypatch):
+    """Models outside the 'well-scaled' bounds of the 2-state fast path take its guarded steps (every stored weight normalised, zero
+    weights handled): transition probabilities of 1e-300 / 1e-200 against the oracle (found in round 2: anything below ~1e-100 used to
+    give NaN, the step's W^3-sized products underflowed), an exactly zero one against the 1e-300 result."""
+    monkeypatch.delenv("XT_EMUL_GENERIC", raising=False)
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "emul"))
+    import run_emul as E
+    rng = np.random.default_rng(4)
+    Cs = np.cumsum(rng.normal(0, 0.05, (9, 14, 2)), 1)
+    ds, Fs = np.array([0.002, 0.1]), np.array([.3, .7])
+    LE = np.array([[[0.02]]])
+    ps = O.p_stay_table(ds, 2, 1, [1.0])
+    got = {}
+    for eps in (0.0, 1e-300, 1e-200, 1e-25, 1e-3):
+        T = np.array([[1.0 - eps, eps], [0.15, 0.85]])
+        got[eps] = E.run(Cs, LE, ds, Fs, T, 0.1, 1, ps, 1, 6, 3, nblocks=1)[0]
+        if eps > 0:
+            assert np.abs(got[eps] - O.proba_cs(Cs, LE, ds, Fs, T, 0.1, 1, [1.0], 1, 6, 3)).max() < 1e-10, eps
+    assert np.all(np.isfinite(got[0.0])) and np.abs(got[0.0] - got[1e-300]).max() < 1e-10
+
+
 @pytest.mark.parametrize("generic", [False, True])
 def test_absurd_jump_stays_a_tiny_weight(generic, monkeypatch):
     """A jump of thousands of localisation errors in one frame: the Gaussian exponent leaves the range of the table-driven exp.  The

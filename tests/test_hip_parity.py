@@ -296,6 +296,27 @@ def test_absurd_jump_clamps_instead_of_wrapping(S, F):
     assert np.isfinite(got[3]) and got[3] < -7e6 and ref[3] < -7e6, (got[3], ref[3])
 
 
+def test_tiny_and_zero_transition_probabilities():
+    """Transition probabilities far below the 'well-scaled' bounds of the 2-state fast path (1e-200, 1e-300: the guarded steps normalise
+    every stored weight) against the oracle, and an exactly zero one (absorbing state: the reference's log-domain code returns NaN and its
+    objective refuses such models) against the 1e-300 result - the extra sequences contribute nothing at double precision."""
+    from extrack_amd import synth, tracking as T
+    from oracle import oracle_np as O
+    Fs = np.array([0.3, 0.7])
+    Cs = synth.brownian_tracks(50, 14, [0.0, 0.25], [[0.9, 0.1], [0.15, 0.85]], Fs, seed=3)
+    ds = np.sqrt(2 * np.array([1e-4, 0.25]) * 0.02)
+    LE = np.array([[[0.02]]])
+    out = {}
+    for eps in (0.0, 1e-300, 1e-200, 1e-25):
+        Tm = np.array([[1.0 - eps, eps], [0.15, 0.85]])
+        out[eps] = T.Proba_Cs(Cs, LE, ds, Fs, Tm, 0.1, 1, [1.0], 1, 6, 3)
+        if eps > 0:
+            ref = O.proba_cs(Cs, LE, ds, Fs, Tm, 0.1, 1, [1.0], 1, 6, 3)
+            np.testing.assert_allclose(out[eps], ref, rtol=1e-13, atol=1e-10)
+    assert np.all(np.isfinite(out[0.0]))
+    np.testing.assert_allclose(out[0.0], out[1e-300], rtol=1e-13, atol=1e-10)
+
+
 def test_large_coordinate_offsets():
     """Positions around 1e4 um (pixel-like coordinates): both implementations difference nearby fp64 numbers; parity must hold to the
     conditioning of the problem (|c| * eps / sigma^2 ~ 1e-12 * 1e4 / 4e-4 per step)."""
