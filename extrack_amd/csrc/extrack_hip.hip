@@ -256,6 +256,19 @@ extern "C" int extrack_upload_bucket(extrack_ctx* ctx, const double* tracks, int
     b.L = len;
     b.D = dims;
     b.KS = sigma ? sigma_dims : 0;
+    if (sigma) {  // range of the per-peak errors: lets the 2-state fast path prove its scaling bounds (NaN entries poison their track anyway)
+        double lo = INFINITY, hi = -INFINITY;
+        const size_t ns = (size_t)n * len * sigma_dims;
+        for (size_t i = 0; i < ns; ++i) {
+            const double v = sigma[i];
+            if (v == v) {
+                lo = v < lo ? v : lo;
+                hi = v > hi ? v : hi;
+            }
+        }
+        b.sig_min = lo;
+        b.sig_max = hi;
+    }
     const size_t tb = (size_t)n * len * dims * sizeof(double);
     double* dt = nullptr;
     XT_HIP(ctx, hipMalloc(&dt, tb));
@@ -410,9 +423,8 @@ static int xt_prepare(extrack_ctx* ctx, const extrack_model* m)
     if (rc) return rc;
     XtModelHost mh;
     xt_model_host(m, mh);
-    std::vector<double> blob;
-    xt_build_blob(mh, ctx->cfg, blob);
-    return xt_upload_blob(ctx, blob);
+    xt_build_blob(mh, ctx->cfg, ctx->blob_host);  // kept on the host: the launcher reads the scaling slots of the header
+    return xt_upload_blob(ctx, ctx->blob_host);
 }
 
 struct DevLauncher {
@@ -546,6 +558,30 @@ static int xt_launch_group(extrack_ctx* ctx, const extrack_model* m, const std::
     }
     l.threads = threads;
     l.tracks_per_block = tpb;
+    if (fast2) {
+        // range of the localisation variance over the launch -> may the fast path drop its guards (xt_build_blob)?
+        double lo = INFINITY, hi = -INFINITY;
+        if (m->locerr_mode == 0) {
+            for (int k = 0; k < m->locerr_dims && k < 3; ++k) {
+                lo = std::min(lo, m->locerr[k] * m->locerr[k]);
+                hi = std::max(hi, m->locerr[k] * m->locerr[k]);
+            }
+        } else {
+            for (XtBucket* b : bks) {
+                double s0 = b->sig_min, s1 = b->sig_max;  // NaN when the bucket was attached by device pointer: not provable
+                if (m->locerr_mode == 2) {
+                    const double a0 = s0 * m->slope + m->offset, a1 = s1 * m->slope + m->offset;
+                    s0 = std::max(std::min(a0, a1), 1e-6);
+                    s1 = std::max(std::max(a0, a1), 1e-6);
+                    if (a0 != a0 || a1 != a1) s0 = s1 = NAN;
+                }
+                lo = (s0 == s0) ? std::min(lo, s0 * s0) : NAN;
+                hi = (s1 == s1) ? std::max(hi, s1 * s1) : NAN;
+                if (lo != lo || hi != hi) break;
+            }
+        }
+        l.a.well_scaled = (ctx->blob_host.size() > 8 && xt_model_well_scaled(ctx->blob_host, lo, hi)) ? 1 : 0;
+    }
     if (l.lds > 160 * 1024) return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "sequence state does not fit the 160 KiB LDS of a CU");
     l.desc_off = desc_off;
     for (XtBucket* b : bks) {

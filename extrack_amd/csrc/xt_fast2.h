@@ -261,7 +261,7 @@ XT_HD void xt_ll_s2_body(const XtKernelArgs& a, Ctx& cx)
     }
     double l2g[K];
     for (int k = 0; k < K; ++k) l2g[k] = hdr[k];
-    const bool well_scaled = hdr[5] != 0.0 && a.locerr_mode == 0;  // model flag (xt_build_blob); per-peak errors are not bounded there
+    const bool well_scaled = a.well_scaled != 0;  // decided per launch on the host (xt_model_well_scaled)
 
     // LDS map (bytes): [tables 1 KiB][zm][m x D][u x K] (each XT_F2_WAVES x 128 doubles) [ze: XT_F2_WAVES x 128 ints in 8-byte slots][pos][sig]
     constexpr int ZEO = (1 + D + K) * XT_F2_ARR;

@@ -115,6 +115,7 @@ struct XtBucket {
     const double* d_tracks = nullptr;
     const double* d_sigma = nullptr;
     double* d_dt = nullptr;  // [N][L] per-track time steps (extrack_set_bucket_dt), owned
+    double sig_min = NAN, sig_max = NAN;  // range of the per-peak localisation errors (host uploads only; NaN: unknown)
     bool owned = false;
     int64_t N = 0;
     int L = 0, D = 0, KS = 0;
@@ -208,6 +209,7 @@ struct extrack_ctx {
     int th_stage_in_lds_mode = 0;  // EXTRACK_TH_STAGE_LDS: LDS-typed copy of the pilot means/stds also when the state is in LDS (measured: no gain)
     int th_no_gen_single = 0;  // EXTRACK_TH_NO_GEN_SINGLE: never use the one-buffer general apply variant
     int th_plan_bs = 0;         // plan kernel, > 64 sequences: pivot rows per batch = wavefronts x max(n, 1); < 0: one batch (EXTRACK_TH_PLAN_BS)
+    std::vector<double> blob_host;  // model tables of the current fixed-window evaluation (xt_prepare)
     bool th_plan_threads_forced = false;
     int th_plan_threads = 512;  // workgroup size of the plan kernel (EXTRACK_TH_PLAN_THREADS)
     int th_force_tt = 0, th_force_threads = 0, th_oversub = 2;  // tuning knobs (EXTRACK_TH_TT / _THREADS / _OVERSUB)

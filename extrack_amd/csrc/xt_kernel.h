@@ -65,6 +65,7 @@ struct XtKernelArgs {
     int32_t isBL, min_len;
     int32_t locerr_mode;      // 0 global (blob[0..2]), 1 per-peak sigma, 2 per-peak affine clip(s*slope+offset,1e-6)
     int32_t KS;               // last dim of sigma (1 or D)
+    int32_t well_scaled;      // 2-state fast path: lazy re-normalisation + zero-free steps are sound for this launch (xt_model_well_scaled)
     int32_t prev_div;         // S^(F-NS-1): prev digit of group g = g / prev_div
     int32_t pw[16];           // S^i
     double ll_const;          // -(L-1)*D/2*log(2*pi)

@@ -143,25 +143,30 @@ static inline void xt_build_blob(const XtModelHost& m, const XtConfig& c, std::v
             TAB[4 * SG + o] = d2;
         }
     }
-    // header slot 5: "well scaled" model - every initial fraction and transition (x stay) weight in [1e-20, 1], localisation variance
-    // + displacement variance in [1e-12, 1e4] (global localisation error only: the kernel checks the mode).  Then (a) no sequence weight
+    // "Well scaled" model: every initial fraction and transition (x stay) weight in [1e-20, 1], localisation variance + displacement
+    // variance in [1e-12, 1e4].  Then (a) no sequence weight
     // is ever exactly zero once the window is populated and (b) a mantissa left un-normalised for XT_F2_RENORM steps stays within
     // [1e-80, 1e55], far from where the step's products (W^3 den^2) would leave the fp64 range: the 2-state fast path then drops its
     // zero handling and re-normalises lazily; any other model takes the fully guarded steps.
+    // The launcher (xt_model_well_scaled) combines slot 5 (fractions / weights in range) and the displacement-variance range in slots
+    // 6, 7 with the range of the localisation variance - global, or from the per-peak errors seen at upload - into the kernel argument.
     bool ok = true;
     for (int s = 0; s < S; ++s) ok = ok && m.Fs[s] >= 1e-20 && m.Fs[s] <= 1.0;
     for (size_t i = 0; i < 2 * SG; ++i) ok = ok && TAB[i] >= 1e-20 && TAB[i] <= 1.0;
-    double l2min = 1e300, l2max = 0.0, d2min = 1e300, d2max = 0.0;
-    for (int k = 0; k < m.locerr_dims && k < 3; ++k) {
-        l2min = std::min(l2min, blob[k]);
-        l2max = std::max(l2max, blob[k]);
-    }
+    double d2min = 1e300, d2max = 0.0;
     for (size_t i = 0; i < SG; ++i) {
         d2min = std::min(d2min, TAB[4 * SG + i]);
         d2max = std::max(d2max, TAB[4 * SG + i]);
     }
-    ok = ok && l2min + d2min >= 1e-12 && 2.0 * l2max + d2max <= 1e4;
     blob[5] = ok ? 1.0 : 0.0;
+    blob[6] = d2min;
+    blob[7] = d2max;
+}
+
+// Well-scaled test of a launch (see xt_build_blob): l2lo / l2hi = range of the localisation variance over everything the launch reads.
+static inline bool xt_model_well_scaled(const std::vector<double>& blob, double l2lo, double l2hi)
+{
+    return blob[5] != 0.0 && l2lo == l2lo && l2hi == l2hi && l2lo + blob[6] >= 1e-12 && 2.0 * l2hi + blob[7] <= 1e4;
 }
 
 // Model tables of the threshold-fusion kernels (xt_th.h): same five [prev][.] tables and header as xt_build_blob, but the

@@ -226,6 +226,26 @@ extern "C" int xt_emul_run(const double* tracks, const double* sigma, long long 
     l.a.min_len = min_len;
     l.a.locerr_mode = locerr_mode;
     l.a.KS = KS;
+    {   // the launcher's scaling decision for the 2-state fast path (extrack_hip.hip: xt_launch_group)
+        double lo = INFINITY, hi = -INFINITY;
+        if (locerr_mode == 0) {
+            for (int k = 0; k < locerr_dims && k < 3; ++k) {
+                lo = std::min(lo, m.locerr[k] * m.locerr[k]);
+                hi = std::max(hi, m.locerr[k] * m.locerr[k]);
+            }
+        } else {
+            for (long long i = 0; i < N * L * KS; ++i) {
+                double v = sigma[i];
+                if (locerr_mode == 2) v = std::max(v * slope + offset, 1e-6);
+                if (v == v) {
+                    lo = std::min(lo, v * v);
+                    hi = std::max(hi, v * v);
+                }
+            }
+        }
+        l.a.well_scaled = xt_model_well_scaled(blob, lo, hi) ? 1 : 0;
+        if (getenv("XT_EMUL_GUARDED")) l.a.well_scaled = 0;
+    }
     l.a.ll_const = -(double)(L - 1) * D * 0.5 * XT_LOG2PI;
     l.threads = threads;
     l.nblocks = nblocks;
@@ -303,6 +323,14 @@ extern "C" int xt_emul_run_multi(int nbuckets, const double** tracks, const long
     l.a.min_len = min_len;
     l.a.locerr_mode = 0;
     l.a.KS = 1;
+    {
+        double lo = INFINITY, hi = -INFINITY;
+        for (int k = 0; k < locerr_dims && k < 3; ++k) {
+            lo = std::min(lo, m.locerr[k] * m.locerr[k]);
+            hi = std::max(hi, m.locerr[k] * m.locerr[k]);
+        }
+        l.a.well_scaled = xt_model_well_scaled(blob, lo, hi) ? 1 : 0;
+    }
     bool ok;
     if (xt_use_fast2(S, NS, F, false)) {
         l.threads = 64 * XT_F2_WAVES;

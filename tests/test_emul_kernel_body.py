@@ -41,8 +41,15 @@ def test_generic_body_on_golden_subset(kernel_cases, monkeypatch):
     assert n > 150 and worst < 1e-10 and worstp < 1e-9, (n, worst, worstp)
 
 
-def test_fast2_body_on_golden_two_state_cases(kernel_cases, monkeypatch):
+@pytest.mark.parametrize("guarded", [False, True])
+def test_fast2_body_on_golden_two_state_cases(kernel_cases, guarded, monkeypatch):
+    """guarded: the fully guarded steps of the fast path (per-step normalisation of every weight, zero handling) instead of the lazy /
+    zero-free ones that well-scaled models take."""
     monkeypatch.delenv("XT_EMUL_GENERIC", raising=False)
+    if guarded:
+        monkeypatch.setenv("XT_EMUL_GUARDED", "1")
+    else:
+        monkeypatch.delenv("XT_EMUL_GUARDED", raising=False)
     meta, data = kernel_cases
     worst = 0.0
     n = 0
