@@ -21,10 +21,19 @@ import csv, glob, collections, sys, os
 root = sys.argv[1]
 # ---- PMC summary per kernel
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
+rows = []
 for f in glob.glob(root + "/p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         if "xt_" in r["Kernel_Name"] and "reduce" not in r["Kernel_Name"]:
-            agg[r["Kernel_Name"].split("(")[0][:64]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            rows.append((r["Kernel_Name"].split("(")[0][:64], int(r["Grid_Size"]), r["Counter_Name"], float(r["Counter_Value"])))
+# the bench also runs small-dataset fits (hundreds of tiny launches of the same kernels): per kernel keep the launches whose grid is at
+# least half the largest one seen, i.e. the full-size BASELINE configurations
+gmax = collections.defaultdict(int)
+for k, g, c, v in rows:
+    gmax[k] = max(gmax[k], g)
+for k, g, c, v in rows:
+    if 2 * g >= gmax[k]:
+        agg[k][c].append(v)
 with open(root + "/pmc_summary.txt", "w") as out:
     for k, d in sorted(agg.items()):
         for c, v in sorted(d.items()):
