@@ -336,12 +336,13 @@ XT_HD void xt_ll_s2_body(const XtKernelArgs& a, Ctx& cx)
         // steps t .. tend with transition row TT (the F phases of the circular digit buffer unrolled: every LDS
         // address is a register, phase h = t mod F)
 #define XT_F2_PHASE(H, ZF_, LAZY_)                                                     \
-    if (F > (H) && t <= tend2 && (t % F) == (H)) {                                     \
+    if (F > (H) && t <= tend2 && ph == (H)) {                                          \
         double c[D], l2[K];                                                            \
         getpos(t, c, l2);                                                              \
         xt_f2_step<F, D, K, ((H) < F ? (H) : 0), ZF_, LAZY_>(lds, st, c, l2, TT, TD2); \
         cx.wave_sync();                                                                \
         ++t;                                                                           \
+        ph = (H) + 1 == F ? 0 : (H) + 1;                                               \
     }
 #define XT_F2_PHASES(ZF_, LAZY_)  \
     XT_F2_PHASE(1, ZF_, LAZY_)    \
@@ -352,6 +353,7 @@ XT_HD void xt_ll_s2_body(const XtKernelArgs& a, Ctx& cx)
     XT_F2_PHASE(6, ZF_, LAZY_)    \
     XT_F2_PHASE(0, ZF_, LAZY_)
         auto run_steps = [&](int& t, int tend, const double* TT) {
+            int ph = t % F;  // phase of the circular digit buffer, advanced with t (no modulo in the step loop)
             if (!well_scaled) {  // fully guarded steps: zero weights handled, re-normalisation in every step
                 const int tend2 = tend;
                 while (t <= tend2) { XT_F2_PHASES(false, false) }
