@@ -45,7 +45,7 @@ def test_th_bodies_on_golden_subset():
     assert len(rows) >= 20 and worst < 1e-10, (len(rows), worst)
 
 
-@pytest.mark.parametrize("threshold,max_nb,threads,staged", [(0.12, 400, 128, False), (0.1, 100, 192, True)])
+@pytest.mark.parametrize("threshold,max_nb,threads,staged", [(0.1, 100, 192, True)])
 def test_th_plan_many_sequences_wrapped_classes(threshold, max_nb, threads, staged, monkeypatch):
     """More than 128 expanded sequences per step with 3 states: the reference's int8 index wrap makes the history classes irregular;
     the plan kernel then walks per-class candidate lists.  Several wavefronts, global workspace with / without the LDS staging copy.
