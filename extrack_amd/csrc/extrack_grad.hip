@@ -4,6 +4,7 @@
 
 #include "xt_grad.h"
 #include "xt_grad_host.h"
+#include "xt_reg2.h"
 
 // Waves per SIMD the register allocator is asked to allow.  Measured on C2 (1e6 x 30, 7 directions, PJ = 4): 2 -> 63 ms,
 // 3 -> 53 ms (168 VGPRs, 108 B of scratch per lane), 4 -> 60 ms (128 VGPRs, 272 B of scratch).
@@ -109,6 +110,7 @@ extern "C" int extrack_loglik_grad(extrack_ctx* ctx, const extrack_model* m, int
     int rc = xt_validate_model(ctx, m);
     if (rc) return rc;
     if (ctx->buckets.empty()) return xt_fail(ctx, EXTRACK_E_INVALID, "no bucket uploaded");
+    if (n_dir == 0) return extrack_loglik(ctx, m, total_ll, nullptr);  // no direction: the plain likelihood kernels
     for (int i = 0; i < n_dir; ++i)
         if (!tangents[i].ds2 || !tangents[i].Fs || !tangents[i].TrMat || !tangents[i].p_stay)
             return xt_fail(ctx, EXTRACK_E_INVALID, "null tangent field");
@@ -180,6 +182,87 @@ extern "C" int extrack_loglik_grad(extrack_ctx* ctx, const extrack_model* m, int
         memcpy(ctx->h_desc + doff, descs.data(), descs.size() * sizeof(XtBucketDesc));
         XT_HIP(ctx, hipMemcpyAsync(ctx->d_desc + doff, ctx->h_desc + doff, descs.size() * sizeof(XtBucketDesc), hipMemcpyHostToDevice, ctx->stream));
         XT_HIP(ctx, hipEventRecord(ctx->ev_blob[(ctx->blob_turn - 1u) & 1u], ctx->stream));
+        // ---- two-state models: register-resident kernels (xt_reg2.h), <= 8 directions per pass, tangents in VGPRs
+        const bool r2 = ctx->grad_reg2 && xt_use_reg2(c.S, c.NS, c.F) && m->locerr_mode == 0 && n_dir > 0 && xt_r2_kernel(c.F, D, K, 1) != nullptr;
+        if (r2) {
+            const int tpw = 64 >> (c.F - 1), tpb = tpw * XT_F2_WAVES, threads = 64 * XT_F2_WAVES;
+            const int npass = (n_dir + 7) / 8, per = (n_dir + npass - 1) / npass;
+            double lo = INFINITY, hi = -INFINITY;
+            for (int k = 0; k < m->locerr_dims && k < 3; ++k) {
+                lo = std::min(lo, m->locerr[k] * m->locerr[k]);
+                hi = std::max(hi, m->locerr[k] * m->locerr[k]);
+            }
+            for (int p0 = 0; p0 < n_dir; p0 += per) {
+                const int NP = std::min(per, n_dir - p0);
+                const void* kp = xt_r2_kernel(c.F, D, K, NP);
+                if (!kp) return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "gradient kernel variant not built");
+                XtKernelArgs a;
+                memset(&a, 0, sizeof(a));
+                xt_fill_args_from_config(c, a);
+                XtGradArgs ga;
+                memset(&ga, 0, sizeof(ga));
+                const size_t lds = (size_t)xt_r2_block_bytes(NP, D, 0, tpw);
+                auto key = std::make_pair(kp, std::make_pair(threads, lds));
+                auto it = ctx->occ_cache.find(key);
+                if (it == ctx->occ_cache.end()) {
+                    int o = 0;
+                    XT_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, kp, threads, lds));
+                    it = ctx->occ_cache.emplace(key, o < 1 ? 1 : o).first;
+                }
+                const int occ = it->second;
+                const double target = (double)occ * ctx->n_cu * ctx->oversub;
+                double wsum = 0.0;
+                std::vector<int64_t> nbatch(descs.size());
+                for (size_t i = 0; i < descs.size(); ++i) {
+                    nbatch[i] = (descs[i].N + tpb - 1) / tpb;
+                    wsum += (double)nbatch[i] * (descs[i].L - 1);
+                }
+                int64_t acc = 0;
+                for (size_t i = 0; i < descs.size(); ++i) {
+                    int64_t n = (int64_t)ceil(target * ((double)nbatch[i] * (descs[i].L - 1)) / wsum);
+                    n = n < 1 ? 1 : (n > nbatch[i] ? nbatch[i] : n);
+                    acc += n;
+                    a.blk_end[i] = (int32_t)acc;
+                }
+                const int grid = (int)acc;
+                if ((rc = xt_grad_reserve(ctx, &ctx->d_gpartials, &ctx->gpartials_cap, (size_t)grid * (NP + 1) + (size_t)(NP + 1)))) return rc;
+                a.desc = ctx->d_desc + doff;
+                a.ndesc = (int32_t)descs.size();
+                a.blob = ctx->d_blob;
+                a.TPB = tpb;
+                a.min_len = m->min_len;
+                a.locerr_mode = 0;
+                a.KS = 1;
+                a.well_scaled = xt_model_well_scaled(blob, lo, hi) ? 1 : 0;
+                ga.dblob = ctx->d_dblob + (size_t)p0 * TB;
+                ga.gpartials = ctx->d_gpartials;
+                ga.NP = NP;
+                ga.TB = TB;
+                XT_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+                void* kargs[2] = {(void*)&a, (void*)&ga};
+                XT_HIP(ctx, hipLaunchKernel(kp, dim3(grid), dim3(threads), kargs, lds, ctx->stream));
+                XT_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+                double* d_out = ctx->d_gpartials + (size_t)grid * (NP + 1);
+                hipLaunchKernelGGL(xt_grad_reduce, dim3(NP + 1), dim3(256), 0, ctx->stream, ctx->d_gpartials, grid, NP + 1, d_out);
+                XT_HIP(ctx, hipGetLastError());
+                host_out.assign((size_t)NP + 1, 0.0);
+                XT_HIP(ctx, hipMemcpyAsync(host_out.data(), d_out, (size_t)(NP + 1) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+                XT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                float ms = 0.f;
+                XT_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+                ms_total += ms;
+                if (p0 == 0) *total_ll += host_out[0];
+                for (int i = 0; i < NP; ++i) grad[p0 + i] += host_out[1 + i];
+                ctx->launch_info[0] = grid;
+                ctx->launch_info[1] = threads;
+                ctx->launch_info[2] = (int32_t)lds;
+                ctx->launch_info[3] = tpb;
+                ctx->launch_info[4] = occ;
+                ctx->launch_info[5] = ctx->n_cu;
+            }
+            doff += g.size();
+            continue;
+        }
         for (int p0 = 0; p0 < std::max(n_dir, 1); p0 += npass_dir) {
             const int NP = n_dir == 0 ? 0 : std::min(npass_dir, n_dir - p0);
             GradLauncher l;

@@ -5,6 +5,7 @@
 #include "xt_dispatch.h"
 #include "xt_entry.h"
 #include "xt_fast2.h"
+#include "xt_reg2.h"
 
 template <int G_, int D, int K, bool PREDS, int MAXT>
 __global__ void __launch_bounds__(MAXT, (MAXT == 256 && !PREDS && G_ != 4 ? 4 : 1)) xt_track_kernel(XtKernelArgs a)
@@ -98,6 +99,8 @@ extern "C" int extrack_create(int device_id, extrack_ctx** out)
         int v = atoi(ev);
         if (v >= 1 && v <= 64) c->oversub = v;
     }
+    if (const char* ev = getenv("EXTRACK_LL_PATH")) c->ll_reg2 = strcmp(ev, "reg2") == 0 ? 1 : (strcmp(ev, "lds") == 0 ? 0 : c->ll_reg2);
+    if (const char* ev = getenv("EXTRACK_GRAD_PATH")) c->grad_reg2 = strcmp(ev, "lds") == 0 ? 0 : 1;
     if (const char* ev = getenv("EXTRACK_TH_TT")) {
         int v = atoi(ev);
         if (v >= 1 && v <= 256 && (v & (v - 1)) == 0) c->th_force_tt = v;
@@ -456,13 +459,21 @@ struct DevLauncher {
     template <int F, int D, int K>
     bool run_f2()
     {
+        if (ctx->ll_reg2) {  // register-resident variant (xt_reg2.h)
+            const void* kp = xt_r2_kernel(F, D, K, 0);
+            return kp ? launch_ptr(kp) : false;
+        }
         return launch(xt_ll_s2_kernel<F, D, K>);
     }
 
     template <class KernT>
     bool launch(KernT kern)
     {
-        const void* kp = (const void*)kern;
+        return launch_ptr((const void*)kern);
+    }
+
+    bool launch_ptr(const void* kp)
+    {
         auto key = std::make_pair(kp, std::make_pair(threads, lds));
         auto it = ctx->occ_cache.find(key);
         if (it == ctx->occ_cache.end()) {
@@ -471,7 +482,7 @@ struct DevLauncher {
                 if (herr != hipSuccess) return true;
             }
             int o = 0;
-            herr = hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, kern, threads, lds);
+            herr = hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, kp, threads, lds);
             if (herr != hipSuccess) return true;
             it = ctx->occ_cache.emplace(key, o < 1 ? 1 : o).first;
         }
@@ -504,8 +515,9 @@ struct DevLauncher {
         if (herr != hipSuccess) return true;
         a.desc = ctx->d_desc + desc_off;
         a.ndesc = nb;
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, ctx->stream, a);
-        herr = hipGetLastError();
+        void* kargs[1] = {(void*)&a};
+        herr = hipLaunchKernel(kp, dim3(grid), dim3(threads), kargs, lds, ctx->stream);
+        if (herr == hipSuccess) herr = hipGetLastError();
         return true;
     }
 };
@@ -550,7 +562,8 @@ static int xt_launch_group(extrack_ctx* ctx, const extrack_model* m, const std::
         const int tpw = 64 >> (c.F - 1);
         tpb = tpw * XT_F2_WAVES;
         threads = 64 * XT_F2_WAVES;
-        l.lds = (size_t)xt_f2_block_bytes(D, K, m->locerr_mode ? b0.KS : 0, tpw);
+        l.lds = ctx->ll_reg2 ? (size_t)xt_r2_block_bytes(0, D, m->locerr_mode ? b0.KS : 0, tpw)
+                             : (size_t)xt_f2_block_bytes(D, K, m->locerr_mode ? b0.KS : 0, tpw);
     } else {
         xt_geometry(c, D, K, tpb, threads);
         if (threads > 1024) return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "n_states^(frame_len-nb_substeps) > 1024 groups per track is not built");

@@ -90,6 +90,57 @@ struct DevCtx {
         if (GP >= 64) v = mx(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 32));
         return v;
     }
+    // ---- lane-pair primitives of the register-resident 2-state path (xt_reg2.h).  BIT = lane-id bit of the pair (partner = lane ^ 2^BIT).
+    // xor_*: the partner's value.  Bits 0, 1, 3: one DPP move per dword; bit 2: row_shl:4 / row_shr:4 under complementary bank masks;
+    // bit 4: ds_swizzle (xor 16 inside 32 lanes); bit 5: v_permlane32_swap of two copies.
+    template <int BIT>
+    __device__ static __forceinline__ int xor_i32(int v)
+    {
+        if (BIT == 0) return dpp_i32<0xB1>(v);   // quad_perm [1,0,3,2]
+        if (BIT == 1) return dpp_i32<0x4E>(v);   // quad_perm [2,3,0,1]
+        if (BIT == 2) {
+            const int r = __builtin_amdgcn_update_dpp(v, v, 0x104, 0xf, 0x5, false);  // quads 0, 2 read lane + 4
+            return __builtin_amdgcn_update_dpp(r, v, 0x114, 0xf, 0xA, false);          // quads 1, 3 read lane - 4
+        }
+        if (BIT == 3) return dpp_i32<0x128>(v);  // row_ror:8
+        if (BIT == 4) return __builtin_amdgcn_ds_swizzle(v, 0x401F);
+        const auto r = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
+        return (threadIdx.x & 32) ? (int)r[0] : (int)r[1];
+    }
+    template <int BIT>
+    __device__ static __forceinline__ double xor_f64(double v)
+    {
+        return __hiloint2double(xor_i32<BIT>(__double2hiint(v)), xor_i32<BIT>(__double2loint(v)));
+    }
+    // pair_exchange: the 2 x 2 transpose of a step.  Before: a, b = the lane's two new sequences (new digit qa for a, 1 - qa for b); after:
+    // a, b = the two sequences of the lane's next group (newest digit = the lane's bit BIT).  "Natural" bits (4, 5): qa = 0 and the
+    // permlane swap instructions transpose directly; the other bits: qa = the lane's own bit, a stays and b is traded with the partner.
+    template <int BIT>
+    __device__ static constexpr bool pair_natural() { return BIT >= 4; }
+    template <int BIT>
+    __device__ static __forceinline__ void pair_exchange_i32(int& a, int& b)
+    {
+        if (BIT == 4) {
+            const auto r = __builtin_amdgcn_permlane16_swap((unsigned)a, (unsigned)b, false, false);
+            a = (int)r[0];
+            b = (int)r[1];
+        } else if (BIT == 5) {
+            const auto r = __builtin_amdgcn_permlane32_swap((unsigned)a, (unsigned)b, false, false);
+            a = (int)r[0];
+            b = (int)r[1];
+        } else {
+            b = xor_i32<BIT>(b);
+        }
+    }
+    template <int BIT>
+    __device__ static __forceinline__ void pair_exchange(double& a, double& b)
+    {
+        int ah = __double2hiint(a), al = __double2loint(a), bh = __double2hiint(b), bl = __double2loint(b);
+        pair_exchange_i32<BIT>(ah, bh);
+        pair_exchange_i32<BIT>(al, bl);
+        a = __hiloint2double(ah, al);
+        b = __hiloint2double(bh, bl);
+    }
     __device__ __forceinline__ int shfl_xor_i32(int v, int m) { return __shfl_xor(v, m, 64); }
     __device__ __forceinline__ double shfl_xor_f64(double v, int m) { return __shfl_xor(v, m, 64); }
     __device__ __forceinline__ void atomic_max_i32(int* p, int v)
@@ -135,6 +186,8 @@ struct extrack_ctx {
     int device = 0;
     int n_cu = 0;
     int oversub = 8;  // block generations per CU (EXTRACK_OVERSUB overrides; tuning knob)
+    int ll_reg2 = 1;  // 2-state likelihood: 1 = register-resident kernel (xt_reg2.h), 0 = LDS-resident (xt_fast2.h); EXTRACK_LL_PATH=reg2|lds
+    int grad_reg2 = 1;  // 2-state gradient: register-resident kernel where built (EXTRACK_GRAD_PATH=reg2|lds)
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     std::vector<XtBucket> buckets;
@@ -238,3 +291,4 @@ int xt_reserve_partials(extrack_ctx* ctx, size_t n);
 size_t xt_desc_base(const extrack_ctx* ctx);
 size_t xt_max_grid(const extrack_ctx* ctx);
 __global__ void xt_reduce_partials(const double* __restrict__ partials, int n, double* __restrict__ out);
+const void* xt_r2_kernel(int F, int D, int K, int NP);  // extrack_reg2.hip: register-resident 2-state kernels, nullptr = not built

@@ -9,6 +9,7 @@
 #include <thread>
 #include <vector>
 
+#include "emul_ctx.h"
 #include "../../extrack_amd/csrc/xt_dispatch.h"
 #include "../../extrack_amd/csrc/xt_entry.h"
 #include "../../extrack_amd/csrc/xt_fast2.h"
@@ -16,95 +17,9 @@
 #include "../../extrack_amd/csrc/xt_grad_host.h"
 #include "../../extrack_amd/csrc/xt_hist.h"
 #include "../../extrack_amd/csrc/xt_hist_host.h"
+#include "../../extrack_amd/csrc/xt_reg2.h"
 #include "../../extrack_amd/csrc/xt_tables.h"
 #include "../../extrack_amd/csrc/xt_th.h"
-
-struct HostCtx {
-    int tid_, nthreads_, block_, nblocks_;
-    double* smem_;
-    pthread_barrier_t* bar_;
-    pthread_barrier_t* wbar_ = nullptr;  // this wave's barrier
-    double* wscr_ = nullptr;             // this wave's 64-entry shuffle scratch
-    int lane() const { return tid_ & 63; }
-    int uniform(int v) const { return v; }
-    int wave_in_block() const { return tid_ >> 6; }
-    int waves_per_block() const { return nthreads_ >> 6; }
-    void wave_sync() { pthread_barrier_wait(wbar_); }
-    double shfl_xor_f64(double v, int m)
-    {
-        wscr_[lane()] = v;
-        pthread_barrier_wait(wbar_);
-        double o = wscr_[lane() ^ m];
-        pthread_barrier_wait(wbar_);
-        return o;
-    }
-    int shfl_xor_i32(int v, int m) { return (int)shfl_xor_f64((double)v, m); }
-    template <int GP>
-    double group_sum_f64(double v)
-    {
-        for (int m = 1; m < GP; m <<= 1) v += shfl_xor_f64(v, m);
-        return v;
-    }
-    template <int GP>
-    int group_max_i32(int v)
-    {
-        for (int m = 1; m < GP; m <<= 1) {
-            const int o = shfl_xor_i32(v, m);
-            v = o > v ? o : v;
-        }
-        return v;
-    }
-    unsigned long long ballot(bool flag)
-    {
-        wscr_[lane()] = flag ? 1.0 : 0.0;
-        pthread_barrier_wait(wbar_);
-        unsigned long long m = 0;
-        for (int i = 0; i < 64; ++i)
-            if (wscr_[i] != 0.0) m |= 1ull << i;
-        pthread_barrier_wait(wbar_);
-        return m;
-    }
-    int wave_rank(bool flag, int& total)
-    {
-        wscr_[lane()] = flag ? 1.0 : 0.0;
-        pthread_barrier_wait(wbar_);
-        int r = 0, t = 0;
-        for (int i = 0; i < 64; ++i) {
-            const int f = wscr_[i] != 0.0;
-            t += f;
-            r += (i < lane()) ? f : 0;
-        }
-        pthread_barrier_wait(wbar_);
-        total = t;
-        return r;
-    }
-    int tid() const { return tid_; }
-    int nthreads() const { return nthreads_; }
-    int block() const { return block_; }
-    int nblocks() const { return nblocks_; }
-    double* smem() const { return smem_; }
-    void sync() { pthread_barrier_wait(bar_); }
-    void atomic_max_i32(int* p, int v)
-    {
-        int old = __atomic_load_n(p, __ATOMIC_RELAXED);
-        while (old < v && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {
-        }
-    }
-    void atomic_or_u32(uint32_t* p, uint32_t v) { __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
-    void atomic_add_f64(double* p, double v)
-    {
-        uint64_t* pi = (uint64_t*)p;
-        uint64_t old = __atomic_load_n(pi, __ATOMIC_RELAXED);
-        for (;;) {
-            double d;
-            memcpy(&d, &old, 8);
-            d += v;
-            uint64_t nw;
-            memcpy(&nw, &d, 8);
-            if (__atomic_compare_exchange_n(pi, &old, nw, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) break;
-        }
-    }
-};
 
 struct EmulLauncher {
     XtKernelArgs a;
@@ -190,6 +105,8 @@ struct EmulLauncher {
     }
 };
 
+bool emul_r2(int F, int D, int K, int KS, int NP, const XtKernelArgs& a, const XtGradArgs& ga, int nblocks);  // emul_r2.cpp
+
 extern "C" int xt_emul_run(const double* tracks, const double* sigma, long long N, int L, int D, int KS, int S, int NS, int F,
                            int isBL, int min_len, int locerr_mode, int locerr_dims, const double* locerr, double slope,
                            double offset, double pBL, const double* ds, const double* Fs, const double* TrMat,
@@ -256,7 +173,16 @@ extern "C" int xt_emul_run(const double* tracks, const double* sigma, long long 
         info[2] = (int)l.lds_bytes;
         info[3] = cfg.E;
     }
-    if (xt_use_fast2(S, NS, F, preds != 0) && !getenv("XT_EMUL_GENERIC")) {
+    if (xt_use_reg2(S, NS, F) && !preds && getenv("XT_EMUL_REG2")) {
+        XtGradArgs ga;
+        memset(&ga, 0, sizeof(ga));
+        if (info) {
+            info[0] = 64 >> (F - 1);
+            info[1] = 64 * XT_F2_WAVES;
+            info[2] = xt_r2_block_bytes(0, D, locerr_mode ? KS : 0, 64 >> (F - 1));
+        }
+        if (!emul_r2(F, D, K, locerr_mode ? KS : 0, 0, l.a, ga, nblocks)) return -3;
+    } else if (xt_use_fast2(S, NS, F, preds != 0) && !getenv("XT_EMUL_GENERIC")) {
         l.threads = 64 * XT_F2_WAVES;
         l.a.TPB = 0;
         l.lds_bytes = (size_t)xt_f2_block_bytes(D, K, locerr_mode ? KS : 0, 64 >> (F - 1));
@@ -359,32 +285,6 @@ extern "C" int xt_emul_run_multi(int nbuckets, const double** tracks, const long
     return 0;
 }
 
-
-// ---- threshold-fusion kernels (xt_th.h): plan + apply for ONE bucket, emulated block by block.
-template <class Body>
-static void th_emul_blocks(int nblocks, int threads, size_t lds_doubles, Body body)
-{
-    const int nw = threads / 64;
-    for (int b = 0; b < nblocks; ++b) {
-        std::vector<double> smem(lds_doubles + 16, 0.0);
-        pthread_barrier_t bar;
-        pthread_barrier_init(&bar, nullptr, threads);
-        std::vector<pthread_barrier_t> wb(nw);
-        std::vector<std::vector<double>> ws(nw, std::vector<double>(64, 0.0));
-        for (auto& x : wb) pthread_barrier_init(&x, nullptr, 64);
-        std::vector<std::thread> th;
-        for (int t = 0; t < threads; ++t)
-            th.emplace_back([&, t]() {
-                HostCtx cx{t, threads, b, nblocks, smem.data(), &bar};
-                cx.wbar_ = &wb[t >> 6];
-                cx.wscr_ = ws[t >> 6].data();
-                body(cx);
-            });
-        for (auto& x : th) x.join();
-        pthread_barrier_destroy(&bar);
-        for (auto& x : wb) pthread_barrier_destroy(&x);
-    }
-}
 
 // Per-track time steps for the next xt_emul_th_run / xt_emul_th_predict call: dt [N][L] and one p_stay table [G] per chunk.
 static const double* g_th_dt = nullptr;
@@ -810,6 +710,37 @@ extern "C" int xt_emul_grad(const double* tracks, const double* sigma, long long
     if (tan_lds) d += (size_t)((n_dir * TB + 1) & ~1);
     d += (size_t)tpb * ((size_t)xt_grad_region_doubles(cfg.EP, D, K, n_dir) + xt_grad_acc_doubles(n_dir, cfg.NG) + xt_stage_doubles(D));
     l.lds_doubles = d;
+    if (generic_g == 2) {  // register-resident 2-state path, passes of <= 8 directions
+        if (!xt_use_reg2(S, NS, F) || locerr_mode != 0) return -5;
+        double lo = INFINITY, hi = -INFINITY;
+        for (int k = 0; k < locerr_dims && k < 3; ++k) {
+            lo = std::min(lo, m.locerr[k] * m.locerr[k]);
+            hi = std::max(hi, m.locerr[k] * m.locerr[k]);
+        }
+        l.a.well_scaled = (xt_model_well_scaled(blob, lo, hi) && !getenv("XT_EMUL_GUARDED")) ? 1 : 0;
+        if (n_dir == 0) {
+            std::vector<double> part(nblocks, 0.0);
+            l.a.partials = part.data();
+            l.ga.NP = 0;
+            if (!emul_r2(F, D, K, 0, 0, l.a, l.ga, nblocks)) return -3;
+            for (int b = 0; b < nblocks; ++b) out[0] += part[b];
+        }
+        for (int p0 = 0; p0 < n_dir;) {  // passes of 3 or 8 directions (what emul_r2.cpp instantiates), padded with zero directions
+            const int NPp = n_dir - p0 > 3 ? 8 : 3, real = std::min(NPp, n_dir - p0);
+            std::vector<double> gp2((size_t)nblocks * (NPp + 1), 0.0), pad((size_t)NPp * TB, 0.0);
+            memcpy(pad.data(), dblob.data() + (size_t)p0 * TB, (size_t)real * TB * sizeof(double));
+            l.ga.dblob = pad.data();
+            l.ga.gpartials = gp2.data();
+            l.ga.NP = NPp;
+            if (!emul_r2(F, D, K, 0, NPp, l.a, l.ga, nblocks)) return -3;
+            for (int b = 0; b < nblocks; ++b) {
+                if (p0 == 0) out[0] += gp2[(size_t)b * (NPp + 1)];
+                for (int c = 0; c < real; ++c) out[1 + p0 + c] += gp2[(size_t)b * (NPp + 1) + 1 + c];
+            }
+            p0 += real;
+        }
+        return 0;
+    }
     bool ok;
     if (generic_g || cfg.G > 4) ok = emul_grad_dispatch_dk<0>(D, K, l);
     else if (cfg.G == 2) ok = emul_grad_dispatch_dk<2>(D, K, l);

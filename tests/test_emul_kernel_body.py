@@ -41,11 +41,17 @@ def test_generic_body_on_golden_subset(kernel_cases, monkeypatch):
     assert n > 150 and worst < 1e-10 and worstp < 1e-9, (n, worst, worstp)
 
 
+@pytest.mark.parametrize("reg2", [False, True])
 @pytest.mark.parametrize("guarded", [False, True])
-def test_fast2_body_on_golden_two_state_cases(kernel_cases, guarded, monkeypatch):
+def test_fast2_body_on_golden_two_state_cases(kernel_cases, guarded, reg2, monkeypatch):
     """guarded: the fully guarded steps of the fast path (per-step normalisation of every weight, zero handling) instead of the lazy /
-    zero-free ones that well-scaled models take."""
+    zero-free ones that well-scaled models take.  reg2: the register-resident body (xt_reg2.h, the product's default 2-state kernel:
+    state in VGPRs, lane exchanges) instead of the LDS-resident one (xt_fast2.h)."""
     monkeypatch.delenv("XT_EMUL_GENERIC", raising=False)
+    if reg2:
+        monkeypatch.setenv("XT_EMUL_REG2", "1")
+    else:
+        monkeypatch.delenv("XT_EMUL_REG2", raising=False)
     if guarded:
         monkeypatch.setenv("XT_EMUL_GUARDED", "1")
     else:
@@ -54,7 +60,7 @@ def test_fast2_body_on_golden_two_state_cases(kernel_cases, guarded, monkeypatch
     worst = 0.0
     n = 0
     for row in meta:
-        if not (row["S"] == 2 and row["ns"] == 1 and row["F"] in (4, 6)) or row["id"] % 2:
+        if not (row["S"] == 2 and row["ns"] == 1 and row["F"] in (4, 6)) or row["id"] % (4 if reg2 else 2):
             continue
         x = case_inputs(row, data)
         ll, _, tot, info = _run(row, x, False, nblocks=1)
@@ -62,13 +68,17 @@ def test_fast2_body_on_golden_two_state_cases(kernel_cases, guarded, monkeypatch
         worst = max(worst, np.abs(ll - x["LPC"]).max())
         assert abs(tot - ll.sum()) < 1e-9
         n += 1
-    assert n > 60 and worst < 1e-10, (n, worst)
+    assert n > (30 if reg2 else 60) and worst < 1e-10, (n, worst)
 
 
-@pytest.mark.parametrize("F,L,N", [(5, 40, 11), (7, 70, 5), (6, 33, 9), (4, 65, 17)])
-def test_fast2_multi_chunk_tracks(F, L, N, monkeypatch):
-    """Tracks longer than one 32-position staging chunk, partial last batch, several blocks."""
+@pytest.mark.parametrize("F,L,N,reg2", [(5, 40, 11, 0), (7, 70, 5, 0), (6, 33, 9, 0), (4, 65, 17, 0), (5, 40, 11, 1), (7, 70, 5, 1), (6, 33, 9, 1), (4, 65, 17, 1)])
+def test_fast2_multi_chunk_tracks(F, L, N, reg2, monkeypatch):
+    """Tracks longer than one 32-position staging chunk, partial last batch, several blocks (reg2: register-resident body)."""
     monkeypatch.delenv("XT_EMUL_GENERIC", raising=False)
+    if reg2:
+        monkeypatch.setenv("XT_EMUL_REG2", "1")
+    else:
+        monkeypatch.delenv("XT_EMUL_REG2", raising=False)
     import sys, os
     sys.path.insert(0, os.path.join(os.path.dirname(__file__), "emul"))
     import run_emul as E
