@@ -16,7 +16,7 @@ EXPORTS = [
     "extrack_upload_bucket", "extrack_attach_bucket", "extrack_set_bucket_dt", "extrack_clear_buckets", "extrack_bucket_count",
     "extrack_loglik", "extrack_loglik_async", "extrack_predict", "extrack_last_kernel_ms",
     "extrack_last_launch_info", "extrack_p_stay_table", "extrack_loglik_th", "extrack_loglik_th_async", "extrack_th_plan_step",
-    "extrack_predict_th", "extrack_loglik_grad", "extrack_last_grad_ms", "extrack_segment_len_hist", "extrack_refine_positions",
+    "extrack_predict_th", "extrack_loglik_grad", "extrack_loglik_grad_async", "extrack_last_grad_ms", "extrack_segment_len_hist", "extrack_refine_positions",
 ]
 
 _dp = C.POINTER(C.c_double)
@@ -103,10 +103,11 @@ def load():
     lib.extrack_predict_th.argtypes = [vp, C.POINTER(ExtrackModel), i32, C.c_double, i32, i32, vp]
     lib.extrack_th_plan_step.argtypes = [vp, i32, i64, i32, C.POINTER(i32), C.POINTER(i32), vp, vp, i32]
     lib.extrack_loglik_grad.argtypes = [vp, C.POINTER(ExtrackModel), i32, C.POINTER(ExtrackModelTangent), _dp, vp]
+    lib.extrack_loglik_grad_async.argtypes = [vp, C.POINTER(ExtrackModel), i32, C.POINTER(ExtrackModelTangent), vp]
     lib.extrack_segment_len_hist.argtypes = [vp, C.POINTER(ExtrackModel), i32, i32, vp]
     lib.extrack_refine_positions.argtypes = [vp, C.POINTER(ExtrackModel), i32, C.c_double, i32, vp, vp]
     lib.extrack_last_grad_ms.argtypes = [vp, C.POINTER(C.c_float)]
-    if lib.extrack_abi_version() != 3:
+    if lib.extrack_abi_version() != 4:
         raise ImportError("libextrack_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -233,28 +234,55 @@ class Context:
         self._check(self._lib.extrack_loglik(self._h, C.byref(model.c), C.byref(tot), out.ctypes.data_as(C.c_void_p) if per_track else None))
         return (tot.value, out) if per_track else tot.value
 
-    def loglik_grad(self, model, tangents):
-        """(sum LL, d sum LL / d theta_i) for the model directions ``tangents``: list of dicts with the keys ds2 [S], Fs [S],
-        TrMat [S, S], p_stay [S**ns] and optionally locerr (<= 3 values), slope, offset, pBL."""
-        n = len(tangents)
+    @staticmethod
+    def _pack_tangents(model, tangents):
+        """(n, ctypes array of extrack_model_tangent, keep-alive list) from the packed dict of gradient.model_tangents (arrays with the
+        direction as first axis: ds2 [n, S], Fs [n, S], TrMat [n, S, S], p_stay [n, G] and optionally locerr [n, <= 3], slope, offset,
+        pBL [n]) or from a list of per-direction dicts with the same keys."""
+        S = model.c.n_states
+        G = model.p_stay.shape[-1]
+        if isinstance(tangents, dict):
+            n = len(np.atleast_1d(tangents["pBL"])) if "pBL" in tangents else len(tangents["ds2"])
+            get = lambda k, shp: _f64(np.broadcast_to(np.asarray(tangents.get(k, 0.0), float), (n,) + shp))
+        else:
+            n = len(tangents)
+            get = lambda k, shp: _f64(np.array([np.broadcast_to(np.asarray(t.get(k, 0.0), float), shp) for t in tangents]).reshape((n,) + shp))
         arr = (ExtrackModelTangent * max(n, 1))()
         keep = []
-        for i, t in enumerate(tangents):
-            e = arr[i]
-            le = np.zeros(3)
-            v = np.atleast_1d(np.asarray(t.get("locerr", 0.0), float)).ravel()
-            le[:len(v)] = v
-            e.locerr = (C.c_double * 3)(*le)
-            e.slope, e.offset, e.pBL = float(t.get("slope", 0.0)), float(t.get("offset", 0.0)), float(t.get("pBL", 0.0))
-            S = model.c.n_states
-            a4 = [_f64(np.broadcast_to(np.asarray(t.get(k, 0.0), float), shp)) for k, shp in
-                  (("ds2", (S,)), ("Fs", (S,)), ("TrMat", (S, S)), ("p_stay", model.p_stay.shape))]
-            keep.append(a4)
-            e.ds2, e.Fs, e.TrMat, e.p_stay = [x.ctypes.data_as(_dp) for x in a4]
+        if n:
+            le = np.zeros((n, 3))
+            if isinstance(tangents, dict):
+                v = np.asarray(tangents.get("locerr", np.zeros((n, 0))), float).reshape(n, -1)
+                le[:, :v.shape[1]] = v
+            else:
+                for i, t in enumerate(tangents):
+                    v = np.atleast_1d(np.asarray(t.get("locerr", 0.0), float)).ravel()
+                    le[i, :len(v)] = v
+            sl, of, pb = get("slope", ()), get("offset", ()), get("pBL", ())
+            keep = [get("ds2", (S,)), get("Fs", (S,)), get("TrMat", (S, S)), get("p_stay", (G,))]
+            base = [x.ctypes.data for x in keep]
+            step = [x.strides[0] for x in keep]
+            for i in range(n):
+                e = arr[i]
+                e.locerr[0], e.locerr[1], e.locerr[2] = le[i]
+                e.slope, e.offset, e.pBL = sl[i], of[i], pb[i]
+                e.ds2, e.Fs, e.TrMat, e.p_stay = [C.cast(b + i * st, _dp) for b, st in zip(base, step)]
+        return n, arr, keep
+
+    def loglik_grad(self, model, tangents):
+        """(sum LL, d sum LL / d theta_i) for the model directions ``tangents`` (see ``_pack_tangents``)."""
+        n, arr, keep = self._pack_tangents(model, tangents)
         tot = C.c_double(0.0)
         g = np.zeros(max(n, 1))
         self._check(self._lib.extrack_loglik_grad(self._h, C.byref(model.c), n, arr, C.byref(tot), g.ctypes.data_as(C.c_void_p)))
         return tot.value, g[:n]
+
+    def loglik_grad_async(self, model, tangents, d_out_ptr):
+        """Enqueues the evaluation on the context's stream; the DEVICE buffer ``d_out_ptr`` (1 + n doubles) receives
+        {sum LL, gradient} in stream order (the multi-GPU objective all-reduces it there)."""
+        n, arr, keep = self._pack_tangents(model, tangents)
+        self._check(self._lib.extrack_loglik_grad_async(self._h, C.byref(model.c), n, arr, C.c_void_p(d_out_ptr)))
+        return n
 
     def segment_len_hist(self, model, bucket_id, max_nb_states=500):
         """State-duration histogram [len - 1, S] of one bucket (extrack/histograms.py:26-286 semantics, see include/extrack_hip.h)."""

@@ -7,7 +7,8 @@
 #include "xt_reg2.h"
 
 // Waves per SIMD the register allocator is asked to allow.  Measured on C2 (1e6 x 30, 7 directions, PJ = 4): 2 -> 63 ms,
-// 3 -> 53 ms (168 VGPRs, 108 B of scratch per lane), 4 -> 60 ms (128 VGPRs, 272 B of scratch).
+// 3 -> 53 ms (168 VGPRs, 108 B of scratch per lane), 4 -> 60 ms (128 VGPRs, 272 B of scratch).  Three members per group (C3, 13 directions): 3 waves (232 B of
+// scratch) 78.8 ms, 2 waves (248 VGPRs, no scratch) 91.5 ms - the spills are not what bounds this kernel (r03).
 #ifndef XT_GRAD_WAVES
 #define XT_GRAD_WAVES 3
 #endif
@@ -18,8 +19,10 @@ __global__ void __launch_bounds__(MAXT, (MAXT == 256 ? XT_GRAD_WAVES : 1)) xt_gr
     xt_grad_body<G_, D, K>(a, ga, cx);
 }
 
-// Column sums of the per-block partials [nrows][ncol] in a fixed order: one workgroup per column.
-__global__ void __launch_bounds__(256) xt_grad_reduce(const double* __restrict__ partials, int nrows, int ncol, double* __restrict__ out)
+// Column sums of the per-block partials [nrows][ncol] in a fixed order: one workgroup per column.  Column 0 (sum LL) goes to ll_dst
+// (nullptr: dropped - every pass recomputes it, only the first one reports it), column 1 + i to out[i].
+__global__ void __launch_bounds__(256) xt_grad_reduce(const double* __restrict__ partials, int nrows, int ncol, double* __restrict__ ll_dst,
+                                                      double* __restrict__ out)
 {
     __shared__ double sh[256];
     const int col = blockIdx.x;
@@ -31,7 +34,13 @@ __global__ void __launch_bounds__(256) xt_grad_reduce(const double* __restrict__
         if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
         __syncthreads();
     }
-    if (threadIdx.x == 0) out[col] = sh[0];
+    if (threadIdx.x == 0) {
+        if (col == 0) {
+            if (ll_dst) *ll_dst = sh[0];
+        } else {
+            out[col - 1] = sh[0];
+        }
+    }
 }
 
 struct GradLauncher {
@@ -103,14 +112,13 @@ static int xt_grad_reserve(extrack_ctx* ctx, double** buf, size_t* cap, size_t n
     return EXTRACK_OK;
 }
 
-extern "C" int extrack_loglik_grad(extrack_ctx* ctx, const extrack_model* m, int32_t n_dir, const extrack_model_tangent* tangents,
-                                   double* total_ll, double* grad)
+// Enqueues the kernels of one likelihood + gradient evaluation on the context's stream; d_out (device, 1 + n_dir doubles) receives
+// {sum LL, d sum LL / d theta_i}.  Nothing waits for the device: passes and launch groups accumulate in stream order.
+static int xt_grad_enqueue(extrack_ctx* ctx, const extrack_model* m, int32_t n_dir, const extrack_model_tangent* tangents, double* d_out)
 {
-    if (!ctx || !total_ll || n_dir < 0 || (n_dir > 0 && (!tangents || !grad))) return xt_fail(ctx, EXTRACK_E_INVALID, "null argument");
     int rc = xt_validate_model(ctx, m);
     if (rc) return rc;
     if (ctx->buckets.empty()) return xt_fail(ctx, EXTRACK_E_INVALID, "no bucket uploaded");
-    if (n_dir == 0) return extrack_loglik(ctx, m, total_ll, nullptr);  // no direction: the plain likelihood kernels
     for (int i = 0; i < n_dir; ++i)
         if (!tangents[i].ds2 || !tangents[i].Fs || !tangents[i].TrMat || !tangents[i].p_stay)
             return xt_fail(ctx, EXTRACK_E_INVALID, "null tangent field");
@@ -123,10 +131,25 @@ extern "C" int extrack_loglik_grad(extrack_ctx* ctx, const extrack_model* m, int
     xt_build_blob(mh, c, blob);
     if ((rc = xt_upload_blob(ctx, blob))) return rc;
     const int TB = xt_grad_tb_doubles(c.S, c.G);
-    std::vector<double> dblob((size_t)std::max(n_dir, 1) * TB, 0.0);
-    for (int i = 0; i < n_dir; ++i) xt_build_tangent_block(mh, tangents[i], c, m->locerr_mode, dblob.data() + (size_t)i * TB);
-    if ((rc = xt_grad_reserve(ctx, &ctx->d_dblob, &ctx->dblob_cap, dblob.size()))) return rc;
-    XT_HIP(ctx, hipMemcpyAsync(ctx->d_dblob, dblob.data(), dblob.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    // tangent tables: built in a pinned staging buffer the asynchronous copy reads from; an event guards its reuse by the next call
+    const size_t ndbl = (size_t)std::max(n_dir, 1) * TB;
+    if (ctx->dblob_busy) {
+        XT_HIP(ctx, hipEventSynchronize(ctx->ev_dblob));
+        ctx->dblob_busy = false;
+    }
+    if (ndbl > ctx->h_dblob_cap) {
+        if (ctx->h_dblob) (void)hipHostFree(ctx->h_dblob);
+        ctx->h_dblob = nullptr;
+        ctx->h_dblob_cap = 0;
+        XT_HIP(ctx, hipHostMalloc((void**)&ctx->h_dblob, ndbl * sizeof(double)));
+        ctx->h_dblob_cap = ndbl;
+    }
+    if (!ctx->ev_dblob) XT_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_dblob, hipEventDisableTiming));
+    for (int i = 0; i < n_dir; ++i) xt_build_tangent_block(mh, tangents[i], c, m->locerr_mode, ctx->h_dblob + (size_t)i * TB);
+    if ((rc = xt_grad_reserve(ctx, &ctx->d_dblob, &ctx->dblob_cap, ndbl))) return rc;
+    XT_HIP(ctx, hipMemcpyAsync(ctx->d_dblob, ctx->h_dblob, ndbl * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    XT_HIP(ctx, hipEventRecord(ctx->ev_dblob, ctx->stream));
+    ctx->dblob_busy = true;
 
     // launch groups: buckets with the same (dims, sigma dims), longest first
     std::vector<XtBucket*> order;
@@ -144,11 +167,12 @@ extern "C" int extrack_loglik_grad(extrack_ctx* ctx, const extrack_model* m, int
     }
     if (order.size() > (size_t)XT_DESC_CAP / 2) return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "too many buckets");
 
-    *total_ll = 0.0;
-    for (int i = 0; i < n_dir; ++i) grad[i] = 0.0;
-    std::vector<double> host_out;
+    if (groups.size() > 1) return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "gradient: buckets of different dimensionality / error layout in one dataset");
     size_t doff = xt_desc_base(ctx);
-    float ms_total = 0.f;
+    // per-block partial sums of every pass of the evaluation, one after the other (a pass has at most 32 blocks per CU)
+    size_t poff = 0;
+    if ((rc = xt_grad_reserve(ctx, &ctx->d_gpartials, &ctx->gpartials_cap, ((size_t)ctx->n_cu * 32 * 4 + XT_MAX_BUCKETS) * ((size_t)n_dir + 16)))) return rc;
+    XT_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     for (auto& g : groups) {
         const XtBucket& b0 = *g[0];
         const int D = b0.D;
@@ -225,7 +249,7 @@ extern "C" int extrack_loglik_grad(extrack_ctx* ctx, const extrack_model* m, int
                     a.blk_end[i] = (int32_t)acc;
                 }
                 const int grid = (int)acc;
-                if ((rc = xt_grad_reserve(ctx, &ctx->d_gpartials, &ctx->gpartials_cap, (size_t)grid * (NP + 1) + (size_t)(NP + 1)))) return rc;
+                if (poff + (size_t)grid * (NP + 1) > ctx->gpartials_cap) return xt_fail(ctx, EXTRACK_E_HIP, "gradient partial-sum buffer too small");
                 a.desc = ctx->d_desc + doff;
                 a.ndesc = (int32_t)descs.size();
                 a.blob = ctx->d_blob;
@@ -235,24 +259,15 @@ extern "C" int extrack_loglik_grad(extrack_ctx* ctx, const extrack_model* m, int
                 a.KS = 1;
                 a.well_scaled = xt_model_well_scaled(blob, lo, hi) ? 1 : 0;
                 ga.dblob = ctx->d_dblob + (size_t)p0 * TB;
-                ga.gpartials = ctx->d_gpartials;
+                ga.gpartials = ctx->d_gpartials + poff;
                 ga.NP = NP;
                 ga.TB = TB;
-                XT_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
                 void* kargs[2] = {(void*)&a, (void*)&ga};
                 XT_HIP(ctx, hipLaunchKernel(kp, dim3(grid), dim3(threads), kargs, lds, ctx->stream));
-                XT_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
-                double* d_out = ctx->d_gpartials + (size_t)grid * (NP + 1);
-                hipLaunchKernelGGL(xt_grad_reduce, dim3(NP + 1), dim3(256), 0, ctx->stream, ctx->d_gpartials, grid, NP + 1, d_out);
+                hipLaunchKernelGGL(xt_grad_reduce, dim3(NP + 1), dim3(256), 0, ctx->stream, ctx->d_gpartials + poff, grid, NP + 1,
+                                   p0 == 0 ? d_out : nullptr, d_out + 1 + p0);
                 XT_HIP(ctx, hipGetLastError());
-                host_out.assign((size_t)NP + 1, 0.0);
-                XT_HIP(ctx, hipMemcpyAsync(host_out.data(), d_out, (size_t)(NP + 1) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-                XT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-                float ms = 0.f;
-                XT_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
-                ms_total += ms;
-                if (p0 == 0) *total_ll += host_out[0];
-                for (int i = 0; i < NP; ++i) grad[p0 + i] += host_out[1 + i];
+                poff += (size_t)grid * (NP + 1);
                 ctx->launch_info[0] = grid;
                 ctx->launch_info[1] = threads;
                 ctx->launch_info[2] = (int32_t)lds;
@@ -306,7 +321,7 @@ extern "C" int extrack_loglik_grad(extrack_ctx* ctx, const extrack_model* m, int
                 l.a.blk_end[i] = (int32_t)acc;
             }
             l.grid = (int)acc;
-            if ((rc = xt_grad_reserve(ctx, &ctx->d_gpartials, &ctx->gpartials_cap, (size_t)l.grid * (NP + 1) + (size_t)(NP + 1)))) return rc;
+            if (poff + (size_t)l.grid * (NP + 1) > ctx->gpartials_cap) return xt_fail(ctx, EXTRACK_E_HIP, "gradient partial-sum buffer too small");
             l.a.desc = ctx->d_desc + doff;
             l.a.ndesc = (int32_t)descs.size();
             l.a.blob = ctx->d_blob;
@@ -317,26 +332,17 @@ extern "C" int extrack_loglik_grad(extrack_ctx* ctx, const extrack_model* m, int
             l.a.locerr_mode = m->locerr_mode;
             l.a.KS = b0.KS ? b0.KS : 1;
             l.ga.dblob = ctx->d_dblob + (size_t)p0 * TB;
-            l.ga.gpartials = ctx->d_gpartials;
+            l.ga.gpartials = ctx->d_gpartials + poff;
             l.ga.NP = NP;
             l.ga.TB = TB;
             l.ga.tan_lds = tan_lds ? 1 : 0;
             l.ga.PJ = PJ;
-            XT_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
             if (!xt_grad_dispatch(c.G, D, K, l)) return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "gradient kernel variant not built");
             if (l.herr != hipSuccess) return xt_fail(ctx, EXTRACK_E_HIP, std::string("gradient kernel launch: ") + hipGetErrorString(l.herr));
-            XT_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
-            double* d_out = ctx->d_gpartials + (size_t)l.grid * (NP + 1);
-            hipLaunchKernelGGL(xt_grad_reduce, dim3(NP + 1), dim3(256), 0, ctx->stream, ctx->d_gpartials, l.grid, NP + 1, d_out);
+            hipLaunchKernelGGL(xt_grad_reduce, dim3(NP + 1), dim3(256), 0, ctx->stream, ctx->d_gpartials + poff, l.grid, NP + 1,
+                               p0 == 0 ? d_out : nullptr, d_out + 1 + p0);
             XT_HIP(ctx, hipGetLastError());
-            host_out.assign((size_t)NP + 1, 0.0);
-            XT_HIP(ctx, hipMemcpyAsync(host_out.data(), d_out, (size_t)(NP + 1) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-            XT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            float ms = 0.f;
-            XT_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
-            ms_total += ms;
-            if (p0 == 0) *total_ll += host_out[0];
-            for (int i = 0; i < NP; ++i) grad[p0 + i] += host_out[1 + i];
+            poff += (size_t)l.grid * (NP + 1);
             ctx->launch_info[0] = l.grid;
             ctx->launch_info[1] = threads;
             ctx->launch_info[2] = (int32_t)l.lds;
@@ -346,14 +352,44 @@ extern "C" int extrack_loglik_grad(extrack_ctx* ctx, const extrack_model* m, int
         }
         doff += g.size();
     }
-    ctx->grad_ms = ms_total;
+    XT_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    ctx->grad_timed = true;
     ctx->timed = false;
+    return EXTRACK_OK;
+}
+
+extern "C" int extrack_loglik_grad_async(extrack_ctx* ctx, const extrack_model* m, int32_t n_dir, const extrack_model_tangent* tangents,
+                                         double* d_out)
+{
+    if (!ctx || !d_out || n_dir < 0 || (n_dir > 0 && !tangents)) return xt_fail(ctx, EXTRACK_E_INVALID, "null argument");
+    if (n_dir == 0) return extrack_loglik_async(ctx, m, d_out);
+    return xt_grad_enqueue(ctx, m, n_dir, tangents, d_out);
+}
+
+extern "C" int extrack_loglik_grad(extrack_ctx* ctx, const extrack_model* m, int32_t n_dir, const extrack_model_tangent* tangents,
+                                   double* total_ll, double* grad)
+{
+    if (!ctx || !total_ll || n_dir < 0 || (n_dir > 0 && (!tangents || !grad))) return xt_fail(ctx, EXTRACK_E_INVALID, "null argument");
+    if (n_dir == 0) return extrack_loglik(ctx, m, total_ll, nullptr);  // no direction: the plain likelihood kernels
+    int rc = xt_grad_reserve(ctx, &ctx->d_gout, &ctx->gout_cap, (size_t)n_dir + 1);
+    if (rc) return rc;
+    if ((rc = xt_grad_enqueue(ctx, m, n_dir, tangents, ctx->d_gout))) return rc;
+    std::vector<double> host((size_t)n_dir + 1);
+    XT_HIP(ctx, hipMemcpyAsync(host.data(), ctx->d_gout, host.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    XT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *total_ll = host[0];
+    for (int i = 0; i < n_dir; ++i) grad[i] = host[1 + i];
     return EXTRACK_OK;
 }
 
 extern "C" int extrack_last_grad_ms(extrack_ctx* ctx, float* ms)
 {
     if (!ctx || !ms) return EXTRACK_E_INVALID;
+    if (ctx->grad_timed) {
+        XT_HIP(ctx, hipEventSynchronize(ctx->ev1));
+        XT_HIP(ctx, hipEventElapsedTime(&ctx->grad_ms, ctx->ev0, ctx->ev1));
+        ctx->grad_timed = false;
+    }
     *ms = ctx->grad_ms;
     return EXTRACK_OK;
 }

@@ -214,6 +214,9 @@ extern "C" void extrack_destroy(extrack_ctx* ctx)
     }
     if (ctx->d_preds) (void)hipFree(ctx->d_preds);
     if (ctx->d_dblob) (void)hipFree(ctx->d_dblob);
+    if (ctx->h_dblob) (void)hipHostFree(ctx->h_dblob);
+    if (ctx->ev_dblob) (void)hipEventDestroy(ctx->ev_dblob);
+    if (ctx->d_gout) (void)hipFree(ctx->d_gout);
     if (ctx->d_th_blobs) (void)hipFree(ctx->d_th_blobs);
     if (ctx->d_gpartials) (void)hipFree(ctx->d_gpartials);
     if (ctx->d_partials) (void)hipFree(ctx->d_partials);

@@ -209,9 +209,16 @@ struct extrack_ctx {
     size_t th_blobs_cap = 0;        // doubles
     double* d_dblob = nullptr;      // gradient path: tangent tables [n_dir][TB]
     size_t dblob_cap = 0;           // doubles
+    double* h_dblob = nullptr;      // pinned staging of the tangent tables (read by an asynchronous copy)
+    size_t h_dblob_cap = 0;
+    hipEvent_t ev_dblob = nullptr;  // recorded after that copy: the next evaluation waits for it before refilling the staging buffer
+    bool dblob_busy = false;
     double* d_gpartials = nullptr;  // gradient path: per-block partial sums [grid][NP + 1] + the reduced row
     size_t gpartials_cap = 0;       // doubles
     float grad_ms = 0.f;            // device time of the gradient kernels of the last extrack_loglik_grad call
+    bool grad_timed = false;        // ev0 / ev1 bracket a gradient evaluation whose time has not been read yet
+    double* d_gout = nullptr;       // gradient path: {sum LL, gradient} of the synchronous entry point
+    size_t gout_cap = 0;
     double* d_partials = nullptr;
     size_t partials_cap = 0;
     double* d_total = nullptr;

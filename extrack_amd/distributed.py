@@ -75,11 +75,28 @@ class Comm:
         self.dist.all_reduce(t, op=ops[op], group=self.group)
         return float(t.item())
 
-    def allreduce_vector(self, v):
-        """Sum of a small fp64 vector over the ranks (objective + gradient: 1 + nvar doubles per evaluation)."""
+    def allreduce_vector(self, v, op="sum"):
+        """Reduction of a small fp64 vector over the ranks (objective + gradient: 1 + nvar doubles per evaluation)."""
         t = self.torch.as_tensor(np.asarray(v, dtype=np.float64), device=self.device).clone()
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        ops = {"sum": self.dist.ReduceOp.SUM, "min": self.dist.ReduceOp.MIN, "max": self.dist.ReduceOp.MAX}
+        self.dist.all_reduce(t, op=ops[op], group=self.group)
         return t.cpu().numpy()
+
+    def allreduce_checked(self, compute, n):
+        """Sum over the ranks of the ``n`` doubles ``compute()`` returns locally, with error agreement: an exception on ANY rank (a
+        capacity limit hit only by that rank's longest bucket, an out-of-memory, ...) is carried through the same collective as a
+        flag and raised on EVERY rank afterwards - a rank raising alone would leave its peers blocked in the all-reduce."""
+        err = None
+        try:
+            v = np.asarray(compute(), dtype=np.float64).reshape(n)
+        except Exception as e:  # noqa: BLE001 - re-raised below, after the collective
+            err, v = e, np.zeros(n)
+        out = self.allreduce_vector(np.concatenate([v, [0.0 if err is None else 1.0]]))
+        if out[-1] > 0:
+            if err is not None:
+                raise err
+            raise RuntimeError("the evaluation failed on %d other rank(s)" % int(round(out[-1])))
+        return out[:-1]
 
     def global_min_max_len(self, lengths):
         lo = min(lengths) if len(lengths) else 1 << 30
@@ -162,37 +179,66 @@ class Comm:
         if getattr(ts, "shard_chunk", None) != chunk:
             raise ValueError("fusion='threshold' needs shards aligned to the %d-track chunks (Comm.shard_trackset(..., chunk=%d))"
                              % (chunk, chunk))
-        if ts.n_tracks == 0:
-            return self.allreduce_scalar(0.0, "sum")
         if self.backend == "nccl":
-            buf = self._device_buffer(ts)
-            ts.ctx.loglik_th_async(model, threshold, max_nb_states, chunk, buf.data_ptr())  # stream-ordered, no host round trip
-            self.dist.all_reduce(buf, op=self.dist.ReduceOp.SUM, group=self.group)
-            return float(buf.item())
-        return self.allreduce_scalar(ts.loglik_th(model, threshold, max_nb_states, chunk), "sum")
+            return float(self._reduce_on_stream(ts, lambda ptr: ts.ctx.loglik_th_async(model, threshold, max_nb_states, chunk, ptr))[0])
+        return float(self.allreduce_checked(lambda: [ts.loglik_th(model, threshold, max_nb_states, chunk) if ts.n_tracks else 0.0], 1)[0])
 
-    def _device_buffer(self, ts):
-        """fp64 scalar on this rank's GPU + the context bound to torch's current stream (kernels and the collective are ordered
-        on one stream)."""
+    def _reduce_on_stream(self, ts, enqueue, n=1):
+        """Stream-ordered reduction of ``n`` doubles: ``enqueue(device_ptr)`` launches this rank's kernels, which leave the local sums in
+        the first ``n`` slots of a device buffer; slot ``n`` is the failure flag of ``allreduce_checked`` (set when the enqueue raised);
+        RCCL reduces all of it on the same stream and one small read comes back - no host round trip before the collective."""
+        buf = self._device_buffer(ts, n + 1)
+        err = None
+        try:
+            if ts.n_tracks:
+                enqueue(buf.data_ptr())
+            else:
+                buf[0:n].zero_()
+        except Exception as e:  # noqa: BLE001 - re-raised on every rank after the collective
+            err = e
+            buf[0:n].zero_()
+            buf[n:n + 1].fill_(1.0)
+        self.dist.all_reduce(buf, op=self.dist.ReduceOp.SUM, group=self.group)
+        h = buf.cpu().numpy()
+        if h[n] > 0:
+            buf[n:n + 1].zero_()
+            if err is not None:
+                raise err
+            raise RuntimeError("the evaluation failed on %d other rank(s)" % int(round(float(h[n]))))
+        return h[:n].copy()
+
+    def allreduce_loglik_grad(self, ts, model, tangents, n_dir):
+        """{sum LL, d sum LL / d theta} over the ranks: with RCCL the gradient kernels write their 1 + n_dir sums into the buffer the
+        collective reduces, on one stream (extrack_loglik_grad_async); with gloo (CPU tests) through the host."""
+        if self.backend == "nccl":
+            return self._reduce_on_stream(ts, lambda ptr: ts.ctx.loglik_grad_async(model, tangents, ptr), 1 + n_dir)
+
+        def local():
+            if not ts.n_tracks:
+                return np.zeros(1 + n_dir)
+            ll, g = ts.ctx.loglik_grad(model, tangents)
+            return np.concatenate([[ll], g])
+        return self.allreduce_checked(local, 1 + n_dir)
+
+    def _device_buffer(self, ts, n=2):
+        """fp64 device buffer of ``n`` doubles on this rank's GPU (the last one is the failure flag) + the context bound to torch's
+        current stream (kernels and the collective are ordered on one stream)."""
         torch = self.torch
         if self._buf is None:
-            self._buf = torch.zeros(1, dtype=torch.float64, device=self.device)
-        if ts.n_tracks and self._buf.device.index != ts.ctx.device:
+            self._buf = {}
+        buf = self._buf.get(n)
+        if buf is None:
+            buf = self._buf[n] = torch.zeros(n, dtype=torch.float64, device=self.device)
+        if ts.n_tracks and buf.device.index != ts.ctx.device:
             raise RuntimeError("the TrackSet lives on GPU %d but the communicator reduces on %s: pass device=%d (LOCAL_RANK) when "
-                               "building it" % (ts.ctx.device, self._buf.device, self._buf.device.index))
+                               "building it" % (ts.ctx.device, buf.device, buf.device.index))
         if ts.n_tracks:
             ts.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-        return self._buf
+        return buf
 
     # ---- the per-evaluation collective ----------------------------------------------------------------------
     def allreduce_loglik(self, ts, model):
         """Local sum of log-likelihoods on this rank's GPU -> all-reduce(sum) -> python float."""
         if self.backend == "nccl":
-            buf = self._device_buffer(ts)
-            if ts.n_tracks:
-                ts.ctx.loglik_async(model, buf.data_ptr())
-            else:
-                buf.zero_()
-            self.dist.all_reduce(buf, op=self.dist.ReduceOp.SUM, group=self.group)
-            return float(buf.item())
-        return self.allreduce_scalar(ts.loglik(model) if ts.n_tracks else 0.0, "sum")
+            return float(self._reduce_on_stream(ts, lambda ptr: ts.ctx.loglik_async(model, ptr))[0])
+        return float(self.allreduce_checked(lambda: [ts.loglik(model) if ts.n_tracks else 0.0], 1)[0])

@@ -75,6 +75,20 @@ def p_stay_table_grad(ds, nb_states, nb_substeps, cell_dims):
     return p, dp
 
 
+_P_STAY_GRAD_CACHE = {}
+
+
+def p_stay_table_grad_cached(ds, nb_states, nb_substeps, cell_dims):
+    """Cached front of ``p_stay_table_grad`` (an analytic-gradient fit asks for the same diffusion lengths it evaluates at)."""
+    key = (tuple(np.asarray(ds, float).tolist()), int(nb_states), int(nb_substeps), tuple(float(c) for c in cell_dims))
+    hit = _P_STAY_GRAD_CACHE.get(key)
+    if hit is None:
+        if len(_P_STAY_GRAD_CACHE) > 64:
+            _P_STAY_GRAD_CACHE.clear()
+        hit = _P_STAY_GRAD_CACHE[key] = p_stay_table_grad(ds, nb_states, nb_substeps, cell_dims)
+    return hit
+
+
 def sort_buckets(all_tracks, input_LocErr=None):
     """Numeric sort of the length keys, dropping empty buckets (extrack/tracking.py:1346-1367).
 
@@ -154,6 +168,8 @@ class TrackSet:
                 for a in range(0, len(t0), int(dt_chunk)):
                     med = np.median(np.sqrt(ds[None] ** 2 * t0[a:a + int(dt_chunk), None]), axis=0)
                     tabs.append(p_stay_table(med, S, nb_substeps, cell_dims))
+            if not tabs:  # a rank without tracks (distributed shard): one placeholder table, never indexed
+                tabs.append(p_stay_table(ds, S, nb_substeps, cell_dims))
             ps = np.array(tabs)
         else:
             ps = p_stay_table(ds, S, nb_substeps, cell_dims)

@@ -24,7 +24,7 @@ _CSAFE = dict(_SAFE_FUNCS)
 _CSAFE.update({k: getattr(cmath, k) for k in ("exp", "log", "log10", "sqrt", "sin", "cos", "tan", "asin", "acos", "atan", "sinh", "cosh",
                                                 "tanh")})
 for _k in ("fabs", "floor", "ceil", "abs", "min", "max"):
-    _CSAFE.pop(_k, None)  # not analytic: an expression using them falls back to finite differences
+    _CSAFE.pop(_k, None)  # not analytic: param_fitting then differentiates the objective by finite differences (analytic_support)
 
 
 class _V:
@@ -61,27 +61,118 @@ def values_along(params, name, h=_H):
     return vals
 
 
-def model_tangents(params, dt, nb_substeps, Matrix_type, cell_dims, names, has_sigma=False):
-    """Tangent dicts (the ``tangents`` argument of ``_lib.Context.loglik_grad``), one per free parameter in ``names``."""
+_NSAFE = {"exp": np.exp, "log": np.log, "log10": np.log10, "sqrt": np.sqrt, "sin": np.sin, "cos": np.cos, "tan": np.tan, "asin": np.arcsin,
+          "acos": np.arccos, "atan": np.arctan, "sinh": np.sinh, "cosh": np.cosh, "tanh": np.tanh, "pi": np.pi, "e": np.e, "pow": np.power}
+_CODE_CACHE = {}
+
+
+def _expr_code(p):
+    """Compiled constraint expression of a parameter (ours carry it; an lmfit Parameter only has the string)."""
+    code = getattr(p, "_code", None)
+    if code is None and getattr(p, "expr", None):
+        code = _CODE_CACHE.get(p.expr)
+        if code is None:
+            from .lmfit_compat import _compile_expr
+            code = _CODE_CACHE[p.expr] = _compile_expr(p.expr)
+    return code
+
+
+def _values_batched(params, names, h=_H):
+    """{param name: complex array [n_dir]}: direction i displaces the free parameter names[i] by i*h; every ``expr`` parameter is
+    re-evaluated on the whole batch at once (numpy complex arithmetic).  Raises TypeError / NameError / ValueError when an
+    expression is not complex-differentiable (abs, min, max, comparisons, ...)."""
+    n = len(names)
+    vals = {}
+    for k, p in params.items():
+        vals[k] = np.full(n, complex(p.value))
+    for i, nm in enumerate(names):
+        vals[nm][i] += 1j * h
+    pending = [(k, _expr_code(p)) for k, p in params.items() if getattr(p, "expr", None)]
+    for _ in range(len(pending) + 1):
+        if not pending:
+            break
+        env = dict(_NSAFE)
+        env.update(vals)
+        nxt = []
+        for k, code in pending:
+            try:
+                vals[k] = np.asarray(eval(code, {"__builtins__": {}}, env), complex) * np.ones(n)
+            except NameError as e:
+                if any(nm in str(e) for nm in ("abs", "min", "max", "fabs", "floor", "ceil")):
+                    raise TypeError("parameter expression is not analytic: %s" % e)
+                nxt.append((k, code))
+        if len(nxt) == len(pending):
+            raise NameError("unresolved names in parameter expressions")
+        pending = nxt
+    return vals
+
+
+def _extract_batched(vals, nb_substeps, Matrix_type):
+    """``tracking._extract_arrays`` on a batch: vals {name: complex [n]} -> le [k, n], Ds [S, n], Fs [S, n], TrMat [S, S, n], pBL [n],
+    (slope [n], offset [n]) or None.  Matrix types with a matrix exponential go direction by direction."""
+    names = np.sort(list(vals.keys()))
+    n = len(next(iter(vals.values())))
+    le = np.array([vals[k] for k in names if k.startswith("LocErr")]).reshape(-1, n)
+    so = (vals["slope_LocErr"], vals["offset_LocErr"]) if "slope_LocErr" in vals else None
+    Ds = np.array([vals[k] for k in names if k.startswith("D") and len(k) < 3])
+    Fs = np.array([vals[k] for k in names if k.startswith("F")])
+    S = len(Ds)
+    pBL = vals.get("pBL")
+    if Matrix_type in (0, 1):
+        T = np.zeros((S, S, n), complex)
+        for k in vals:
+            if k != "pBL" and k.startswith("p"):
+                T[int(k[1]), int(k[2])] = vals[k]
+        T = T / nb_substeps
+        if Matrix_type == 1:
+            T = 1 - np.exp(-T)
+        d = np.arange(S)
+        T[d, d] = 0
+        T[d, d] = 1 - T.sum(1)
+        return le, Ds, Fs, T, pBL, so
     from .tracking import _extract_arrays
-    base = {k: _V(p.value) for k, p in params.items()}
-    _, Ds0, _, _, _, _ = _extract_arrays(base, dt, nb_substeps, Matrix_type)
-    S = len(Ds0)
-    ds = np.sqrt(2 * np.real(Ds0) * dt)
-    _, dps = engine.p_stay_table_grad(ds, S, nb_substeps, cell_dims)  # [G], [G, S]
-    out = []
-    for n in names:
-        cv = values_along(params, n)
-        le, Ds, Fs, TrMat, pBL, so = _extract_arrays({k: _V(v) for k, v in cv.items()}, dt, nb_substeps, Matrix_type)
-        t = dict(ds2=2 * dt * np.imag(Ds) / _H, Fs=np.imag(Fs) / _H, TrMat=np.imag(TrMat) / _H, pBL=float(np.imag(pBL) / _H))
-        t["p_stay"] = dps @ t["ds2"]
-        if has_sigma:
-            if so is not None:
-                t["slope"], t["offset"] = float(np.imag(so[0]) / _H), float(np.imag(so[1]) / _H)
-        else:
-            t["locerr"] = np.imag(le) / _H
-        out.append(t)
-    return out
+    T = np.zeros((S, S, n), complex)
+    for i in range(n):
+        T[:, :, i] = _extract_arrays({k: _V(complex(v[i])) for k, v in vals.items()}, 1.0, nb_substeps, Matrix_type)[3]
+    return le, Ds, Fs, T, pBL, so
+
+
+def model_tangents(params, dt, nb_substeps, Matrix_type, cell_dims, names, has_sigma=False):
+    """Tangents of the model arrays along the free parameters ``names``, packed for ``_lib.Context.loglik_grad``: dict of arrays with
+    the direction as FIRST axis (ds2 [n, S], Fs [n, S], TrMat [n, S, S], p_stay [n, G], pBL [n], locerr [n, k] or slope / offset [n]).
+    One batched complex-step evaluation of the parameter plumbing (expr constraints -> extract_params) for all directions."""
+    vals = _values_batched(params, names)
+    le, Ds, Fs, TrMat, pBL, so = _extract_batched(vals, nb_substeps, Matrix_type)
+    S = len(Ds)
+    ds = np.sqrt(2 * np.real(Ds[:, 0]) * dt)
+    _, dps = engine.p_stay_table_grad_cached(ds, S, nb_substeps, cell_dims)  # [G], [G, S]
+    n = len(names)
+    t = dict(ds2=np.ascontiguousarray(2 * dt * np.imag(Ds).T / _H), Fs=np.ascontiguousarray(np.imag(Fs).T / _H),
+             TrMat=np.ascontiguousarray(np.moveaxis(np.imag(TrMat), 2, 0) / _H),
+             pBL=(np.imag(pBL) / _H if pBL is not None else np.zeros(n)))
+    t["p_stay"] = np.ascontiguousarray(t["ds2"] @ dps.T)
+    if has_sigma:
+        if so is not None:
+            t["slope"], t["offset"] = np.imag(so[0]) / _H, np.imag(so[1]) / _H
+    else:
+        t["locerr"] = np.ascontiguousarray(np.imag(le).T / _H)
+    return t
+
+
+def tangent_rows(t):
+    """The packed tangents of ``model_tangents`` as a list of per-direction dicts (tests, diagnostics)."""
+    n = len(t["pBL"])
+    return [{k: v[i] for k, v in t.items()} for i in range(n)]
+
+
+def analytic_support(params, names):
+    """None if every constraint expression is complex-differentiable along ``names``, else the reason (str): the caller then
+    differentiates the objective by finite differences instead."""
+    try:
+        _values_batched(params, names)
+    except (TypeError, NameError, ValueError, ZeroDivisionError, AttributeError) as e:
+        return "%s: %s" % (type(e).__name__, e)
+    return None
 
 
 def objective_and_gradient(params, ts, dt, cell_dims, nb_states, nb_substeps, frame_len, Matrix_type=1, comm=None, names=None):
@@ -93,11 +184,13 @@ def objective_and_gradient(params, ts, dt, cell_dims, nb_states, nb_substeps, fr
     if model is None:
         return np.inf, np.zeros(len(names))
     tang = model_tangents(params, dt, nb_substeps, Matrix_type, cell_dims, names, has_sigma=ts.has_sigma)
-    if ts.n_tracks:
-        ll, g = ts.ctx.loglik_grad(model, tang)
-    else:
-        ll, g = 0.0, np.zeros(len(names))
+
     if comm is not None:
-        v = comm.allreduce_vector(np.concatenate([[ll], g]))
-        ll, g = float(v[0]), v[1:]
+        v = comm.allreduce_loglik_grad(ts, model, tang, len(names))
+    elif ts.n_tracks:
+        ll, g = ts.ctx.loglik_grad(model, tang)
+        v = np.concatenate([[ll], g])
+    else:
+        v = np.zeros(1 + len(names))
+    ll, g = float(v[0]), v[1:]
     return -ll, -np.asarray(g)

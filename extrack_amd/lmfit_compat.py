@@ -286,6 +286,41 @@ def _own_minimize(fcn, params, method="leastsq", args=None, kws=None, iter_cb=No
                            aborted=False, errorbars=False)
 
 
+def _to_own_parameters(params):
+    """Our Parameters from any lmfit-style mapping {name: object with value / vary / min / max / expr}."""
+    own = _OwnParameters()
+    for k, p in params.items():
+        expr = getattr(p, "expr", None) or None
+        q = _OwnParameter(k, value=None if expr else p.value, vary=p.vary, min=p.min, max=p.max, expr=expr,
+                          brute_step=getattr(p, "brute_step", None))
+        q._val = float(p.value) if p.value is not None else None
+        OrderedDict.__setitem__(own, k, q)
+    own.update_constraints()
+    return own
+
+
+def minimize_with_gradient(fcn, params, method="bfgs", args=None, kws=None, nan_policy="propagate", fcn_grad=None, **fit_kws):
+    """``minimize`` with an analytic gradient: always the built-in scipy driver (``_own_minimize``: MINUIT bounds transform + its chain
+    rule).  With real lmfit installed the fit runs on a converted copy of the lmfit Parameters - routing a ``jac`` through lmfit's
+    scalar minimisers would need its internal variable transform, which is unpinned here - and the result's ``.params`` is a copy of
+    the caller's lmfit Parameters carrying the fitted values (``.value`` of every free and every ``expr`` parameter)."""
+    own = params if isinstance(params, _OwnParameters) else _to_own_parameters(params)
+    res = _own_minimize(fcn, own, method=method, args=args, kws=kws, nan_policy=nan_policy, fcn_grad=fcn_grad, **fit_kws)
+    if not isinstance(params, _OwnParameters):
+        out = copy.deepcopy(params)
+        for k, p in res.params.items():
+            if not getattr(out[k], "expr", None):
+                out[k].value = p.value
+        for k, p in res.params.items():  # expr parameters follow from the free ones; make sure the copy shows the same numbers
+            if getattr(out[k], "expr", None) and hasattr(out, "update_constraints"):
+                out.update_constraints()
+                break
+        res.own_params, res.params = res.params, out
+    return res
+
+
+_OwnParameters, _OwnParameter = Parameters, Parameter
+
 if HAVE_LMFIT:  # pragma: no cover
     Parameters = _lmfit.Parameters  # noqa: F811
     Parameter = _lmfit.Parameter    # noqa: F811

@@ -400,6 +400,45 @@ def cum_Proba_Cs_grad(params, names, all_tracks, dt, cell_dims, input_LocErr, nb
     return out, g
 
 
+def _pick_gradient(params, fargs, explicit, comm=None):
+    """Should ``param_fitting`` hand the optimiser the analytic gradient (one ``extrack_loglik_grad`` pass per iteration) rather than
+    let it difference the objective (nvar + 1 evaluations per iteration, what the reference does, extrack/tracking.py:1371)?
+    Yes when (a) every constraint expression is complex-differentiable and (b) - unless the caller asked for it explicitly - a timing
+    probe on this dataset says a gradient call costs less than the nvar + 1 objective calls it replaces: the gradient kernels beat finite
+    differences for two-state models (tangents in registers, xt_reg2.h) but not yet for >= 3 states, and on datasets of a few
+    thousand tracks the comparison is decided by host overheads.  With ``comm`` the decision is taken on the slowest rank's timings."""
+    import time
+    from . import gradient
+    names = gradient.free_names(params)
+    why = gradient.analytic_support(params, names)
+    if why is not None:
+        if explicit:
+            raise ValueError("gradient='analytic': a parameter expression is not differentiable (%s)" % why)
+        return False
+    if explicit:
+        return True
+    import contextlib, io
+    a = list(fargs)
+    a[7] = 0  # verbose
+    sink = io.StringIO()
+    with contextlib.redirect_stdout(sink):
+        try:
+            cum_Proba_Cs(params, *a)  # warm-up: tables, workspaces, clocks
+            cum_Proba_Cs_grad(params, names, *a)
+            t0 = time.perf_counter()
+            cum_Proba_Cs(params, *a)
+            t_ll = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            cum_Proba_Cs_grad(params, names, *a)
+            t_g = time.perf_counter() - t0
+        except Exception:  # e.g. a model the gradient kernels do not serve: the objective itself decides later
+            return False
+    if comm is not None:
+        v = comm.allreduce_vector(np.array([t_ll, t_g]), op="max")
+        t_ll, t_g = float(v[0]), float(v[1])
+    return t_g < (len(names) + 1) * t_ll
+
+
 # ------------------------------------------------------------------------------------------------------------
 # public API
 # ------------------------------------------------------------------------------------------------------------
@@ -413,8 +452,8 @@ def param_fitting(all_tracks, dt, params=None, nb_states=2, nb_substeps=1, frame
     communicator's device, else 0), ``comm`` (distributed shard communicator: every rank passes the WHOLE dataset and keeps its
     shard), ``fusion`` ("window" | "threshold" | None = process default, see the module docstring), ``gradient``
     ("analytic": the optimiser gets the exact gradient from the GPU, one evaluation per iteration; "fd": it differences the
-    objective like the reference's; None: analytic where it exists - fixed-window kernel, gradient-based method, the built-in
-    lmfit-compatible minimiser - else fd)."""
+    objective like the reference's; None: analytic where it exists (fixed-window kernel, gradient-based method, differentiable
+    constraint expressions) AND a timing probe on this dataset says it is the cheaper way to a gradient, else fd: ``_pick_gradient``)."""
     fusion = "threshold" if _check_fusion(fusion) else "window"
     device = _resolve_device(device, comm)
     if params is None:
@@ -439,17 +478,24 @@ def param_fitting(all_tracks, dt, params=None, nb_states=2, nb_substeps=1, frame
     else:
         ts = TrackSet(tracks, sigmas, device=device, dts=dts)
     from . import lmfit_compat
-    can_grad = fusion == "window" and not lmfit_compat.HAVE_LMFIT and str(method).lower() in lmfit_compat._GRADIENT_METHODS
+    can_grad = fusion == "window" and str(method).lower() in lmfit_compat._GRADIENT_METHODS
     if gradient not in (None, "analytic", "fd"):
         raise ValueError("gradient must be None, 'analytic' or 'fd'")
     if gradient == "analytic" and not can_grad:
-        raise ValueError("gradient='analytic' needs fusion='window', a gradient-based method and the built-in minimiser")
-    extra = dict(fcn_grad=cum_Proba_Cs_grad) if can_grad and gradient != "fd" else {}
+        raise ValueError("gradient='analytic' needs fusion='window' and a gradient-based method")
+    fargs = (ts, dt, cell_dims, sigmas, nb_states, nb_substeps, frame_len, verbose, workers, Matrix_type, threshold, max_nb_states, 2000,
+             comm, fusion)
     try:
-        fit = minimize(cum_Proba_Cs, params,
-                       args=(ts, dt, cell_dims, sigmas, nb_states, nb_substeps, frame_len, verbose, workers, Matrix_type, threshold,
-                             max_nb_states, 2000, comm, fusion),
-                       method=method, nan_policy="propagate", **extra)
+        use_grad = can_grad and gradient != "fd"
+        if use_grad:
+            use_grad = _pick_gradient(params, fargs, explicit=(gradient == "analytic"), comm=comm)
+        if use_grad:
+            # the built-in BFGS driver takes the analytic gradient (chain rule through the bounds transform applied there); with real
+            # lmfit installed its Parameters are converted for the fit and the fitted values written back into a copy of them
+            fit = lmfit_compat.minimize_with_gradient(cum_Proba_Cs, params, args=fargs, method=method, nan_policy="propagate",
+                                                      fcn_grad=cum_Proba_Cs_grad)
+        else:
+            fit = minimize(cum_Proba_Cs, params, args=fargs, method=method, nan_policy="propagate")
     finally:
         ts.close()
     if verbose == 0:

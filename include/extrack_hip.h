@@ -50,7 +50,7 @@
 extern "C" {
 #endif
 
-#define EXTRACK_ABI_VERSION 3
+#define EXTRACK_ABI_VERSION 4
 
 #define EXTRACK_OK 0
 #define EXTRACK_E_INVALID (-1)     /* bad argument / unsupported configuration */
@@ -143,10 +143,16 @@ typedef struct extrack_model_tangent {
 /* One evaluation of the fixed-window log-likelihood (as extrack_loglik) together with its derivative along n_dir model
  * directions, by forward-mode differentiation inside the recursion (window fusion included: it is the exact gradient of the
  * value extrack_loglik returns, not an approximation).  total_ll: sum of per-track log-likelihoods; grad[i] = d total_ll /
- * d theta_i (host, n_dir entries).  n_dir may be 0 (then it is extrack_loglik through the gradient kernel). */
+ * d theta_i (host, n_dir entries).  n_dir may be 0 (then it is extrack_loglik).  Two-state models with one substep run with the
+ * sequence state and its tangents in registers (csrc/xt_reg2.h), <= 8 directions per pass; other models with the tangents in LDS. */
 int extrack_loglik_grad(extrack_ctx* ctx, const extrack_model* model, int32_t n_dir, const extrack_model_tangent* tangents,
                         double* total_ll, double* grad);
-/* Device time (ms) of the gradient kernels of the last extrack_loglik_grad call. */
+/* The same evaluation enqueued on the context's stream (extrack_set_stream) without waiting for it: d_out (DEVICE, 1 + n_dir
+ * doubles) receives {sum LL, d sum LL / d theta_i} in stream order - the multi-GPU objective all-reduces that buffer on the same
+ * stream (RCCL), like extrack_loglik_async does for the scalar.  The tangent arrays are consumed before the call returns. */
+int extrack_loglik_grad_async(extrack_ctx* ctx, const extrack_model* model, int32_t n_dir, const extrack_model_tangent* tangents,
+                              double* d_out);
+/* Device time (ms) of the gradient kernels of the last extrack_loglik_grad / extrack_loglik_grad_async call (waits for them). */
 int extrack_last_grad_ms(extrack_ctx* ctx, float* ms);
 
 /* State-duration histogram of one bucket (extrack/histograms.py:26-286 P_segment_len, third return value, summed over the bucket's

@@ -84,6 +84,9 @@ class OracleContext:
             return sum(O.proba_cs(b, le_, ds_, Fs_, T_, pBL_, 0 if b.shape[1] == hi else 1, CELL, ns, F, lo).sum() for b in self.data)
         h = 1e-6
         g = []
+        if isinstance(tangents, dict):  # the packed form of gradient.model_tangents
+            from extrack_amd import gradient
+            tangents = gradient.tangent_rows(tangents)
         for t in tangents:
             def at(sg):
                 return total(np.sqrt(ds ** 2 + sg * h * np.asarray(t["ds2"])), Fs + sg * h * np.asarray(t["Fs"]), T + sg * h * np.asarray(t["TrMat"]),
@@ -199,6 +202,28 @@ def _worker(rank, world, port, q, scenario):
                                     fusion="threshold")
             ts.close()
             out.update(th=th, th_ref=OT.cum_proba_cs_th(vals, small, 0.02, CELL, None, 1, 6, 1, 0.2, 120, chunk=16))
+            # the same with per-track time steps: the empty rank builds a model without a single chunk table (advisor r2: it used to
+            # raise alone, before the collective, and leave rank 0 waiting)
+            sdt = [0.02 * np.random.default_rng(5).uniform(0.5, 1.5, b.shape[:2]) for b in l2]
+            ts = comm.shard_trackset(l2, chunk=16, dts=sdt)
+            with contextlib.redirect_stdout(io.StringIO()):
+                thd = T.cum_Proba_Cs(p, ts, None, CELL, None, 2, 1, 6, verbose=0, max_number_of_tracks_per_matrix=16, comm=comm,
+                                     fusion="threshold")
+            ts.close()
+            out.update(thd=thd, thd_ref=OT.cum_proba_cs_th(vals, small, {"9": sdt[0]}, CELL, None, 1, 6, 1, 0.2, 120, chunk=16))
+            # a failure inside ONE rank's evaluation is raised on every rank after the collective (nobody is left waiting)
+            ts = comm.shard_trackset(l2, chunk=16)
+            if rank == 0:
+                def boom(*a, **k):
+                    raise RuntimeError("injected failure on rank 0")
+                ts.loglik_th = boom
+            try:
+                with contextlib.redirect_stdout(io.StringIO()):
+                    T.cum_Proba_Cs(p, ts, 0.02, CELL, None, 2, 1, 6, verbose=0, max_number_of_tracks_per_matrix=16, comm=comm, fusion="threshold")
+                out["agreed"] = False
+            except RuntimeError as e:
+                out["agreed"] = ("injected" in str(e)) if rank == 0 else ("other rank" in str(e))
+            ts.close()
             # collective error agreement: an empty dataset raises on EVERY rank, nobody is left waiting in a collective
             try:
                 comm.shard_trackset([np.zeros((0, 5, 2))])
@@ -250,7 +275,8 @@ def test_rank_without_tracks_and_collective_failure():
     res = _run("empty_rank")
     for r in res:
         assert abs(r["th"] - r["th_ref"]) < 1e-12 * abs(r["th_ref"]), r
-        assert r["raised"] is True
+        assert abs(r["thd"] - r["thd_ref"]) < 1e-12 * abs(r["thd_ref"]), r
+        assert r["raised"] is True and r["agreed"] is True, r
 
 
 def test_shard_range_partitions_exactly():

@@ -117,7 +117,7 @@ def test_host_chain_rule_matches_finite_differences():
                               estimated_Fs=[0.3, 0.45], estimated_transition_rates=[0.05, 0.1, 0.15, 0.2, 0.07, 0.12])
         names = gradient.free_names(p)
         assert "F2" not in names and len(names) == 3 + 2 + 2 + 6 + 1
-        tang = gradient.model_tangents(p, 0.02, 2, Matrix_type, [1.0, 0.7], names)
+        tang = gradient.tangent_rows(gradient.model_tangents(p, 0.02, 2, Matrix_type, [1.0, 0.7], names))
 
         def arrays(q):
             le, Ds, Fs, Tm, pBL, so = T._extract_arrays(q, 0.02, 2, Matrix_type)
@@ -164,3 +164,52 @@ def test_minimiser_uses_the_analytic_gradient():
     assert r_an.nfev * 2.5 < r_fd.nfev and r_an.ngev > 0
     r_pw = _own_minimize(f, p, method="powell", fcn_grad=fg)  # derivative-free methods ignore it
     assert r_pw.ngev == 0
+
+
+def test_non_analytic_expression_is_detected():
+    """advisor r2: an ``expr`` using abs / min / max / a comparison cannot be complex-differentiated; ``analytic_support`` reports it and
+    ``param_fitting(gradient=None)`` then differences the objective (``gradient='analytic'`` raises)."""
+    from extrack_amd import gradient, tracking as T
+    p = T.generate_params(nb_states=2, LocErr_type=1, estimated_Ds=[1e-3, 0.25], estimated_LocErr=[0.02], estimated_Fs=[0.6], estimated_transition_rates=0.1)
+    names = gradient.free_names(p)
+    assert gradient.analytic_support(p, names) is None
+    p.add("D1", expr="max(D0, 0.1) + 0.1")
+    assert gradient.analytic_support(p, gradient.free_names(p)) is not None
+    p.add("D1", expr="D0 + 0.1 if D0 > 0.05 else 0.2")
+    assert gradient.analytic_support(p, gradient.free_names(p)) is not None
+    p.add("D1", expr="D0 + exp(-D0) * 0.2")
+    assert gradient.analytic_support(p, gradient.free_names(p)) is None
+    t = gradient.tangent_rows(gradient.model_tangents(p, 0.02, 1, 1, [1.0], gradient.free_names(p)))
+    d0 = p["D0"].value
+    assert abs(t[0]["ds2"][1] - 2 * 0.02 * (1 - 0.2 * np.exp(-d0))) < 1e-12  # d(2 D1 dt)/d D0 through the expression
+
+
+def test_gradient_fit_on_foreign_parameters_object():
+    """``minimize_with_gradient`` runs the built-in driver on a converted copy of any lmfit-style Parameters mapping (what happens when
+    real lmfit is installed) and returns the caller's type with the fitted values."""
+    import copy
+    from extrack_amd.lmfit_compat import minimize_with_gradient
+
+    class FPar:
+        def __init__(self, name, value=None, vary=True, min=-np.inf, max=np.inf, expr=None):
+            self.name, self.value, self.vary, self.min, self.max, self.expr = name, value, vary, min, max, expr
+
+    class FPars(dict):
+        def update_constraints(self):
+            self["d"].value = self["a"].value + self["c"].value
+
+    fp = FPars(a=FPar("a", -1.0, min=-3, max=3), b=FPar("b", 2.0, min=0), c=FPar("c", 0.5), d=FPar("d", 0.0, vary=False, expr="a + c"))
+
+    def f(q):
+        a, b = q["a"].value, q["b"].value
+        return (1 - a) ** 2 + 100 * (b - a * a) ** 2 + (q["d"].value - 1.5) ** 2
+
+    def fg(q, names):
+        a, b, c = q["a"].value, q["b"].value, q["c"].value
+        g = dict(a=-2 * (1 - a) - 400 * a * (b - a * a) + 2 * (a + c - 1.5), b=200 * (b - a * a), c=2 * (a + c - 1.5))
+        return f(q), np.array([g[n] for n in names])
+
+    r = minimize_with_gradient(f, fp, method="bfgs", fcn_grad=fg)
+    assert isinstance(r.params, FPars) and r.params is not fp and fp["a"].value == -1.0
+    assert abs(r.params["a"].value - 1) < 1e-5 and abs(r.params["b"].value - 1) < 1e-4 and abs(r.params["d"].value - 1.5) < 1e-5
+    assert r.ngev > 0 and abs(r.residual[0]) < 1e-8

@@ -109,15 +109,15 @@ def test_c1_fit_analytic_gradient_same_optimum_fewer_calls(capsys):
 
 
 def test_c3_fit_analytic_gradient_same_optimum_fewer_calls(capsys):
-    """Reduced-size configs[2] (3 states, 46 buckets of lengths 5-50, 6e4 tracks, 13 free parameters): analytic-gradient fit vs
-    finite-difference fit."""
+    """Reduced-size configs[2] (3 states, 46 buckets of lengths 5-50, 6e4 tracks, 13 free parameters, the reference's default
+    frame_len = 6): analytic-gradient fit vs finite-difference fit."""
     from extrack_amd import tracking as T
     from test_hip_configs import _c3_tracks
     tracks = _c3_tracks(6e4, seed0=500)
     p0 = T.generate_params(nb_states=3, LocErr_type=1, LocErr_bounds=[0.005, 0.1], D_max=3, estimated_Ds=[0.0001, 0.02, 0.4],
                            estimated_Fs=[0.3, 0.3], estimated_transition_rates=0.1)
-    fa = T.param_fitting(tracks, 0.02, params=p0, nb_states=3, frame_len=4, verbose=0, method="bfgs", cell_dims=[1], gradient="analytic")
-    ff = T.param_fitting(tracks, 0.02, params=p0, nb_states=3, frame_len=4, verbose=0, method="bfgs", cell_dims=[1], gradient="fd")
+    fa = T.param_fitting(tracks, 0.02, params=p0, nb_states=3, frame_len=6, verbose=0, method="bfgs", cell_dims=[1], gradient="analytic")
+    ff = T.param_fitting(tracks, 0.02, params=p0, nb_states=3, frame_len=6, verbose=0, method="bfgs", cell_dims=[1], gradient="fd")
     capsys.readouterr()
     print("C3 fit: analytic nfev %d (residual %.6f), fd nfev %d (residual %.6f)" % (fa.nfev, fa.residual[0], ff.nfev, ff.residual[0]))
     assert fa.residual[0] <= ff.residual[0] + 1e-6 * abs(ff.residual[0])
@@ -150,3 +150,31 @@ def test_gradient_full_size_properties():
         parts_v, parts_g = parts_v + v, parts_g + g
     assert abs(parts_v - v1) < 1e-12 * abs(v1) and np.abs(parts_g - g1).max() < 1e-10 * np.abs(g1).max()
     print("gradient kernel: %.2f ms for 1e6 tracks x %d directions" % (ms, len(names)))
+
+
+def test_default_gradient_choice_follows_the_timing_probe(capsys):
+    """``param_fitting(gradient=None)``: the optimiser gets the analytic gradient only where a gradient call is cheaper than the nvar + 1
+    objective calls it replaces on THIS dataset (tracking._pick_gradient).  Two-state models (tangents in registers) -> analytic; the
+    3-state model at frame_len 6 (tangents in LDS, slower than finite differences today) -> finite differences, same optimum."""
+    import time
+    from extrack_amd import synth, tracking as T
+    from test_hip_configs import _c3_tracks
+    Cs = synth.brownian_tracks(200000, 30, [0.0, 0.25], [[.9, .1], [.1, .9]], [.6, .4], seed=3)
+    p2 = T.generate_params(nb_states=2, LocErr_type=1, LocErr_bounds=[0.005, 0.1], D_max=3, estimated_Ds=[0.0001, 0.1], estimated_Fs=[0.5],
+                           estimated_transition_rates=0.05)
+    t0 = time.perf_counter()
+    f2 = T.param_fitting({"30": Cs}, 0.02, params=p2, nb_states=2, frame_len=6, verbose=0, method="bfgs", cell_dims=[1])
+    t_auto = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    f2fd = T.param_fitting({"30": Cs}, 0.02, params=p2, nb_states=2, frame_len=6, verbose=0, method="bfgs", cell_dims=[1], gradient="fd")
+    t_fd = time.perf_counter() - t0
+    tracks = _c3_tracks(3e4, seed0=900)
+    p3 = T.generate_params(nb_states=3, LocErr_type=1, LocErr_bounds=[0.005, 0.1], D_max=3, estimated_Ds=[0.0001, 0.02, 0.4],
+                           estimated_Fs=[0.3, 0.3], estimated_transition_rates=0.1)
+    f3 = T.param_fitting(tracks, 0.02, params=p3, nb_states=3, frame_len=6, verbose=0, method="bfgs", cell_dims=[1])
+    capsys.readouterr()
+    print("2 states: default fit %.2f s (ngev %d, nfev %d) vs fd fit %.2f s (nfev %d); 3 states F=6: ngev %d" % (
+        t_auto, f2.ngev, f2.nfev, t_fd, f2fd.nfev, f3.ngev))
+    assert f2.ngev > 0 and f2.residual[0] <= f2fd.residual[0] + 1e-6 * abs(f2fd.residual[0])
+    assert t_auto < t_fd  # the probe's promise: never the slower way
+    assert f3.ngev == 0

@@ -23,7 +23,7 @@ def _params(vals):
 def test_library_loaded_and_device():
     from extrack_amd import _lib
     ctx = _lib.Context(0)
-    assert ctx._lib.extrack_abi_version() == 3
+    assert ctx._lib.extrack_abi_version() == 4
     ctx.close()
 
 
