@@ -232,7 +232,7 @@ def other_configs(device):
     try:
         from oracle import oracle_c, oracle_np as O
         cores = _one_socket_cores()
-        LocErr, ds, Fs, T, pBL = O.extract_params(vals, DT, 3, 1)
+        LocErr, ds, Fs, T, pBL = O.extract_params(vals, DT, 4, 3)  # (params, dt, nb_states, nb_substeps)
         smp = synth.brownian_tracks(2 * cores, L5, [0.0, 0.02, 0.1, 0.5], Tm, [0.25] * 4, seed=3)
         t0 = time.perf_counter()
         oracle_c.run(smp, LocErr, ds, Fs, T, pBL, 0, O.p_stay_table(ds, 4, 3, CELL), 3, 4, L5, nthreads=cores)
@@ -285,7 +285,7 @@ def other_configs(device):
     return out
 
 
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -295,7 +295,10 @@ def main():
     ap.add_argument("--tracks", type=int, default=None, help="tracks per GPU (c2) / in total (c4); default = the BASELINE config")
     ap.add_argument("--no-extra", action="store_true", help="skip the configs[2] / configs[4] measurements after the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    a = ap.parse_args()
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
+                    help="process-group backend: nccl = RCCL over xGMI (the measurement); gloo = rehearsal of the multi-rank control flow on a box "
+                         "without GPUs (tests/test_bench_gloo.py substitutes the device context; nothing it prints is a measurement)")
+    a = ap.parse_args(argv)
 
     import torch
     from extrack_amd import synth, tracking
@@ -307,7 +310,9 @@ def main():
     if world != a.gpus:
         if world == 1 and a.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % a.gpus)
-    torch.cuda.set_device(local)
+    on_gpu = a.backend == "nccl"
+    if on_gpu:
+        torch.cuda.set_device(local)
     comm = None
     if world > 1 or os.environ.get("EXTRACK_BENCH_FORCE_COMM") == "1":
         import torch.distributed as dist
@@ -317,7 +322,10 @@ def main():
         os.environ.setdefault("WORLD_SIZE", str(world))
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")  # one node: the bootstrap never needs an external interface
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if on_gpu:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group("gloo")
         from extrack_amd.distributed import Comm
         comm = Comm()
 
@@ -346,7 +354,8 @@ def main():
     def barrier():
         if comm is not None:
             torch.distributed.barrier()
-        torch.cuda.synchronize()
+        if on_gpu:
+            torch.cuda.synchronize()
 
     for _ in range(a.warmup):
         val = step()
@@ -368,7 +377,7 @@ def main():
     launch_info = ts.ctx.last_launch_info()
     th = None
     grad_info = None
-    if world == 1 and a.tracks == N_TRACKS and a.config == "c2":
+    if on_gpu and world == 1 and a.tracks == N_TRACKS and a.config == "c2":
         from extrack_amd import gradient
         pg = tracking.generate_params(nb_states=2, LocErr_type=1, estimated_Ds=[1e-3, DS_COEF[1]], estimated_LocErr=[LOCERR], estimated_Fs=[FS[0]],
                                       estimated_transition_rates=0.1)
@@ -378,7 +387,7 @@ def main():
         grad_info = {"what": "BASELINE configs[1] data: -sum(LL) AND its exact gradient (7 free parameters) in one pass of the gradient kernel "
                              "(extrack_loglik_grad), the evaluation an analytic-gradient BFGS iteration costs",
                      "kernel_ms": ts.ctx.last_grad_ms(), "n_directions": len(gnames), "grad_inf_norm": float(np.abs(gg).max())}
-    if world == 1 and a.tracks == N_TRACKS and a.config == "c2":
+    if on_gpu and world == 1 and a.tracks == N_TRACKS and a.config == "c2":
         for _ in range(2):
             th_val = ts.loglik_th(model, 0.2, 120, 2000)
         torch.cuda.synchronize()
@@ -394,7 +403,7 @@ def main():
               "launch": ts.ctx.last_launch_info()}
     ts.close()
     extra = None
-    if world == 1 and a.config == "c2" and a.tracks == N_TRACKS and not a.no_extra:
+    if on_gpu and world == 1 and a.config == "c2" and a.tracks == N_TRACKS and not a.no_extra:
         extra = other_configs(local)
     if comm is not None:
         torch.distributed.barrier()
@@ -405,7 +414,7 @@ def main():
     evals_per_s = (total_tracks / N_TRACKS) * a.steps / dt_all
     k_ms = float(np.mean(kernel_ms))
     alg_bytes = a.tracks * LEN * DIMS * 8          # one read of the track, LL reduced in-kernel
-    achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+    achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0  # no device timer in the gloo rehearsal
     traffic = None   # HBM bytes per launch from the committed rocprofv3 PMC passes (tools/gpu_pmc.sh -> profiles/hbm_traffic.json)
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if os.path.exists(tpath) and a.tracks == N_TRACKS:
@@ -413,28 +422,41 @@ def main():
             traffic = json.load(open(tpath)).get("bytes_per_launch")
         except Exception:
             traffic = None
-    # secondary (honest) bound: fp64 vector issue.  Flop count per track-step from the kernel's ISA:
-    # 34 FMA + 50 other fp64 instructions per wave-step of 2 tracks -> 118 flop x 64 lanes / 2 tracks = 3776 flop.
-    flop_per_eval = a.tracks * (LEN - 1) * 3776.0
-    valu_issue_cycles = a.tracks / 2 * (LEN - 1) * (84 * 4 + 37 * 2)   # fp64 ops issue in 4 cycles/wave, 32-bit ops in >= 2
-    tflops = flop_per_eval / (k_ms * 1e-3) / 1e12
+    # secondary (honest) bound: fp64 vector issue, from the instruction mix of the steady-state step of the CURRENT build
+    # (tools/isa_mix.py -> profiles/isa_mix.json; regenerated whenever csrc/xt_reg2.h changes)
+    mix = None
+    mpath = os.path.join(ROOT, "profiles", "isa_mix.json")
+    if os.path.exists(mpath):
+        try:
+            mix = json.load(open(mpath))
+        except Exception:
+            mix = None
     out = {
         "metric": "log-likelihood evals/sec (1e6 tracks, 2-state, len=30)", "value": evals_per_s, "unit": "1e6-track LL evals/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-        "scaling": scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "scaling": scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic" if on_gpu else "synthetic (gloo REHEARSAL, not a measurement)",
         "config": {"workload": ("BASELINE configs[1]: %d tracks/GPU, 2 states, len=30, 2-D, nb_substeps=1, frame_len=6, "
                                 "single log-likelihood eval per step" % a.tracks) if a.config == "c2" else
                                ("BASELINE configs[3]: %d tracks in total, row-sharded over %d GPU(s) (%d on rank 0), 2 states, len=30, 2-D, "
                                 "nb_substeps=1, frame_len=6, single log-likelihood eval per step" % (total_tracks, world, a.tracks)),
                    "tracks_per_gpu": a.tracks, "total_tracks": total_tracks, "parallelism": "dp%d" % world, "launch": launch_info},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic, "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                     "traffic": traffic, "traffic_source": "static: rocprofv3 PMC passes of an earlier run of this workload, profiles/hbm_traffic.json "
+                                                           "(not re-measured inside this run)",
+                     "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes,
                      "note": "the recursion is FP64-VALU bound, not HBM bound (arithmetic intensity ~300 flop/B, DESIGN.md)",
-                     "fp64_valu": {"achieved": tflops, "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s", "frac": tflops / FP64_VALU_PEAK_TF,
-                                   "flop_per_launch": flop_per_eval,
-                                   "valu_issue_floor_ms": valu_issue_cycles / (256 * 4) / 2.4e9 * 1e3}},
+                     },
         "neg_loglik": -val,
     }
+    if mix is not None and k_ms > 0:
+        wave_steps = a.tracks / mix["tracks_per_wave"] * (LEN - 1)
+        flop_per_eval = wave_steps * mix["flop_per_wave_step"]
+        tflops = flop_per_eval / (k_ms * 1e-3) / 1e12
+        out["roofline"]["fp64_valu"] = {
+            "achieved": tflops, "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s", "frac": tflops / FP64_VALU_PEAK_TF, "flop_per_launch": flop_per_eval,
+            "valu_issue_floor_ms": wave_steps * mix["issue_cycles_per_wave_step"] / (256 * 4) / 2.4e9 * 1e3,
+            "instructions_per_wave_step": {"fp64": mix["fp64_valu_per_wave_step"], "valu32": mix["valu32_per_wave_step"], "lds": mix["lds_per_wave_step"]},
+            "source": "profiles/isa_mix.json (tools/isa_mix.py on the current sources): " + mix["kernel"]}
     if th is not None:
         out["threshold_fusion"] = th
     if grad_info is not None:
@@ -442,7 +464,7 @@ def main():
         out["loglik_gradient"] = grad_info
     if extra is not None:
         out["extra"] = extra
-    if not a.no_cpu_baseline and world == 1:
+    if not a.no_cpu_baseline and world == 1 and on_gpu:
         out["cpu_baseline"] = cpu_baseline()
         out["speedup_vs_cpu_baseline"] = evals_per_s / out["cpu_baseline"]["value"]
         try:

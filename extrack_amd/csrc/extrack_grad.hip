@@ -172,7 +172,9 @@ static int xt_grad_enqueue(extrack_ctx* ctx, const extrack_model* m, int32_t n_d
     // per-block partial sums of every pass of the evaluation, one after the other (a pass has at most 32 blocks per CU)
     size_t poff = 0;
     if ((rc = xt_grad_reserve(ctx, &ctx->d_gpartials, &ctx->gpartials_cap, ((size_t)ctx->n_cu * 32 * 4 + XT_MAX_BUCKETS) * ((size_t)n_dir + 16)))) return rc;
-    XT_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    if (!ctx->evg0) XT_HIP(ctx, hipEventCreate(&ctx->evg0));
+    if (!ctx->evg1) XT_HIP(ctx, hipEventCreate(&ctx->evg1));
+    XT_HIP(ctx, hipEventRecord(ctx->evg0, ctx->stream));
     for (auto& g : groups) {
         const XtBucket& b0 = *g[0];
         const int D = b0.D;
@@ -352,9 +354,8 @@ static int xt_grad_enqueue(extrack_ctx* ctx, const extrack_model* m, int32_t n_d
         }
         doff += g.size();
     }
-    XT_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    XT_HIP(ctx, hipEventRecord(ctx->evg1, ctx->stream));
     ctx->grad_timed = true;
-    ctx->timed = false;
     return EXTRACK_OK;
 }
 
@@ -386,8 +387,8 @@ extern "C" int extrack_last_grad_ms(extrack_ctx* ctx, float* ms)
 {
     if (!ctx || !ms) return EXTRACK_E_INVALID;
     if (ctx->grad_timed) {
-        XT_HIP(ctx, hipEventSynchronize(ctx->ev1));
-        XT_HIP(ctx, hipEventElapsedTime(&ctx->grad_ms, ctx->ev0, ctx->ev1));
+        XT_HIP(ctx, hipEventSynchronize(ctx->evg1));
+        XT_HIP(ctx, hipEventElapsedTime(&ctx->grad_ms, ctx->evg0, ctx->evg1));
         ctx->grad_timed = false;
     }
     *ms = ctx->grad_ms;

@@ -217,6 +217,8 @@ extern "C" void extrack_destroy(extrack_ctx* ctx)
     if (ctx->h_dblob) (void)hipHostFree(ctx->h_dblob);
     if (ctx->ev_dblob) (void)hipEventDestroy(ctx->ev_dblob);
     if (ctx->d_gout) (void)hipFree(ctx->d_gout);
+    if (ctx->evg0) (void)hipEventDestroy(ctx->evg0);
+    if (ctx->evg1) (void)hipEventDestroy(ctx->evg1);
     if (ctx->d_th_blobs) (void)hipFree(ctx->d_th_blobs);
     if (ctx->d_gpartials) (void)hipFree(ctx->d_gpartials);
     if (ctx->d_partials) (void)hipFree(ctx->d_partials);

@@ -216,7 +216,8 @@ struct extrack_ctx {
     double* d_gpartials = nullptr;  // gradient path: per-block partial sums [grid][NP + 1] + the reduced row
     size_t gpartials_cap = 0;       // doubles
     float grad_ms = 0.f;            // device time of the gradient kernels of the last extrack_loglik_grad call
-    bool grad_timed = false;        // ev0 / ev1 bracket a gradient evaluation whose time has not been read yet
+    hipEvent_t evg0 = nullptr, evg1 = nullptr;  // bracket the kernels of the last gradient evaluation
+    bool grad_timed = false;        // ... whose time has not been read yet
     double* d_gout = nullptr;       // gradient path: {sum LL, gradient} of the synchronous entry point
     size_t gout_cap = 0;
     double* d_partials = nullptr;
