@@ -1120,7 +1120,7 @@ static int xt_th_run_group(extrack_ctx* ctx, const extrack_model* m, const std::
         while (ncap < std::max(maxE, maxG)) ncap *= 2;
         if (ncap == capE) ncap *= 2;
         if (ncap > XT_TH_MAXCAP)
-            return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "more than 8192 live state sequences per step: raise threshold or lower max_nb_states");
+            return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "more than 8192 live state sequences per step (threshold fusion expands every sequence by n_states^nb_substeps before it merges): raise threshold, lower max_nb_states or nb_substeps - or use the fixed-window kernel (fusion='window' / extrack_loglik), which serves this model");
         ctx->th_capE = ncap;
     }
     // apply geometry: a workgroup serves tiles of TT tracks of one chunk and keeps that chunk's plan in LDS when it is small
@@ -1522,7 +1522,7 @@ extern "C" int extrack_predict_th(extrack_ctx* ctx, const extrack_model* m, int3
             while (ncap < std::max(maxE, maxG)) ncap *= 2;
             if (ncap == capE) ncap *= 2;
             if (ncap > XT_TH_MAXCAP) {
-                rc = xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "more than 8192 live state sequences per step: raise threshold or lower max_nb_states");
+                rc = xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "more than 8192 live state sequences per step (threshold fusion expands every sequence by n_states^nb_substeps before it merges): raise threshold, lower max_nb_states or nb_substeps - or use the fixed-window kernel (fusion='window' / extrack_loglik), which serves this model");
                 break;
             }
             ctx->th_capE = ncap;
@@ -1721,7 +1721,7 @@ static int xt_refine_pass(extrack_ctx* ctx, const extrack_model* m, const double
                 while (ncap < std::max(st[1], st[2])) ncap *= 2;
                 if (ncap == capE) ncap *= 2;
                 if (ncap > XT_TH_MAXCAP) {
-                    rc = xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "more than 8192 live state sequences per step: raise threshold or lower max_nb_states");
+                    rc = xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "more than 8192 live state sequences per step (threshold fusion expands every sequence by n_states^nb_substeps before it merges): raise threshold, lower max_nb_states or nb_substeps - or use the fixed-window kernel (fusion='window' / extrack_loglik), which serves this model");
                     break;
                 }
                 ctx->th_capE = ncap;

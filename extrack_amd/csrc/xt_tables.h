@@ -33,7 +33,7 @@ static inline std::string xt_build_config(int S, int NS, int F, XtConfig& c)
     if (F <= NS) return "frame_len must be at least nb_substeps + 1";
     if (F > 15) return "frame_len too large";
     double e = pow((double)S, F);
-    if (e > 8192.0) return "n_states^frame_len exceeds the LDS-resident limit (8192 sequences)";
+    if (e > 8192.0) return "n_states^frame_len exceeds the LDS-resident limit (8192 sequences): lower frame_len (the window), or use the threshold-fusion kernel (fusion='threshold'), whose live-sequence count adapts to the data";
     c.S = S;
     c.NS = NS;
     c.F = F;

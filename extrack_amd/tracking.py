@@ -471,10 +471,8 @@ def param_fitting(all_tracks, dt, params=None, nb_states=2, nb_substeps=1, frame
     if dts is not None and fusion != "threshold":
         raise NotImplementedError("per-track time steps (dt as a dict of arrays) exist in the threshold-fusion kernel only "
                                   "(extrack/tracking.py:494-499): use fusion='threshold' (or EXTRACK_FUSION=threshold)")
-    if comm is not None:
-        if dts is not None:
-            raise NotImplementedError("per-track time steps are not sharded over a communicator yet: one GPU")
-        ts = comm.shard_trackset(tracks, sigmas, device=device, chunk=2000 if fusion == "threshold" else None)
+    if comm is not None:  # per-track time steps are cut like the tracks (whole 2000-track chunks: a chunk's field-of-view table comes from ITS tracks)
+        ts = comm.shard_trackset(tracks, sigmas, device=device, chunk=2000 if fusion == "threshold" else None, dts=dts)
     else:
         ts = TrackSet(tracks, sigmas, device=device, dts=dts)
     from . import lmfit_compat
@@ -516,12 +514,13 @@ def predict_Bs(all_tracks, dt, params, cell_dims=[1], nb_states=4, frame_len=5, 
     device = _resolve_device(device, comm)
     if comm is not None:
         from .distributed import shard_range
-        loc_tracks = {k: np.asarray(v)[slice(*shard_range(len(v), comm.rank, comm.world))] for k, v in all_tracks.items()}
-        loc_sig = None if input_LocErr is None else {k: np.asarray(v)[slice(*shard_range(len(v), comm.rank, comm.world))]
-                                                     for k, v in input_LocErr.items()}
-        if _check_fusion(fusion) and nb_max != 1:
-            raise NotImplementedError("fusion='threshold' with nb_max > 1 depends on the chunking of the whole bucket: one GPU only")
-        loc_dt = dt if not isinstance(dt, dict) else {k: np.asarray(v)[slice(*shard_range(len(v), comm.rank, comm.world))] for k, v in dt.items()}
+        # threshold fusion takes its merge decisions per chunk of nb_max consecutive tracks of a bucket (extrack/tracking.py:856-875): the
+        # shards are whole chunks, so every rank annotates exactly the chunks a single GPU would
+        ch = int(nb_max) if (_check_fusion(fusion) and nb_max and nb_max > 1) else None
+        cut = lambda v: np.asarray(v)[slice(*shard_range(len(v), comm.rank, comm.world, ch))]
+        loc_tracks = {k: cut(v) for k, v in all_tracks.items()}
+        loc_sig = None if input_LocErr is None else {k: cut(v) for k, v in input_LocErr.items()}
+        loc_dt = dt if not isinstance(dt, dict) else {k: cut(v) for k, v in dt.items()}
         local = predict_Bs(loc_tracks, loc_dt, params, cell_dims, nb_states, frame_len, max_nb_states, threshold, workers, loc_sig, verbose,
                            nb_max, device, None, fusion)
         return comm.gather_rows(local)

@@ -100,6 +100,17 @@ class OracleContext:
         b = self.data[bucket_id]
         return OH.p_segment_len(b, le, ds, Fs, T, lo, pBL, 0 if b.shape[1] == hi else 1, CELL, 1, max_nb_states)
 
+    def predict_th(self, model, bucket_id, threshold=0.1, max_nb_states=200, nb_max=1):
+        from oracle import oracle_th as OT
+        le, ds, Fs, T, pBL, ns, F, lo, hi = self._model(model)
+        b = self.data[bucket_id]
+        parts = []
+        for a0 in range(0, len(b), nb_max):
+            dsc = ds if bucket_id not in self.dts else ds[None, None] * np.sqrt(self.dts[bucket_id][a0:a0 + nb_max])[:, :, None]
+            parts.append(OT.p_cs_inter_bound_stats_th(b[a0:a0 + nb_max], le, dsc, Fs, T, pBL, 0 if b.shape[1] == hi else 1, CELL, 1, F, 1, lo,
+                                                      threshold, max_nb_states)[1])
+        return np.concatenate(parts)
+
     def predict(self, model, bucket_id):
         from oracle import oracle_np as O
         le, ds, Fs, T, pBL, ns, F, lo, hi = self._model(model)
@@ -191,6 +202,29 @@ def _worker(rank, world, port, q, scenario):
                 out["pred_keys"] = sorted(pr.keys(), key=int)
             else:
                 assert pr is None
+        elif scenario == "api":
+            # the public API with a communicator where round 2 still refused: per-track time steps in param_fitting (fusion =
+            # 'threshold') and threshold-fusion posteriors in chunks of nb_max > 1 tracks (shards = whole chunks)
+            rng = np.random.default_rng(11)
+            dtd = {k: 0.02 * rng.uniform(0.5, 1.5, v.shape[:2]) for k, v in tracks.items()}
+            with contextlib.redirect_stdout(io.StringIO()):
+                pr = T.predict_Bs(tracks, 0.02, p, cell_dims=CELL, nb_states=2, frame_len=4, threshold=0.2, max_nb_states=60, nb_max=7, comm=comm,
+                                  fusion="threshold")
+            if rank == 0:
+                ref = OT.predict_bs_th(vals, tracks, 0.02, CELL, 4, 60, 0.2, None, 7)
+                out["pred_th_err"] = max(np.abs(pr[k] - ref[k]).max() for k in tracks)
+            else:
+                assert pr is None
+            pf = Parameters()
+            for k, v in vals.items():
+                pf.add(k, value=v, vary=(k in ("D1", "p01")), min=1e-4 if k != "F1" else -np.inf, max=1.0 if k != "F1" else np.inf)
+            pf["F1"].expr = None
+            with contextlib.redirect_stdout(io.StringIO()):
+                fit = T.param_fitting(tracks, dtd, params=pf, nb_states=2, frame_len=4, verbose=0, method="powell", cell_dims=CELL, comm=comm,
+                                      fusion="threshold", threshold=0.2, max_nb_states=60)
+            out["fit_res"] = float(fit.residual[0])
+            out["fit_ref"] = OT.cum_proba_cs_th({k: fit.params[k].value for k in fit.params}, tracks, dtd, CELL, None, 1, 4, 1, 0.2, 60, chunk=2000)
+            out["fit_D1"] = fit.params["D1"].value
         elif scenario == "empty_rank":
             # fewer chunks than ranks: rank 1 holds nothing, contributes 0.0 and must not dead-lock the others
             small = {"9": tracks["9"][:10]}
@@ -269,6 +303,15 @@ def test_two_rank_product_path_matches_unsharded():
     assert res[0]["pred_err"] < 1e-12 and res[0]["pred_keys"] == ["5", "6", "7", "8", "9", "10", "11", "12"]
     # chunk-aligned shards are balanced over ALL buckets (one-chunk buckets are dealt round-robin, not piled on rank 0)
     assert abs(res[0]["th_n"] - res[1]["th_n"]) <= 32 and min(res[0]["th_n"], res[1]["th_n"]) > 40
+
+
+def test_public_api_with_communicator_dt_dict_and_chunked_threshold_posteriors():
+    res = _run("api")
+    r0 = [r for r in res if "pred_th_err" in r][0]
+    assert r0["pred_th_err"] < 1e-12
+    for r in res:
+        assert abs(r["fit_res"] - r["fit_ref"]) < 1e-10 * abs(r["fit_ref"]), r
+    assert res[0]["fit_res"] == res[1]["fit_res"] and res[0]["fit_D1"] == res[1]["fit_D1"]
 
 
 def test_rank_without_tracks_and_collective_failure():
