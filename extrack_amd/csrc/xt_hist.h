@@ -22,6 +22,7 @@
 #include "xt_math.h"
 
 #define XT_HIST_MAXW 4  // history words (64 bits each): len * bits_per_state <= 256
+#define XT_HIST_EPT 8   // register path of the ranking sort: at most this many candidates per thread (2048 candidates at 256 threads)
 
 struct XtHistArgs {
     const double* tracks;  // [N][L][D]
@@ -44,14 +45,119 @@ struct XtHistArgs {
 XT_HD int xt_hist_blob_doubles(int S) { return 32 + 2 * S * S; }
 XT_HD int xt_hist_parent_doubles(int PC, int D, int K, int HW) { return PC * (2 + D + K + HW); }
 XT_HD int xt_hist_tmp_doubles(int PC, int D, int K) { return PC * (1 + D + K); }
-// LDS doubles: blob + staged track + candidate arrays (key, LPc, LLc: NC doubles each; idx: NC ints) + per-parent scratch + histogram +
-// reduction scratch (+ the two parent buffers when they fit)
+// LDS doubles: blob + staged track + candidate arrays (key: NC doubles; idx: NC ints - a candidate's LP / LL are recomputed from its parent
+// when it is gathered, which keeps the footprint of the default max_nb_states = 500 below 80 KiB: two workgroups per CU) + per-parent
+// scratch + histogram + reduction scratch (+ the two parent buffers when they fit)
 XT_HD size_t xt_hist_lds_doubles(int S, int L, int D, int K, int KS, int PC, int NC, int HW, int nthreads, bool par_lds)
 {
-    size_t d = (size_t)((xt_hist_blob_doubles(S) + 1) & ~1) + (size_t)L * (D + KS) + 3 * (size_t)NC + (size_t)NC / 2 + xt_hist_tmp_doubles(PC, D, K) +
+    size_t d = (size_t)((xt_hist_blob_doubles(S) + 1) & ~1) + (size_t)L * (D + KS) + (size_t)NC + (size_t)NC / 2 + xt_hist_tmp_doubles(PC, D, K) +
                (size_t)(L - 1) * S + nthreads + 8;
     if (par_lds) d += 2 * (size_t)xt_hist_parent_doubles(PC, D, K, HW);
     return d;
+}
+
+// Ranking sort of the candidates, descending by key, equal keys by candidate index ascending (a total order: the result does not depend on
+// the sorting network): bitonic network over NS2 = EPT * nthreads (key, index) pairs with the elements in REGISTERS, thread t owning the
+// positions t * EPT .. t * EPT + EPT - 1.  Stages with a partner distance below EPT compare inside a thread, those below 64 * EPT trade the
+// elements between the lanes of a wavefront (DPP / permlane moves: no LDS round trip, no barrier), only the few stages with a larger distance go
+// through the LDS arrays.  EPT is a compile-time constant and every comparison is branch-free: the first version (run-time EPT, `||`
+// comparisons) compiled to one exec-mask branch per element and ran no faster than the all-LDS form (650 cycles per stage, r02).
+template <int EPT, class Ctx>
+XT_HD void xt_hist_sort_regs(Ctx& cx, double* key, int* idx, int NS2)
+{
+    const int tid = cx.tid(), nt = cx.nthreads();
+    const int NP2 = NS2 >> 1;
+    constexpr int LOG_EPT = EPT == 1 ? 0 : (EPT == 2 ? 1 : (EPT == 4 ? 2 : 3));
+    double kk[EPT];
+    int ii[EPT];
+    XT_UNROLL
+    for (int b = 0; b < EPT; ++b) {
+        kk[b] = key[tid * EPT + b];
+        ii[b] = idx[tid * EPT + b];
+    }
+    for (int k2 = 2; k2 <= NS2; k2 <<= 1) {
+        int j2 = k2 >> 1;
+        if (j2 >= 64 * EPT) {  // partner in another wavefront: through LDS
+            XT_UNROLL
+            for (int b = 0; b < EPT; ++b) {
+                key[tid * EPT + b] = kk[b];
+                idx[tid * EPT + b] = ii[b];
+            }
+            cx.sync();
+            for (; j2 >= 64 * EPT; j2 >>= 1) {
+                for (int pp = tid; pp < NP2; pp += nt) {
+                    const int t = ((pp & ~(j2 - 1)) << 1) | (pp & (j2 - 1)), u = t + j2;
+                    const bool desc = (t & k2) == 0;
+                    const double ka = key[t], kb = key[u];
+                    const int ia = idx[t], ib = idx[u];
+                    const bool a_first = (ka > kb) | ((ka == kb) & (ia < ib));
+                    if (desc != a_first) {
+                        key[t] = kb;
+                        key[u] = ka;
+                        idx[t] = ib;
+                        idx[u] = ia;
+                    }
+                }
+                cx.sync();
+            }
+            XT_UNROLL
+            for (int b = 0; b < EPT; ++b) {
+                kk[b] = key[tid * EPT + b];
+                ii[b] = idx[tid * EPT + b];
+            }
+        }
+        // partner in another lane of the wavefront (lane ^ 2^MB): DPP / permlane moves with compile-time lane masks (Ctx::xor_*)
+#define XT_HIST_LANE_STAGE(MB)                                                                        \
+    if ((EPT << (MB)) <= (k2 >> 1)) {                                                                 \
+        constexpr int j2s = EPT << (MB);                                                              \
+        double ok[EPT];                                                                               \
+        int oi[EPT];                                                                                  \
+        XT_UNROLL                                                                                     \
+        for (int b = 0; b < EPT; ++b) {                                                               \
+            ok[b] = cx.template xor_f64<(MB)>(kk[b]);                                                 \
+            oi[b] = cx.template xor_i32<(MB)>(ii[b]);                                                 \
+        }                                                                                             \
+        XT_UNROLL                                                                                     \
+        for (int b = 0; b < EPT; ++b) {                                                               \
+            const int pidx = tid * EPT + b;                                                           \
+            const bool self_first = (kk[b] > ok[b]) | ((kk[b] == ok[b]) & (ii[b] < oi[b]));           \
+            const bool want_first = ((pidx & j2s) == 0) == ((pidx & k2) == 0);                        \
+            const bool take = self_first != want_first;                                               \
+            kk[b] = take ? ok[b] : kk[b];                                                             \
+            ii[b] = take ? oi[b] : ii[b];                                                             \
+        }                                                                                             \
+    }
+        XT_HIST_LANE_STAGE(5)
+        XT_HIST_LANE_STAGE(4)
+        XT_HIST_LANE_STAGE(3)
+        XT_HIST_LANE_STAGE(2)
+        XT_HIST_LANE_STAGE(1)
+        XT_HIST_LANE_STAGE(0)
+#undef XT_HIST_LANE_STAGE
+        XT_UNROLL
+        for (int jj = EPT / 2; jj > 0; jj >>= 1) {  // both elements in this thread (compile-time register indices)
+            if (jj > (k2 >> 1)) continue;
+            XT_UNROLL
+            for (int b = 0; b < EPT; ++b)
+                if ((b & jj) == 0) {
+                    const int u = b | jj;
+                    const bool desc = ((tid * EPT + b) & k2) == 0;
+                    const bool a_first = (kk[b] > kk[u]) | ((kk[b] == kk[u]) & (ii[b] < ii[u]));
+                    const bool swap = desc != a_first;
+                    const double tk = swap ? kk[u] : kk[b];
+                    kk[u] = swap ? kk[b] : kk[u];
+                    kk[b] = tk;
+                    const int ti = swap ? ii[u] : ii[b];
+                    ii[u] = swap ? ii[b] : ii[u];
+                    ii[b] = ti;
+                }
+        }
+    }
+    XT_UNROLL
+    for (int b = 0; b < EPT; ++b) {
+        key[tid * EPT + b] = kk[b];
+        idx[tid * EPT + b] = ii[b];
+    }
 }
 
 template <int D, int K, class Ctx>
@@ -75,10 +181,6 @@ XT_HD void xt_hist_body(const XtHistArgs& a, Ctx& cx)
     double* ssig = w;
     w += (size_t)L * KS;
     double* key = w;
-    w += NC;
-    double* LPc = w;
-    w += NC;
-    double* LLc = w;
     w += NC;
     int* idx = (int*)w;
     w += NC / 2;
@@ -224,19 +326,16 @@ XT_HD void xt_hist_body(const XtHistArgs& a, Ctx& cx)
             // B: per candidate j = i * S + r
             const int nc = n * S;
             const bool prune = nc > a.K;
-            for (int j = tid; j < nc; j += nt) {
-                const int i = j / S, r = j - i * S;
-                const int prev = (int)(P_H(cur)[i] & smask);
-                LPc[j] = P_LP(cur)[i] + logT[prev * S + r] + tLC[i];
-                LLc[j] = P_LL(cur)[i] + (c >= a.min_l ? Lpst[r] : 0.0);
-                if (prune) {
+            if (prune)
+                for (int j = tid; j < nc; j += nt) {
+                    const int i = j / S, r = j - i * S;
+                    const int prev = (int)(P_H(cur)[i] & smask);
                     double m[D], v[K];
                     for (int d = 0; d < D; ++d) m[d] = tM[(size_t)d * PC + i];
                     for (int k = 0; k < K; ++k) v[k] = d2t[prev * S + r] + tS[(size_t)k * PC + i] + ln[k];
-                    key[j] = LPc[j] + gauss(cn, m, v);
+                    key[j] = P_LP(cur)[i] + logT[prev * S + r] + tLC[i] + gauss(cn, m, v);
                     idx[j] = j;
                 }
-            }
             if (prune)
                 for (int j = nc + tid; j < NC; j += nt) {
                     key[j] = -INFINITY;
@@ -268,18 +367,26 @@ XT_HD void xt_hist_body(const XtHistArgs& a, Ctx& cx)
                         idx[u] = ia;
                     }
                 };
-                for (int k2 = 2; k2 <= NS2; k2 <<= 1) {
-                    int j2 = k2 >> 1;
-                    for (; j2 > 64; j2 >>= 1) {
-                        for (int pp = tid; pp < NP2; pp += nt) cmpx(pp, j2, k2);
-                        cx.sync();
-                    }
-                    for (int p0 = 0; p0 < NP2; p0 += nt)
-                        for (int jj = j2; jj > 0; jj >>= 1) {
-                            if (p0 + tid < NP2) cmpx(p0 + tid, jj, k2);
-                            cx.wave_sync();
+                const int ept = NS2 / nt;  // elements per thread of the register path (thread t owns positions t * ept .. t * ept + ept - 1)
+                if (ept >= 1 && ept <= XT_HIST_EPT && (nt & 63) == 0) {
+                    if (ept == 1) xt_hist_sort_regs<1>(cx, key, idx, NS2);
+                    else if (ept == 2) xt_hist_sort_regs<2>(cx, key, idx, NS2);
+                    else if (ept == 4) xt_hist_sort_regs<4>(cx, key, idx, NS2);
+                    else xt_hist_sort_regs<8>(cx, key, idx, NS2);
+                } else {
+                    for (int k2 = 2; k2 <= NS2; k2 <<= 1) {
+                        int j2 = k2 >> 1;
+                        for (; j2 > 64; j2 >>= 1) {
+                            for (int pp = tid; pp < NP2; pp += nt) cmpx(pp, j2, k2);
+                            cx.sync();
                         }
-                    if (k2 >= 128) cx.sync();
+                        for (int p0 = 0; p0 < NP2; p0 += nt)
+                            for (int jj = j2; jj > 0; jj >>= 1) {
+                                if (p0 + tid < NP2) cmpx(p0 + tid, jj, k2);
+                                cx.wave_sync();
+                            }
+                        if (k2 >= 128) cx.sync();
+                    }
                 }
                 cx.sync();
                 nnew = a.K;
@@ -290,8 +397,9 @@ XT_HD void xt_hist_body(const XtHistArgs& a, Ctx& cx)
                 const int jl = prune ? idx[nc - a.K + t] : t;  // reference quirk: LL of the LAST K entries of the ranking
                 const int i = j / S, r = j - i * S;
                 const int prev = (int)(P_H(cur)[i] & smask);
-                P_LP(nxt)[t] = LPc[j];
-                P_LL(nxt)[t] = LLc[jl];
+                const int il = jl / S, rl = jl - il * S;
+                P_LP(nxt)[t] = P_LP(cur)[i] + logT[prev * S + r] + tLC[i];
+                P_LL(nxt)[t] = P_LL(cur)[il] + (c >= a.min_l ? Lpst[rl] : 0.0);
                 for (int d = 0; d < D; ++d) P_M(nxt)[(size_t)d * PC + t] = tM[(size_t)d * PC + i];
                 for (int k = 0; k < K; ++k) P_S(nxt)[(size_t)k * PC + t] = d2t[prev * S + r] + tS[(size_t)k * PC + i];
                 uint64_t carry = (uint64_t)r;

@@ -19,6 +19,12 @@
 #define XT_HD inline
 #endif
 
+#if defined(__clang__)
+#define XT_UNROLL _Pragma("unroll")  // loops over register arrays: an index that is not a compile-time constant puts the array into scratch
+#else
+#define XT_UNROLL
+#endif
+
 #define XT_EMIN (-(1 << 30))          // exponent of an exactly-zero weight
 #define XT_LN2 0.693147180559945309417232121458
 #define XT_LOG2PI 1.83787706640934548356065947281

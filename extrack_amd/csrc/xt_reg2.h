@@ -28,11 +28,6 @@
 #include "xt_grad.h"
 
 #define XT_INL __attribute__((always_inline))  // lambdas of the body: a closure that is not inlined lives in scratch memory
-#if defined(__clang__)
-#define XT_UNROLL _Pragma("unroll")
-#else
-#define XT_UNROLL
-#endif
 
 XT_HD void xt_sched_fence()
 {
