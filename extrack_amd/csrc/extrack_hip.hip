@@ -217,6 +217,8 @@ extern "C" void extrack_destroy(extrack_ctx* ctx)
     if (ctx->h_dblob) (void)hipHostFree(ctx->h_dblob);
     if (ctx->ev_dblob) (void)hipEventDestroy(ctx->ev_dblob);
     if (ctx->d_gout) (void)hipFree(ctx->d_gout);
+    for (int i = 0; i < extrack_ctx::RF_SLOTS; ++i)
+        if (ctx->rf_buf[i]) (void)hipFree(ctx->rf_buf[i]);
     if (ctx->evg0) (void)hipEventDestroy(ctx->evg0);
     if (ctx->evg1) (void)hipEventDestroy(ctx->evg1);
     if (ctx->d_th_blobs) (void)hipFree(ctx->d_th_blobs);
@@ -1554,7 +1556,7 @@ extern "C" int extrack_predict_th(extrack_ctx* ctx, const extrack_model* m, int3
 // (xt_th.h, refine mode) + the combination of the "future" and "past" predictions of every position
 // ------------------------------------------------------------------------------------------------
 struct XtRefineArgs {
-    const double* tracks;  // [N][L][D] original time order
+    const double* tracks;  // [N][L][D] original time order (rows of this launch)
     const double* fut;     // records of the pass over the time-reversed track: entry e = state after positions L-1 .. L-1-e
     const double* past;    // records of the pass over the track as it is:      entry e = state after positions 0 .. e
     const uint8_t* fut_new;
@@ -1563,81 +1565,84 @@ struct XtRefineArgs {
     const int32_t* past_cnt;
     double* mu_out;        // [N][L][D]
     double* sig_out;       // [N][L]
-    int64_t N;
+    int64_t N;             // rows of this launch (the records are [L - 1][N][cap][2 + D])
     int32_t L, S, cap_f, cap_p;  // sequences recorded per (entry, track) by the two passes
     double l2;             // squared localisation error
     double logF[XT_MAX_STATES];
 };
 
 // One thread per (track, position): softmax-weighted mean of the pair means / root mean of the pair variances
-// (refined_localization.py:222-298 get_pos_PDF + :329-337).  Two sweeps over the pairs: maximum of the log-weights, then the sums.
+// (refined_localization.py:222-298 get_pos_PDF + :329-337).  ONE sweep over the pairs with a running maximum of the log-weights (the sums
+// are rescaled when it grows): every record is read once.  Adjacent threads serve adjacent tracks of the same position, so a wavefront
+// walks 64 neighbouring record rows.
 template <int D>
 __global__ void __launch_bounds__(256) xt_refine_combine(XtRefineArgs a)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= a.N * a.L) return;
-    const int64_t x = i / a.L;
-    const int k = (int)(i - x * a.L);
+    const int k = (int)(i / a.N);
+    const int64_t x = i - (int64_t)k * a.N;
     const int L = a.L, R = 2 + D;
     double c[D];
     for (int d = 0; d < D; ++d) c[d] = a.tracks[(x * L + k) * D + d];
     double wmax = -INFINITY, sw = 0.0, smu[D], ssg = 0.0;
     for (int d = 0; d < D; ++d) smu[d] = 0.0;
-    for (int sweep = 0; sweep < 2; ++sweep) {
-        if (k == 0 || k == L - 1) {
-            // end positions: one pass only; the reference's last record already carries the density of this position (and the
-            // initial fractions for position 0) through its in-place update (refined_localization.py:188-193), and get_pos_PDF adds the
-            // overlap term once more
-            const int cap = k == 0 ? a.cap_f : a.cap_p;
-            const double* rec = (k == 0 ? a.fut : a.past) + (((int64_t)(L - 2) * a.N + x) * cap) * R;
-            const uint8_t* nw = (k == 0 ? a.fut_new : a.past_new) + (int64_t)(L - 2) * cap;
-            const int n = (k == 0 ? a.fut_cnt : a.past_cnt)[L - 2];
-            for (int q = 0; q < n; ++q) {
-                const double lp = rec[q * R], sd = rec[q * R + 1 + D], v = sd * sd + a.l2;
-                double dsq = 0.0;
-                for (int d = 0; d < D; ++d) dsq += (c[d] - rec[q * R + 1 + d]) * (c[d] - rec[q * R + 1 + d]);
-                const double lk = -0.5 * D * log(2.0 * M_PI * v) - dsq / (2.0 * v);
-                const double w = lp + 2.0 * lk + (k == 0 ? a.logF[nw[q]] : 0.0);
-                if (sweep == 0) {
-                    wmax = w > wmax ? w : wmax;
-                } else {
-                    const double p = exp(w - wmax);
-                    sw += p;
-                    for (int d = 0; d < D; ++d) smu[d] += p * (rec[q * R + 1 + d] * a.l2 + c[d] * sd * sd) / v;
-                    ssg += p * (a.l2 * sd * sd / v);
-                }
+    auto add = [&](double w, const double* mu, double var) {
+        if (w > wmax) {  // rescale what has been summed to the new maximum (exp(-inf) = 0 the first time, when the sums are 0 anyway)
+            const double sc = exp(wmax - w);
+            sw *= sc;
+            ssg *= sc;
+            for (int d = 0; d < D; ++d) smu[d] *= sc;
+            wmax = w;
+        }
+        const double p = exp(w - wmax);
+        sw += p;
+        for (int d = 0; d < D; ++d) smu[d] += p * mu[d];
+        ssg += p * var;
+    };
+    if (k == 0 || k == L - 1) {
+        // end positions: one pass only; the reference's last record already carries the density of this position (and the
+        // initial fractions for position 0) through its in-place update (refined_localization.py:188-193), and get_pos_PDF adds the
+        // overlap term once more
+        const int cap = k == 0 ? a.cap_f : a.cap_p;
+        const double* rec = (k == 0 ? a.fut : a.past) + (((int64_t)(L - 2) * a.N + x) * cap) * R;
+        const uint8_t* nw = (k == 0 ? a.fut_new : a.past_new) + (int64_t)(L - 2) * cap;
+        const int n = (k == 0 ? a.fut_cnt : a.past_cnt)[L - 2];
+        for (int q = 0; q < n; ++q) {
+            const double lp = rec[q * R], sd = rec[q * R + 1 + D], v = sd * sd + a.l2;
+            double dsq = 0.0, mu[D];
+            for (int d = 0; d < D; ++d) {
+                dsq += (c[d] - rec[q * R + 1 + d]) * (c[d] - rec[q * R + 1 + d]);
+                mu[d] = (rec[q * R + 1 + d] * a.l2 + c[d] * sd * sd) / v;
             }
-        } else {
-            const double* rf = a.fut + (((int64_t)(L - 2 - k) * a.N + x) * a.cap_f) * R;
-            const double* rp = a.past + (((int64_t)(k - 1) * a.N + x) * a.cap_p) * R;
-            const uint8_t* nf = a.fut_new + (int64_t)(L - 2 - k) * a.cap_f;
-            const uint8_t* np_ = a.past_new + (int64_t)(k - 1) * a.cap_p;
-            const int n1 = a.fut_cnt[L - 2 - k], n2 = a.past_cnt[k - 1];
-            for (int q1 = 0; q1 < n1; ++q1) {
-                const double lp1 = rf[q1 * R], s1 = rf[q1 * R + 1 + D];
-                const double v12 = s1 * s1 + a.l2, vA = s1 * s1 * a.l2 / v12;
-                double muA[D], d1 = 0.0;
+            const double lk = -0.5 * D * log(2.0 * M_PI * v) - dsq / (2.0 * v);
+            add(lp + 2.0 * lk + (k == 0 ? a.logF[nw[q]] : 0.0), mu, a.l2 * sd * sd / v);
+        }
+    } else {
+        const double* rf = a.fut + (((int64_t)(L - 2 - k) * a.N + x) * a.cap_f) * R;
+        const double* rp = a.past + (((int64_t)(k - 1) * a.N + x) * a.cap_p) * R;
+        const uint8_t* nf = a.fut_new + (int64_t)(L - 2 - k) * a.cap_f;
+        const uint8_t* np_ = a.past_new + (int64_t)(k - 1) * a.cap_p;
+        const int n1 = a.fut_cnt[L - 2 - k], n2 = a.past_cnt[k - 1];
+        for (int q1 = 0; q1 < n1; ++q1) {
+            const double lp1 = rf[q1 * R], s1 = rf[q1 * R + 1 + D];
+            const double v12 = s1 * s1 + a.l2, vA = s1 * s1 * a.l2 / v12;
+            double muA[D], d1 = 0.0;
+            for (int d = 0; d < D; ++d) {
+                const double m1 = rf[q1 * R + 1 + d];
+                muA[d] = (m1 * a.l2 + c[d] * s1 * s1) / v12;
+                d1 += (m1 - c[d]) * (m1 - c[d]);
+            }
+            const double lk1 = -0.5 * D * log(2.0 * M_PI * v12) - d1 / (2.0 * v12);
+            for (int q2 = 0; q2 < n2; ++q2) {
+                if (np_[q2] != nf[q1]) continue;  // pairs that agree on the state at this position
+                const double s3 = rp[q2 * R + 1 + D], v3 = vA + s3 * s3;
+                double d2 = 0.0, mu[D];
                 for (int d = 0; d < D; ++d) {
-                    const double m1 = rf[q1 * R + 1 + d];
-                    muA[d] = (m1 * a.l2 + c[d] * s1 * s1) / v12;
-                    d1 += (m1 - c[d]) * (m1 - c[d]);
+                    d2 += (muA[d] - rp[q2 * R + 1 + d]) * (muA[d] - rp[q2 * R + 1 + d]);
+                    mu[d] = (muA[d] * s3 * s3 + rp[q2 * R + 1 + d] * vA) / v3;
                 }
-                const double lk1 = -0.5 * D * log(2.0 * M_PI * v12) - d1 / (2.0 * v12);
-                for (int q2 = 0; q2 < n2; ++q2) {
-                    if (np_[q2] != nf[q1]) continue;  // pairs that agree on the state at this position
-                    const double s3 = rp[q2 * R + 1 + D], v3 = vA + s3 * s3;
-                    double d2 = 0.0;
-                    for (int d = 0; d < D; ++d) d2 += (muA[d] - rp[q2 * R + 1 + d]) * (muA[d] - rp[q2 * R + 1 + d]);
-                    const double w = lp1 + rp[q2 * R] + lk1 - 0.5 * D * log(2.0 * M_PI * v3) - d2 / (2.0 * v3);
-                    if (sweep == 0) {
-                        wmax = w > wmax ? w : wmax;
-                    } else {
-                        const double p = exp(w - wmax);
-                        sw += p;
-                        for (int d = 0; d < D; ++d) smu[d] += p * (muA[d] * s3 * s3 + rp[q2 * R + 1 + d] * vA) / v3;
-                        ssg += p * (vA * s3 * s3 / v3);
-                    }
-                }
+                add(lp1 + rp[q2 * R] + lk1 - 0.5 * D * log(2.0 * M_PI * v3) - d2 / (2.0 * v3), mu, vA * s3 * s3 / v3);
             }
         }
     }
@@ -1645,9 +1650,36 @@ __global__ void __launch_bounds__(256) xt_refine_combine(XtRefineArgs a)
     a.sig_out[x * L + k] = sqrt(ssg / sw);
 }
 
-// One recording pass over bucket `d_tracks` ([N][L][D] on the device): capacity probe on the pilot tracks, then the full launch.
-static int xt_refine_pass(extrack_ctx* ctx, const extrack_model* m, const double* d_tracks, int64_t N, int L, int D, double threshold,
-                          int32_t max_nb_states, double** d_rec, uint8_t** d_new, int32_t** d_cnt, int* cap_out)
+// Time-reversed copy of a bucket [N][L][D] on the device (the pass "from the future" walks the track backwards).
+__global__ void __launch_bounds__(256) xt_reverse_tracks(const double* __restrict__ src, double* __restrict__ dst, int64_t N, int L, int D)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= N * L * D) return;
+    const int64_t x = i / ((int64_t)L * D);
+    const int r = (int)(i - x * L * D), p = r / D, d = r - p * D;
+    dst[i] = src[(x * L + (L - 1 - p)) * D + d];
+}
+
+// Grow-only device buffers of the refinement path, kept in the context between calls: a hipMalloc / hipFree pair per record array and
+// call cost more than the kernels (r02: 0.25 s wall for 30 ms of kernels on 1e5 x 30).
+static int xt_rf_reserve(extrack_ctx* ctx, int slot, size_t bytes)
+{
+    if (bytes <= ctx->rf_cap_bytes[slot]) return EXTRACK_OK;
+    XT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->rf_buf[slot]) (void)hipFree(ctx->rf_buf[slot]);
+    ctx->rf_buf[slot] = nullptr;
+    ctx->rf_cap_bytes[slot] = 0;
+    hipError_t e = hipMalloc(&ctx->rf_buf[slot], bytes);
+    if (e != hipSuccess) return xt_fail(ctx, EXTRACK_E_HIP, std::string("refinement buffer (") + std::to_string(bytes >> 20) + " MiB): " + hipGetErrorString(e));
+    ctx->rf_cap_bytes[slot] = bytes;
+    return EXTRACK_OK;
+}
+enum { XT_RF_REV = 0, XT_RF_REC0, XT_RF_REC1, XT_RF_NEW0, XT_RF_NEW1, XT_RF_CNT0, XT_RF_CNT1, XT_RF_MU, XT_RF_SIG, XT_RF_STATUS };
+
+// One launch of the recording kernel over bucket `d_tracks` ([N][L][D] on the device).  rows == 0: capacity probe on the pilot tracks
+// (nothing recorded; *cap_out = sequences to record per entry); else: the tracks [row0, row0 + rows) are recorded into a.rf_out.
+static int xt_refine_launch(extrack_ctx* ctx, const extrack_model* m, const double* d_tracks, int64_t N, int L, int D, double threshold,
+                            int32_t max_nb_states, int64_t row0, int64_t rows, int rf_cap, double* d_rec, uint8_t* d_new, int32_t* d_cnt, int* cap_out)
 {
     const int S = m->n_states, F = m->frame_len, G = S;
     XtThArgs a;
@@ -1668,85 +1700,65 @@ static int xt_refine_pass(extrack_ctx* ctx, const extrack_model* m, const double
     a.pcap = (int)std::min<int64_t>(N, XT_TH_PILOT);
     a.pair_lanes_max_p = ctx->th_pair_lanes;
     a.refine = 1;
-    int32_t* d_status = nullptr;
-    XT_HIP(ctx, hipMalloc(&d_status, 4 * sizeof(int32_t)));
+    int rc = xt_rf_reserve(ctx, XT_RF_STATUS, 4 * sizeof(int32_t));
+    if (rc) return rc;
+    int32_t* d_status = (int32_t*)ctx->rf_buf[XT_RF_STATUS];
     a.status = d_status;
-    int rc = EXTRACK_OK, maxE = 0;
-    hipError_t e = hipSuccess;
-    for (int stage = 0; stage < 2 && rc == EXTRACK_OK; ++stage) {
-        // stage 0: pilots only, nothing recorded -> sequence counts; stage 1: everything
-        for (;;) {
-            int capE = ctx->th_capE;
-            while (capE < S * G) capE *= 2;
-            ctx->th_capE = capE;
-            a.capE = a.wsP = a.wsE = capE;
-            a.ws_lds = 0;
-            a.N = stage == 0 ? std::min<int64_t>(N, XT_TH_PILOT) : N;
-            a.chunk = (int32_t)std::min<int64_t>(a.N, (int64_t)1 << 30);
-            a.nchunks = 1;
-            a.cmat_words = 0;
-            const int64_t nbatch = a.N > a.pcap ? (a.N - a.pcap + a.pcap - 1) / a.pcap : 0;
-            const int grid = stage == 0 ? 1 : (int)std::max<int64_t>(1, std::min<int64_t>(nbatch, (int64_t)ctx->n_cu * 4));
-            const size_t lds = (size_t)xt_th_plan_lds_doubles(S, G, capE, D, 1) * sizeof(double);
-            a.ws_stride = xt_th_hist_doubles(a.wsE, a.pcap, true, L) + xt_th_ws_doubles(a.wsP, a.wsE, D, 1, F, 1, S, a.pcap, true);
-            const size_t need = (size_t)a.ws_stride * grid * sizeof(double);
-            if (need > ctx->th_ws_cap) {
-                (void)hipStreamSynchronize(ctx->stream);
-                if (ctx->d_th_ws) (void)hipFree(ctx->d_th_ws);
-                ctx->d_th_ws = nullptr;
-                ctx->th_ws_cap = 0;
-                if ((e = hipMalloc(&ctx->d_th_ws, need)) != hipSuccess) {
-                    rc = xt_fail(ctx, EXTRACK_E_HIP, std::string("refinement workspace: ") + hipGetErrorString(e));
-                    break;
-                }
-                ctx->th_ws_cap = need;
-            }
-            a.ws = ctx->d_th_ws;
-            if (lds > 160 * 1024) {
-                rc = xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "plan tables do not fit the 160 KiB LDS of a CU");
-                break;
-            }
-            if (D == 1) e = xt_th_launch_predict<1, 1>(ctx, a, grid, 256, lds);
-            else if (D == 2) e = xt_th_launch_predict<2, 1>(ctx, a, grid, 256, lds);
-            else e = xt_th_launch_predict<3, 1>(ctx, a, grid, 256, lds);
-            int32_t st[4] = {0, 0, 0, 0};
-            if (e == hipSuccess) e = hipMemcpyAsync(st, d_status, sizeof(st), hipMemcpyDeviceToHost, ctx->stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-            if (e != hipSuccess) {
-                rc = xt_fail(ctx, EXTRACK_E_HIP, std::string("refinement pass: ") + hipGetErrorString(e));
-                break;
-            }
-            if (st[0]) {  // capacity overflow: grow and repeat
-                int ncap = capE;
-                while (ncap < std::max(st[1], st[2])) ncap *= 2;
-                if (ncap == capE) ncap *= 2;
-                if (ncap > XT_TH_MAXCAP) {
-                    rc = xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "more than 8192 live state sequences per step (threshold fusion expands every sequence by n_states^nb_substeps before it merges): raise threshold, lower max_nb_states or nb_substeps - or use the fixed-window kernel (fusion='window' / extrack_loglik), which serves this model");
-                    break;
-                }
-                ctx->th_capE = ncap;
-                continue;
-            }
-            maxE = std::max(st[1], st[2]);
-            break;
-        }
-        if (rc != EXTRACK_OK) break;
-        if (stage == 0) {
-            a.rf_cap = std::max(maxE, S * G);
-            const size_t nrec = (size_t)(L - 1) * (size_t)N * a.rf_cap * (2 + D);
-            if ((e = hipMalloc(d_rec, nrec * sizeof(double))) != hipSuccess || (e = hipMalloc(d_new, (size_t)(L - 1) * a.rf_cap)) != hipSuccess ||
-                (e = hipMalloc(d_cnt, (size_t)(L - 1) * sizeof(int32_t))) != hipSuccess) {
-                rc = xt_fail(ctx, EXTRACK_E_HIP, std::string("refinement records: ") + hipGetErrorString(e));
-                break;
-            }
-            a.rf_out = *d_rec;
-            a.rf_new = *d_new;
-            a.rf_cnt = *d_cnt;
-        }
+    const bool probe = rows == 0;
+    if (!probe) {
+        a.rf_cap = rf_cap;
+        a.rf_out = d_rec;
+        a.rf_new = d_new;
+        a.rf_cnt = d_cnt;
+        a.rf_row0 = row0;
+        a.rf_rows = rows;
     }
-    (void)hipFree(d_status);
-    *cap_out = a.rf_cap;
-    return rc;
+    hipError_t e = hipSuccess;
+    for (;;) {
+        int capE = ctx->th_capE;
+        while (capE < S * G) capE *= 2;
+        ctx->th_capE = capE;
+        a.capE = a.wsP = a.wsE = capE;
+        a.ws_lds = 0;
+        a.N = probe ? std::min<int64_t>(N, XT_TH_PILOT) : N;
+        a.chunk = (int32_t)std::min<int64_t>(a.N, (int64_t)1 << 30);
+        a.nchunks = 1;
+        a.cmat_words = 0;
+        const int64_t first = std::max<int64_t>(row0, a.pcap), last = std::min<int64_t>(N, row0 + rows);
+        const int64_t nbatch = (!probe && last > first) ? (last - first + a.pcap - 1) / a.pcap : 0;
+        const int grid = probe ? 1 : (int)std::max<int64_t>(1, std::min<int64_t>(nbatch, (int64_t)ctx->n_cu * 4));
+        const size_t lds = (size_t)xt_th_plan_lds_doubles(S, G, capE, D, 1) * sizeof(double);
+        a.ws_stride = xt_th_hist_doubles(a.wsE, a.pcap, true, L) + xt_th_ws_doubles(a.wsP, a.wsE, D, 1, F, 1, S, a.pcap, true);
+        const size_t need = (size_t)a.ws_stride * grid * sizeof(double);
+        if (need > ctx->th_ws_cap) {
+            (void)hipStreamSynchronize(ctx->stream);
+            if (ctx->d_th_ws) (void)hipFree(ctx->d_th_ws);
+            ctx->d_th_ws = nullptr;
+            ctx->th_ws_cap = 0;
+            if ((e = hipMalloc(&ctx->d_th_ws, need)) != hipSuccess) return xt_fail(ctx, EXTRACK_E_HIP, std::string("refinement workspace: ") + hipGetErrorString(e));
+            ctx->th_ws_cap = need;
+        }
+        a.ws = ctx->d_th_ws;
+        if (lds > 160 * 1024) return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "plan tables do not fit the 160 KiB LDS of a CU");
+        if (D == 1) e = xt_th_launch_predict<1, 1>(ctx, a, grid, 256, lds);
+        else if (D == 2) e = xt_th_launch_predict<2, 1>(ctx, a, grid, 256, lds);
+        else e = xt_th_launch_predict<3, 1>(ctx, a, grid, 256, lds);
+        int32_t st[4] = {0, 0, 0, 0};
+        if (e == hipSuccess) e = hipMemcpyAsync(st, d_status, sizeof(st), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) return xt_fail(ctx, EXTRACK_E_HIP, std::string("refinement pass: ") + hipGetErrorString(e));
+        if (st[0]) {  // capacity overflow: grow and repeat
+            int ncap = capE;
+            while (ncap < std::max(st[1], st[2])) ncap *= 2;
+            if (ncap == capE) ncap *= 2;
+            if (ncap > XT_TH_MAXCAP)
+                return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "more than 8192 live state sequences per step (threshold fusion expands every sequence by n_states^nb_substeps before it merges): raise threshold, lower max_nb_states or nb_substeps - or use the fixed-window kernel (fusion='window' / extrack_loglik), which serves this model");
+            ctx->th_capE = ncap;
+            continue;
+        }
+        if (cap_out) *cap_out = std::max(std::max(st[1], st[2]), S * G);
+        return EXTRACK_OK;
+    }
 }
 
 extern "C" int extrack_refine_positions(extrack_ctx* ctx, const extrack_model* m, int32_t bucket_id, double threshold, int32_t max_nb_states,
@@ -1762,87 +1774,95 @@ extern "C" int extrack_refine_positions(extrack_ctx* ctx, const extrack_model* m
     if (!(threshold >= 0.0)) return xt_fail(ctx, EXTRACK_E_INVALID, "threshold must be >= 0");
     if (m->frame_len <= 1 || m->frame_len > 15) return xt_fail(ctx, EXTRACK_E_INVALID, "frame_len must be in (1, 15]");
     XtBucket& b = ctx->buckets[bucket_id];
-    const int S = m->n_states, L = b.L, D = b.D;
+    const int S = m->n_states, L = b.L, D = b.D, R = 2 + D;
     if (L < 2) return xt_fail(ctx, EXTRACK_E_INVALID, "position refinement needs tracks of at least 2 positions");
     XT_HIP(ctx, hipSetDevice(ctx->device));
-    // time-reversed copy of the bucket for the pass "from the future" (made on the host: the tracks are small next to the records)
     const size_t nel = (size_t)b.N * L * D;
-    std::vector<double> h((size_t)nel), hr((size_t)nel);
-    XT_HIP(ctx, hipMemcpy(h.data(), b.d_tracks, nel * sizeof(double), hipMemcpyDeviceToHost));
-    for (int64_t x = 0; x < b.N; ++x)
-        for (int p = 0; p < L; ++p)
-            for (int d = 0; d < D; ++d) hr[((size_t)x * L + p) * D + d] = h[((size_t)x * L + (L - 1 - p)) * D + d];
-    double* d_rev = nullptr;
-    XT_HIP(ctx, hipMalloc(&d_rev, nel * sizeof(double)));
-    double *d_fut = nullptr, *d_past = nullptr;
-    uint8_t *d_fnew = nullptr, *d_pnew = nullptr;
-    int32_t *d_fcnt = nullptr, *d_pcnt = nullptr;
-    double *d_mu = nullptr, *d_sig = nullptr;
-    hipError_t e = hipMemcpy(d_rev, hr.data(), nel * sizeof(double), hipMemcpyHostToDevice);
-    if (e != hipSuccess) rc = xt_fail(ctx, EXTRACK_E_HIP, std::string("refinement: ") + hipGetErrorString(e));
-    int capF = 0, capP = 0;
+    // time-reversed copy of the bucket for the pass "from the future", made on the device
+    if ((rc = xt_rf_reserve(ctx, XT_RF_REV, nel * sizeof(double)))) return rc;
+    double* d_rev = (double*)ctx->rf_buf[XT_RF_REV];
+    hipLaunchKernelGGL(xt_reverse_tracks, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, ctx->stream, b.d_tracks, d_rev, b.N, L, D);
+    XT_HIP(ctx, hipGetLastError());
+    // pass 0: from the future (reversed track, the matrix as given, refined_localization.py:211); pass 1: from the past (track as it is,
+    // transposed matrix, :213-216).  No initial fractions in the recorded weights (:93).
     std::vector<double> ones(S, 1.0), Tt((size_t)S * S);
     for (int i = 0; i < S; ++i)
         for (int j = 0; j < S; ++j) Tt[(size_t)i * S + j] = m->TrMat[(size_t)j * S + i];
-    for (int pass = 0; pass < 2 && rc == EXTRACK_OK; ++pass) {
-        // pass 0: from the future (reversed track, the matrix as given, refined_localization.py:211); pass 1: from the past (track as it
-        // is, transposed matrix, :213-216).  No initial fractions in the recorded weights (:93).
+    std::vector<double> blobs[2];
+    for (int pass = 0; pass < 2; ++pass) {
         XtModelHost mh;
         xt_model_host(m, mh);
         mh.Fs = ones.data();
         mh.TrMat = pass == 0 ? m->TrMat : Tt.data();
-        std::vector<double> blob;
         int G = 0;
-        std::string err = xt_th_build_blob(mh, blob, G);
-        if (!err.empty()) {
-            rc = xt_fail(ctx, EXTRACK_E_INVALID, err);
-            break;
+        std::string err = xt_th_build_blob(mh, blobs[pass], G);
+        if (!err.empty()) return xt_fail(ctx, EXTRACK_E_INVALID, err);
+    }
+    const double* src[2] = {d_rev, b.d_tracks};
+    // capacity probes on the pilot tracks: sequences to record per entry of either pass
+    int cap[2] = {0, 0};
+    for (int pass = 0; pass < 2; ++pass) {
+        if ((rc = xt_upload_blob(ctx, blobs[pass]))) return rc;
+        if ((rc = xt_refine_launch(ctx, m, src[pass], b.N, L, D, threshold, max_nb_states, 0, 0, 0, nullptr, nullptr, nullptr, &cap[pass]))) return rc;
+    }
+    // row blocks: both passes' records of a block stay within the memory budget (EXTRACK_REFINE_BUDGET_MB, default 16 GiB of the 288 GB);
+    // the merge plan only depends on the pilot tracks, which every launch re-walks, so the blocks are independent
+    size_t budget = (size_t)16 << 30;
+    if (const char* ev = getenv("EXTRACK_REFINE_BUDGET_MB")) {
+        const long v = atol(ev);
+        if (v >= 1) budget = (size_t)v << 20;
+    }
+    const size_t per_row = (size_t)(L - 1) * (size_t)(cap[0] + cap[1]) * R * sizeof(double);
+    int64_t RB = (int64_t)std::max<size_t>(XT_TH_PILOT, budget / per_row);
+    RB = std::min<int64_t>(RB, b.N);
+    for (int pass = 0; pass < 2; ++pass) {
+        if ((rc = xt_rf_reserve(ctx, XT_RF_REC0 + pass, (size_t)(L - 1) * (size_t)RB * cap[pass] * R * sizeof(double)))) return rc;
+        if ((rc = xt_rf_reserve(ctx, XT_RF_NEW0 + pass, (size_t)(L - 1) * cap[pass]))) return rc;
+        if ((rc = xt_rf_reserve(ctx, XT_RF_CNT0 + pass, (size_t)(L - 1) * sizeof(int32_t)))) return rc;
+    }
+    if ((rc = xt_rf_reserve(ctx, XT_RF_MU, nel * sizeof(double)))) return rc;
+    if ((rc = xt_rf_reserve(ctx, XT_RF_SIG, (size_t)b.N * L * sizeof(double)))) return rc;
+    double* d_mu = (double*)ctx->rf_buf[XT_RF_MU];
+    double* d_sig = (double*)ctx->rf_buf[XT_RF_SIG];
+    XT_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    for (int64_t row0 = 0; row0 < b.N; row0 += RB) {
+        const int64_t rows = std::min<int64_t>(RB, b.N - row0);
+        for (int pass = 0; pass < 2; ++pass) {
+            if ((rc = xt_upload_blob(ctx, blobs[pass]))) return rc;
+            if ((rc = xt_refine_launch(ctx, m, src[pass], b.N, L, D, threshold, max_nb_states, row0, rows, cap[pass], (double*)ctx->rf_buf[XT_RF_REC0 + pass],
+                                       (uint8_t*)ctx->rf_buf[XT_RF_NEW0 + pass], (int32_t*)ctx->rf_buf[XT_RF_CNT0 + pass], nullptr)))
+                return rc;
         }
-        if ((rc = xt_upload_blob(ctx, blob))) break;
-        rc = pass == 0 ? xt_refine_pass(ctx, m, d_rev, b.N, L, D, threshold, max_nb_states, &d_fut, &d_fnew, &d_fcnt, &capF)
-                       : xt_refine_pass(ctx, m, b.d_tracks, b.N, L, D, threshold, max_nb_states, &d_past, &d_pnew, &d_pcnt, &capP);
-    }
-    if (rc == EXTRACK_OK) {
-        if ((e = hipMalloc(&d_mu, nel * sizeof(double))) != hipSuccess || (e = hipMalloc(&d_sig, (size_t)b.N * L * sizeof(double))) != hipSuccess)
-            rc = xt_fail(ctx, EXTRACK_E_HIP, std::string("refinement output: ") + hipGetErrorString(e));
-    }
-    if (rc == EXTRACK_OK) {
         XtRefineArgs ra;
         memset(&ra, 0, sizeof(ra));
-        ra.tracks = b.d_tracks;
-        ra.fut = d_fut;
-        ra.past = d_past;
-        ra.fut_new = d_fnew;
-        ra.past_new = d_pnew;
-        ra.fut_cnt = d_fcnt;
-        ra.past_cnt = d_pcnt;
-        ra.mu_out = d_mu;
-        ra.sig_out = d_sig;
-        ra.N = b.N;
+        ra.tracks = b.d_tracks + (size_t)row0 * L * D;
+        ra.fut = (const double*)ctx->rf_buf[XT_RF_REC0];
+        ra.past = (const double*)ctx->rf_buf[XT_RF_REC1];
+        ra.fut_new = (const uint8_t*)ctx->rf_buf[XT_RF_NEW0];
+        ra.past_new = (const uint8_t*)ctx->rf_buf[XT_RF_NEW1];
+        ra.fut_cnt = (const int32_t*)ctx->rf_buf[XT_RF_CNT0];
+        ra.past_cnt = (const int32_t*)ctx->rf_buf[XT_RF_CNT1];
+        ra.mu_out = d_mu + (size_t)row0 * L * D;
+        ra.sig_out = d_sig + (size_t)row0 * L;
+        ra.N = rows;
         ra.L = L;
         ra.S = S;
-        ra.cap_f = capF;
-        ra.cap_p = capP;
+        ra.cap_f = cap[0];
+        ra.cap_p = cap[1];
         ra.l2 = m->locerr[0] * m->locerr[0];
         for (int s2 = 0; s2 < S; ++s2) ra.logF[s2] = log(m->Fs[s2]);
-        {
-            const int grid = (int)(((int64_t)b.N * L + 255) / 256);
-            XT_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-            if (D == 1) hipLaunchKernelGGL(xt_refine_combine<1>, dim3(grid), dim3(256), 0, ctx->stream, ra);
-            else if (D == 2) hipLaunchKernelGGL(xt_refine_combine<2>, dim3(grid), dim3(256), 0, ctx->stream, ra);
-            else hipLaunchKernelGGL(xt_refine_combine<3>, dim3(grid), dim3(256), 0, ctx->stream, ra);
-            e = hipGetLastError();
-            if (e == hipSuccess) e = hipEventRecord(ctx->ev1, ctx->stream);
-            ctx->timed = true;
-            if (e == hipSuccess) e = hipMemcpyAsync(mu, d_mu, nel * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
-            if (e == hipSuccess) e = hipMemcpyAsync(sigma, d_sig, (size_t)b.N * L * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-            if (e != hipSuccess) rc = xt_fail(ctx, EXTRACK_E_HIP, std::string("refinement combine: ") + hipGetErrorString(e));
-        }
+        const int grid = (int)(((int64_t)rows * L + 255) / 256);
+        if (D == 1) hipLaunchKernelGGL(xt_refine_combine<1>, dim3(grid), dim3(256), 0, ctx->stream, ra);
+        else if (D == 2) hipLaunchKernelGGL(xt_refine_combine<2>, dim3(grid), dim3(256), 0, ctx->stream, ra);
+        else hipLaunchKernelGGL(xt_refine_combine<3>, dim3(grid), dim3(256), 0, ctx->stream, ra);
+        XT_HIP(ctx, hipGetLastError());
     }
-    for (void* p : {(void*)d_rev, (void*)d_fut, (void*)d_past, (void*)d_fnew, (void*)d_pnew, (void*)d_fcnt, (void*)d_pcnt, (void*)d_mu, (void*)d_sig})
-        if (p) (void)hipFree(p);
-    return rc;
+    XT_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    ctx->timed = true;
+    XT_HIP(ctx, hipMemcpyAsync(mu, d_mu, nel * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    XT_HIP(ctx, hipMemcpyAsync(sigma, d_sig, (size_t)b.N * L * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    XT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return EXTRACK_OK;
 }
 
 extern "C" int extrack_th_plan_step(extrack_ctx* ctx, int32_t bucket_id, int64_t chunk_index, int32_t t, int32_t* n_expanded,

@@ -222,6 +222,9 @@ struct extrack_ctx {
     size_t gout_cap = 0;
     double* d_partials = nullptr;
     size_t partials_cap = 0;
+    static constexpr int RF_SLOTS = 10;   // position refinement: grow-only device buffers kept between calls (extrack_hip.hip: XT_RF_*)
+    void* rf_buf[RF_SLOTS] = {nullptr};
+    size_t rf_cap_bytes[RF_SLOTS] = {0};
     double* d_total = nullptr;
     double* h_total = nullptr;  // pinned
     XtBucketDesc* d_desc = nullptr;  // [XT_DESC_CAP] bucket descriptors of the launches of one evaluation

@@ -134,6 +134,8 @@ struct XtThArgs {
     double* rf_out;        // [L - 1][N][rf_cap][2 + D]: log-weight, mean[D], std   (nullptr: nothing is recorded - capacity probe)
     uint8_t* rf_new;       // [L - 1][rf_cap] newest state of every recorded sequence (shared by the tracks)
     int32_t* rf_cnt;       // [L - 1] recorded sequences per entry
+    int64_t rf_row0, rf_rows;  // this launch records the tracks [rf_row0, rf_row0 + rf_rows) of the bucket (row blocks bound the record memory);
+                               // rf_out is then [L - 1][rf_rows][rf_cap][2 + D], rows relative to rf_row0
 };
 
 // Pointer to read-only data that is addressed with wave-uniform indices: on the device it lives in the constant address
@@ -554,7 +556,7 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
 
         // refinement record of sequence q of entry `ent` (0 .. L-2) of chunk track xg: log-weight (constants dropped), mean, std
         auto rf_put = [&](int ent, int64_t xg, int q, double zm, int ze, const double* mv, double var0) {
-            double* o = a.rf_out + (((int64_t)ent * bk.N + xg) * a.rf_cap + q) * (2 + D);
+            double* o = a.rf_out + (((int64_t)ent * a.rf_rows + (xg - a.rf_row0)) * a.rf_cap + q) * (2 + D);
             o[0] = zm > 0.0 ? log(zm) + (double)ze * XT_LN2 : -INFINITY;
             for (int d = 0; d < D; ++d) o[1 + d] = mv[d];
             o[1 + D] = sqrt(var0);
@@ -919,7 +921,7 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
                 for (int i = tid; i < P * nG; i += nt) {
                     const int x = i / nG, g2 = i - x * nG;
                     xt_th_gather<D, K>(bA, 1, x * wsP, mpk, (int)gst[g2], (int)gst[g2 + 1], TTl, TD2, bB, x * wsP + g2, dtf(x, t));
-                    if (RF && a.rf_out && cx.block() == 0 && g2 < a.rf_cap) {
+                    if (RF && a.rf_out && cx.block() == 0 && a.rf_row0 == 0 && g2 < a.rf_cap) {
                         double mv[D];
                         for (int d = 0; d < D; ++d) mv[d] = bB.m(d, x * wsP + g2);
                         rf_put(t - 1, c0 + x, g2, bB.zm(x * wsP + g2), bB.ze(x * wsP + g2), mv, bB.u(0, x * wsP + g2));
@@ -1076,7 +1078,7 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
             const int tl = L - 1, nE = nParF * G;
             for (int i = tid; i < cnt * nE; i += nt) {
                 const int x = i / nE, jj = i - x * nE, g = jj / G, r = jj - g * G, idx = x * wsP + g, o = (int)nwA[g] * G + r;
-                if (jj >= a.rf_cap) continue;
+                if (jj >= a.rf_cap || (shared && a.rf_row0 != 0)) continue;  // the pilots' rows belong to the first row block
                 double mv[D];
                 for (int d = 0; d < D; ++d) mv[d] = vA.m(d, idx);
                 rf_put(tl - 1, c0 + xb + x, jj, vA.zm(idx) * TAB[o], vA.ze(idx), mv, xt_fma(TD2[o], dtf(xb + x, tl), vA.u(0, idx)));
@@ -1183,8 +1185,10 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
             // ---- tracks beyond the pilots (predict_Bs with nb_max > 30, tracking.py:856-868): they take no part in the merge
             // decisions (fuse_tracks_th looks at the first 30 tracks only, tracking.py:676-691) but are merged with THEIR OWN
             // weights (tracking.py:703-741): replay the recorded plan batch by batch in the pilots' slots
-            for (int xb = RF ? P + PC * cx.block() : P; xb < n && (!RF || a.rf_out); xb += RF ? PC * cx.nblocks() : PC) {
-                const int cnt = (n - xb) < PC ? (n - xb) : PC;
+            const int64_t rf_first = RF ? (a.rf_row0 > P ? a.rf_row0 : (int64_t)P) : 0;
+            const int nrep = RF ? (int)((a.rf_row0 + a.rf_rows) < n ? (a.rf_row0 + a.rf_rows) : n) : n;  // replay bound of this launch
+            for (int xb = RF ? (int)rf_first + PC * cx.block() : P; xb < nrep && (!RF || a.rf_out); xb += RF ? PC * cx.nblocks() : PC) {
+                const int cnt = (nrep - xb) < PC ? (nrep - xb) : PC;
                 cx.sync();
                 for (int i = tid; i < cnt * S; i += nt) {
                     const int x = i / S, s2 = i - x * S, idx = x * wsP + s2;

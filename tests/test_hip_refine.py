@@ -48,6 +48,14 @@ def test_position_refinement_larger_bucket_vs_oracle_and_errors():
     mus, sigs = RL.position_refinement({str(L): Cs}, 0.03, ds, Fs, Tm, frame_len=6, threshold=0.1, max_nb_states=100)
     ref_mu, ref_sig = OR.position_refinement({str(L): Cs}, 0.03, ds, Fs, Tm, 6, 0.1, 100)
     assert np.abs(mus[str(L)] - ref_mu[str(L)]).max() < 1e-9 and np.abs(sigs[str(L)] - ref_sig[str(L)]).max() < 1e-9
+    # the same bucket in row blocks of a few dozen tracks (record memory bounded by EXTRACK_REFINE_BUDGET_MB): every block re-walks the
+    # pilots' plan, the refined positions do not depend on the blocking
+    os.environ["EXTRACK_REFINE_BUDGET_MB"] = "1"
+    try:
+        mus_b, sigs_b = RL.position_refinement({str(L): Cs}, 0.03, ds, Fs, Tm, frame_len=6, threshold=0.1, max_nb_states=100)
+    finally:
+        del os.environ["EXTRACK_REFINE_BUDGET_MB"]
+    assert np.array_equal(mus_b[str(L)], mus[str(L)]) and np.array_equal(sigs_b[str(L)], sigs[str(L)])
     raw = np.sqrt(((Cs - truth) ** 2).mean())
     ref = np.sqrt(((mus[str(L)] - truth) ** 2).mean())
     assert ref < 0.9 * raw, (raw, ref)
