@@ -109,6 +109,18 @@ def cpu_baseline_th(cores, sample_tracks_per_core=16000):
             "sample": "%d tracks in 2000-track chunks, numpy oracle_th; %.0f tracks/s" % (n, n / wall)}
 
 
+def cpu_hist_worker(args):
+    from oracle import oracle_hist as OH
+    tr, vals = args
+    return OH.len_hist(vals, tr, DT, cell_dims=CELL, max_nb_states=500).sum()
+
+
+def cpu_refine_worker(args):
+    from oracle import oracle_refine as OR
+    tr, dsr = args
+    return OR.position_refinement(tr, LOCERR, dsr, np.array(FS), np.array(TRMAT), 6, 0.1, 1000)[0]["30"].sum()
+
+
 def cpu_baseline_compiled(cores, n=400000):
     """Secondary CPU number: the plain-C restatement (oracle/extrack_oracle.c, gcc -O2 -fopenmp, log domain like the reference)
     on the same socket.  Reported next to the numpy baseline so that the GPU/CPU ratio can also be read against compiled code."""
@@ -190,12 +202,48 @@ def other_configs(device):
     out["c3_loglik_grad_F4"] = {"what": "configs[2], frame_len 4: -sum(LL) AND its exact gradient (13 free parameters) in one pass", "kernel_ms": ts.ctx.last_grad_ms(),
                                 "n_directions": len(names), "fd_equivalent_ms": (len(names) + 1) * out["c3_loglik_F4"]["kernel_ms"],
                                 "grad_inf_norm": float(np.abs(gg).max())}
+    for _ in range(2):
+        gv, gg = gradient.objective_and_gradient(pg, ts, DT, CELL, 3, 1, 6, names=names)
+    out["c3_loglik_grad_F6"] = {"what": "configs[2], frame_len 6 (the reference's default): the same one-pass gradient - tangents in LDS, several passes; slower than "
+                                        "the finite differences it would replace, so param_fitting's timing probe keeps finite differences for this model",
+                                "kernel_ms": ts.ctx.last_grad_ms(), "n_directions": len(names),
+                                "fd_equivalent_ms": (len(names) + 1) * out["c3_loglik_F6"]["kernel_ms"]}
     model = tracking._objective_model(P(vals), ts, DT, CELL, None, 3, 1, 6, 1)
     # two untimed evaluations: the first learns the sequence counts (LDS sizing), the second allocates the second stream's launch buffers
     wall, kms, v = timed(lambda: ts.loglik_th(model, 0.2, 120, 2000), 5, warm=2)
     out["c3_loglik_threshold"] = {"what": "configs[2] through the threshold-fusion kernels (v1.6.3 defaults, frame_len 6)", "ms_per_eval": wall * 1e3,
                                   "kernel_ms": kms, "algorithmic_bytes": nbytes, "hbm_gbs": nbytes / (kms * 1e-3) / 1e9, "neg_loglik": -v}
     ts.close()
+    # configs[2] as BASELINE states it: the FULL fit of the 1e6-track dataset (3 states, 13 free parameters, frame_len 6), default settings -
+    # param_fitting decides by a timing probe whether the optimiser gets the one-pass gradient (ngev > 0) or differences the objective
+    import contextlib
+    import io
+    tracks = {str(L): synth.brownian_tracks(n, L, Ds, Tm, [0.3, 0.3, 0.4], seed=1000 + L) for L, n in sizes.items() if n > 0}
+    p0 = tracking.generate_params(nb_states=3, LocErr_type=1, LocErr_bounds=[0.005, 0.1], D_max=3, estimated_Ds=[0.0001, 0.02, 0.4],
+                                  estimated_Fs=[0.3, 0.3], estimated_transition_rates=0.1)
+    with contextlib.redirect_stdout(io.StringIO()):
+        t0 = time.perf_counter()
+        r = tracking.param_fitting(tracks, DT, params=p0, nb_states=3, frame_len=6, cell_dims=CELL, verbose=0, device=device)
+        t_fit = time.perf_counter() - t0
+    out["c3_full_fit_F6"] = {"what": "configs[2]: param_fitting on 1e6 tracks, 3 states, 46 buckets, frame_len 6, BFGS from a generic start (incl. the upload)",
+                             "seconds": t_fit, "objective_calls": int(r.nfev), "gradient_calls": int(getattr(r, "ngev", 0)), "neg_loglik": float(r.residual[0]),
+                             "fitted": {k: float(r.params[k].value) for k in ("D1", "D2", "LocErr", "F0", "F1")},
+                             "simulated": {"D1": 0.04, "D2": 0.25, "LocErr": LOCERR, "F0": 0.3, "F1": 0.3}}
+    del tracks
+    # the same for the headline dataset (configs[1]: 1e6 x 30, 2 states, 7 free parameters): analytic gradient vs finite differences
+    c2 = {str(LEN): synth.brownian_tracks(N_TRACKS, LEN, DS_COEF, TRMAT, FS, LOCERR, DT, DIMS, seed=0)}
+    p2 = tracking.generate_params(nb_states=2, LocErr_type=1, LocErr_bounds=[0.005, 0.1], D_max=3, estimated_Ds=[0.0001, 0.1], estimated_Fs=[0.5],
+                                  estimated_transition_rates=0.05)
+    fits2 = {}
+    for grad in (None, "fd"):
+        with contextlib.redirect_stdout(io.StringIO()):
+            t0 = time.perf_counter()
+            r = tracking.param_fitting(c2, DT, params=p2, nb_states=2, frame_len=6, cell_dims=CELL, verbose=0, device=device, gradient=grad)
+            fits2["default" if grad is None else grad] = {"seconds": time.perf_counter() - t0, "objective_calls": int(r.nfev),
+                                                           "gradient_calls": int(getattr(r, "ngev", 0)), "neg_loglik": float(r.residual[0])}
+    out["c2_full_fit_F6"] = {"what": "configs[1] data: param_fitting on 1e6 x 30, 2 states, frame_len 6 from a generic start; 'default' = gradient=None "
+                                     "(timing probe -> one-pass analytic gradient, tangents in registers), 'fd' = finite differences like the reference", "fit": fits2}
+    del c2
     # ---- configs[4]: 5e5 tracks x 60, 4 states, nb_substeps 3 (frame_len 4) + predict_Bs (nb_substeps 1, frame_len 5)
     N5, L5 = 500000, 60
     Tm = np.full((4, 4), 0.05 / 3)
@@ -241,8 +289,6 @@ def other_configs(device):
     except Exception as e:
         out["c5_loglik_ns3_F4"]["cpu_port_c"] = {"error": str(e)}
     # ---- configs[0]-size dataset (a real experiment: ~7 000 tracks in 16 length buckets): one evaluation of both objectives and a whole fit
-    import contextlib
-    import io
     Ds2, Tm2, Fs2 = [0.0, 0.25], [[0.9, 0.1], [0.1, 0.9]], [0.6, 0.4]
     sizes = synth.bucket_sizes_geometric(6730, list(range(5, 21)), 0.85)
     small = {str(L): synth.brownian_tracks(n, L, Ds2, Tm2, Fs2, seed=L) for L, n in sizes.items() if n > 0}
@@ -254,11 +300,12 @@ def other_configs(device):
     w_th, k_th, _ = timed(lambda: ts.loglik_th(model, 0.2, 120, 2000), 50, warm=2)
     ts.close()
     fits = {}
-    for grad in ("analytic", "fd"):
+    for grad in ("analytic", "fd", None):
         with contextlib.redirect_stdout(io.StringIO()):
             t0 = time.perf_counter()
             r = tracking.param_fitting(small, DT, nb_states=2, frame_len=6, cell_dims=CELL, verbose=0, gradient=grad, device=device)
-            fits[grad] = {"seconds": time.perf_counter() - t0, "objective_calls": int(r.nfev), "neg_loglik": float(r.residual[0])}
+            fits["default" if grad is None else grad] = {"seconds": time.perf_counter() - t0, "objective_calls": int(r.nfev),
+                                                          "gradient_calls": int(getattr(r, "ngev", 0)), "neg_loglik": float(r.residual[0])}
     out["c1_like_small_dataset"] = {"what": "6 730 tracks in 16 length buckets (5-20 positions), 2 states, frame_len 6: one evaluation, and param_fitting from the "
                                             "default start with the exact gradient / with finite differences",
                                     "window_ms_per_eval": w_win * 1e3, "window_kernel_ms": k_win, "threshold_ms_per_eval": w_th * 1e3,
@@ -278,10 +325,36 @@ def other_configs(device):
         t0 = time.perf_counter()
         mu, sg = position_refinement(big, 0.02, dsr, np.array(Fs2), np.array(Tm2), frame_len=6, device=device)
         t_r = time.perf_counter() - t0
+    nb30 = big["30"].nbytes
     out["len_hist_1e5x30"] = {"what": "histograms.len_hist, 1e5 tracks x 30, 2 states, max_nb_states 500 (the reference's default)", "seconds": t_h,
-                              "tracks_per_s": 1e5 / t_h, "hist_sum": float(h.sum())}
+                              "tracks_per_s": 1e5 / t_h, "hist_sum": float(h.sum()),
+                              "algorithmic_bytes": nb30 + h.nbytes, "byte_model": "one read of the tracks (480 B / track) + the [29, 2] histogram; the "
+                              "<= 500 surviving sequences of a track (state, ranking keys) never leave the LDS of its workgroup",
+                              "hbm_gbs": (nb30 + h.nbytes) / t_h / 1e9}
     out["position_refinement_1e5x30"] = {"what": "refined_localization.position_refinement, 1e5 tracks x 30, 2 states, frame_len 6, threshold 0.1",
-                                         "seconds": t_r, "tracks_per_s": 1e5 / t_r, "mean_sigma": float(sg["30"].mean())}
+                                         "seconds": t_r, "tracks_per_s": 1e5 / t_r, "mean_sigma": float(sg["30"].mean()),
+                                         "algorithmic_bytes": 2 * nb30 + sg["30"].nbytes,
+                                         "byte_model": "tracks in (480 B / track) + refined positions and stds out (720 B / track); the per-position records of the "
+                                         "forward and backward pass (~24 sequences x 4 doubles per position and pass) go through HBM once each way on top of that",
+                                         "hbm_gbs": (2 * nb30 + sg["30"].nbytes) / t_r / 1e9}
+    try:  # CPU side: the numpy restatements (pinned to the reference's fixtures) on bounded samples, one socket's cores
+        import multiprocessing as mp
+        cores = _one_socket_cores()
+        nh = 50 * cores
+        smp = {"30": big["30"][:nh]}
+        chunks = [({"30": smp["30"][a_:a_ + 50]}, v2) for a_ in range(0, nh, 50)]
+        t0 = time.perf_counter()
+        with mp.get_context("fork").Pool(cores) as pool:
+            pool.map(cpu_hist_worker, chunks)
+        out["len_hist_1e5x30"]["cpu_baseline"] = {"tracks_per_s": nh / (time.perf_counter() - t0), "cores": cores, "kind": "port",
+                                                  "sample": "%d tracks in 50-track chunks (len_hist's chunk), numpy oracle_hist, max_nb_states 500" % nh}
+        t0 = time.perf_counter()
+        with mp.get_context("fork").Pool(cores) as pool:
+            pool.map(cpu_refine_worker, [({"30": smp["30"][a_:a_ + 50]}, dsr) for a_ in range(0, nh, 50)])
+        out["position_refinement_1e5x30"]["cpu_baseline"] = {"tracks_per_s": nh / (time.perf_counter() - t0), "cores": cores, "kind": "port",
+                                                            "sample": "%d tracks in 50-track buckets, numpy oracle_refine" % nh}
+    except Exception as e:
+        out["len_hist_1e5x30"]["cpu_baseline"] = {"error": str(e)}
     return out
 
 

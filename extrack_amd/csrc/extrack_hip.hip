@@ -1037,7 +1037,9 @@ static int xt_th_run_group(extrack_ctx* ctx, const extrack_model* m, const std::
         bool lds_mode = false;
         a.wsP = a.wsE = capE;
         if (ctx->th_learnE > 0 && !force_global) {
-            const int wp = std::min(capE, std::max(S * G, ctx->th_learnP)), we = std::min(capE, std::max(S * G, ctx->th_learnE));
+            // ODD per-pilot strides: the pair tests read the pilots' means / stds with lanes = pilot tracks, i.e. at a stride of wsP / wsE
+            // doubles - an even stride put the 32 lanes on 16 ... 1 bank pairs (r02 PMC: 59 - 71 % of the plan kernel's LDS cycles were conflicts)
+            const int wp = std::min(capE, std::max(S * G, ctx->th_learnP)) | 1, we = std::min(capE, std::max(S * G, ctx->th_learnE)) | 1;
             const size_t need = lds + (size_t)xt_th_ws_doubles(wp, we, D, K, F, NS, S, a.pcap) * sizeof(double);
             if (need <= 64 * 1024) {
                 lds_mode = true;
@@ -1058,7 +1060,7 @@ static int xt_th_run_group(extrack_ctx* ctx, const extrack_model* m, const std::
         }
         if (!lds_mode && ctx->th_learnE > 0 && !force_global) {
             // LDS copy of what the grouping reads (pilot means, stds), sized by the previous evaluation's sequence counts
-            const int sp = std::min(capE, ctx->th_learnP), se = std::min(capE, ctx->th_learnE);
+            const int sp = std::min(capE, ctx->th_learnP) | 1, se = std::min(capE, ctx->th_learnE) | 1;
             const size_t st = (size_t)a.pcap * ((size_t)sp * D + (size_t)se * K) * sizeof(double);
             if (lds + st <= 120 * 1024) {
                 a.stP = sp;
@@ -1457,7 +1459,7 @@ extern "C" int extrack_predict_th(extrack_ctx* ctx, const extrack_model* m, int3
         a.cmat_words = 0;
         size_t lds = (size_t)xt_th_plan_lds_doubles(S, G, capE, D, K) * sizeof(double);
         if (pass == 1) {
-            const int wp = std::min(capE, std::max(S * G, learnP)), we = std::min(capE, std::max(S * G, learnE));
+            const int wp = std::min(capE, std::max(S * G, learnP)) | 1, we = std::min(capE, std::max(S * G, learnE)) | 1;  // odd strides: see the fit-mode launcher
             // bit matrix: only what the probed sequence counts need (a workgroup is one wavefront here: LDS decides how many
             // tracks a CU works on at a time)
             const int cst = (S & (S - 1)) == 0 ? S : 1;
