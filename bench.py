@@ -280,7 +280,7 @@ def other_configs(device):
     try:
         from oracle import oracle_c, oracle_np as O
         cores = _one_socket_cores()
-        LocErr, ds, Fs, T, pBL = O.extract_params(vals, DT, 4, 3)  # (params, dt, nb_states, nb_substeps)
+        LocErr, ds, Fs, T, pBL = O.extract_params(vals, DT, nb_substeps=3, Matrix_type=1)  # the ORACLE's signature (values, dt, nb_substeps, Matrix_type)
         smp = synth.brownian_tracks(2 * cores, L5, [0.0, 0.02, 0.1, 0.5], Tm, [0.25] * 4, seed=3)
         t0 = time.perf_counter()
         oracle_c.run(smp, LocErr, ds, Fs, T, pBL, 0, O.p_stay_table(ds, 4, 3, CELL), 3, 4, L5, nthreads=cores)
