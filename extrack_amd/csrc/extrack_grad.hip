@@ -20,9 +20,13 @@ __global__ void __launch_bounds__(MAXT, (MAXT == 256 ? XT_GRAD_WAVES : 1)) xt_gr
 }
 
 // Column sums of the per-block partials [nrows][ncol] in a fixed order: one workgroup per column.  Column 0 (sum LL) goes to ll_dst
-// (nullptr: dropped - every pass recomputes it, only the first one reports it), column 1 + i to out[i].
+// (nullptr: dropped - every pass recomputes it, only the first one reports it), column 1 + i to out[dst.idx[i]] (the launch may have
+// served the directions in another order than the caller's).
+struct XtGradDst {
+    int32_t idx[16];
+};
 __global__ void __launch_bounds__(256) xt_grad_reduce(const double* __restrict__ partials, int nrows, int ncol, double* __restrict__ ll_dst,
-                                                      double* __restrict__ out)
+                                                      double* __restrict__ out, XtGradDst dst)
 {
     __shared__ double sh[256];
     const int col = blockIdx.x;
@@ -38,9 +42,15 @@ __global__ void __launch_bounds__(256) xt_grad_reduce(const double* __restrict__
         if (col == 0) {
             if (ll_dst) *ll_dst = sh[0];
         } else {
-            out[col - 1] = sh[0];
+            out[col - 1 < 16 ? dst.idx[col - 1] : col - 1] = sh[0];
         }
     }
+}
+static XtGradDst xt_grad_dst_identity(int base)
+{
+    XtGradDst d;
+    for (int i = 0; i < 16; ++i) d.idx[i] = base + i;
+    return d;
 }
 
 struct GradLauncher {
@@ -188,7 +198,7 @@ static int xt_grad_enqueue(extrack_ctx* ctx, const extrack_model* m, int32_t n_d
         }
         // directions per pass: as many as keep one track's state within the LDS of a CU (all of them for the usual models)
         int npass_dir = std::max(n_dir, 1);
-        while (npass_dir > 1 && xt_grad_lds_bytes(c, D, K, npass_dir, 1, false) > 150 * 1024) npass_dir = (npass_dir + 1) / 2;
+        while (npass_dir > 1 && (npass_dir > 16 || xt_grad_lds_bytes(c, D, K, npass_dir, 1, false) > 150 * 1024)) npass_dir = (npass_dir + 1) / 2;
         if (xt_grad_lds_bytes(c, D, K, std::min(npass_dir, std::max(n_dir, 0)), 1, false) > 160 * 1024)
             return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "sequence state with one tangent direction does not fit the 160 KiB LDS of a CU");
         // bucket descriptors of this group (shared by its passes)
@@ -212,14 +222,30 @@ static int xt_grad_enqueue(extrack_ctx* ctx, const extrack_model* m, int32_t n_d
         const bool r2 = ctx->grad_reg2 && xt_use_reg2(c.S, c.NS, c.F) && m->locerr_mode == 0 && n_dir > 0 && xt_r2_kernel(c.F, D, K, 1) != nullptr;
         if (r2) {
             const int tpw = 64 >> (c.F - 1), tpb = tpw * XT_F2_WAVES, threads = 64 * XT_F2_WAVES;
-            const int npass = (n_dir + 7) / 8, per = (n_dir + npass - 1) / npass;
+            // "uniform" directions (xt_r2_uniform_direction, e.g. pBL) cost no per-step work: they ride along with the first pass
+            std::vector<int> full, uni;
+            for (int i = 0; i < n_dir; ++i)
+                ((int)uni.size() < XT_R2_MAXU && xt_r2_uniform_direction(ctx->h_dblob + (size_t)i * TB) ? uni : full).push_back(i);
+            if (full.empty()) {
+                full.push_back(uni.back());
+                uni.pop_back();
+            }
+            // device copy of the tangent blocks in launch order: full directions first, then the uniform ones
+            const int NF = (int)full.size(), NUn = (int)uni.size();
+            if ((rc = xt_grad_reserve(ctx, &ctx->d_dblob2, &ctx->dblob2_cap, (size_t)n_dir * TB))) return rc;
+            for (int i = 0; i < n_dir; ++i) {
+                const int src = i < NF ? full[i] : uni[i - NF];
+                XT_HIP(ctx, hipMemcpyAsync(ctx->d_dblob2 + (size_t)i * TB, ctx->d_dblob + (size_t)src * TB, (size_t)TB * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+            }
+            const int npass = (NF + 7) / 8, per = (NF + npass - 1) / npass;
             double lo = INFINITY, hi = -INFINITY;
             for (int k = 0; k < m->locerr_dims && k < 3; ++k) {
                 lo = std::min(lo, m->locerr[k] * m->locerr[k]);
                 hi = std::max(hi, m->locerr[k] * m->locerr[k]);
             }
-            for (int p0 = 0; p0 < n_dir; p0 += per) {
-                const int NP = std::min(per, n_dir - p0);
+            for (int p0 = 0; p0 < NF; p0 += per) {
+                const int NP = std::min(per, NF - p0);
+                const int NU = p0 == 0 ? NUn : 0, NPT = NP + NU;
                 const void* kp = xt_r2_kernel(c.F, D, K, NP);
                 if (!kp) return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "gradient kernel variant not built");
                 XtKernelArgs a;
@@ -227,7 +253,7 @@ static int xt_grad_enqueue(extrack_ctx* ctx, const extrack_model* m, int32_t n_d
                 xt_fill_args_from_config(c, a);
                 XtGradArgs ga;
                 memset(&ga, 0, sizeof(ga));
-                const size_t lds = (size_t)xt_r2_block_bytes(NP, D, 0, tpw);
+                const size_t lds = (size_t)xt_r2_block_bytes(NPT, D, 0, tpw);
                 auto key = std::make_pair(kp, std::make_pair(threads, lds));
                 auto it = ctx->occ_cache.find(key);
                 if (it == ctx->occ_cache.end()) {
@@ -251,7 +277,7 @@ static int xt_grad_enqueue(extrack_ctx* ctx, const extrack_model* m, int32_t n_d
                     a.blk_end[i] = (int32_t)acc;
                 }
                 const int grid = (int)acc;
-                if (poff + (size_t)grid * (NP + 1) > ctx->gpartials_cap) return xt_fail(ctx, EXTRACK_E_HIP, "gradient partial-sum buffer too small");
+                if (poff + (size_t)grid * (NPT + 1) > ctx->gpartials_cap) return xt_fail(ctx, EXTRACK_E_HIP, "gradient partial-sum buffer too small");
                 a.desc = ctx->d_desc + doff;
                 a.ndesc = (int32_t)descs.size();
                 a.blob = ctx->d_blob;
@@ -260,16 +286,21 @@ static int xt_grad_enqueue(extrack_ctx* ctx, const extrack_model* m, int32_t n_d
                 a.locerr_mode = 0;
                 a.KS = 1;
                 a.well_scaled = xt_model_well_scaled(blob, lo, hi) ? 1 : 0;
-                ga.dblob = ctx->d_dblob + (size_t)p0 * TB;
+                ga.dblob = ctx->d_dblob2 + (size_t)p0 * TB;
                 ga.gpartials = ctx->d_gpartials + poff;
                 ga.NP = NP;
                 ga.TB = TB;
+                ga.NU = NU;
+                ga.udblob = ctx->d_dblob2 + (size_t)NF * TB;
                 void* kargs[2] = {(void*)&a, (void*)&ga};
                 XT_HIP(ctx, hipLaunchKernel(kp, dim3(grid), dim3(threads), kargs, lds, ctx->stream));
-                hipLaunchKernelGGL(xt_grad_reduce, dim3(NP + 1), dim3(256), 0, ctx->stream, ctx->d_gpartials + poff, grid, NP + 1,
-                                   p0 == 0 ? d_out : nullptr, d_out + 1 + p0);
+                XtGradDst dst = xt_grad_dst_identity(0);  // column 1 + i of this launch -> the caller's direction index
+                for (int i = 0; i < NP; ++i) dst.idx[i] = full[p0 + i];
+                for (int i = 0; i < NU; ++i) dst.idx[NP + i] = uni[i];
+                hipLaunchKernelGGL(xt_grad_reduce, dim3(NPT + 1), dim3(256), 0, ctx->stream, ctx->d_gpartials + poff, grid, NPT + 1,
+                                   p0 == 0 ? d_out : nullptr, d_out + 1, dst);
                 XT_HIP(ctx, hipGetLastError());
-                poff += (size_t)grid * (NP + 1);
+                poff += (size_t)grid * (NPT + 1);
                 ctx->launch_info[0] = grid;
                 ctx->launch_info[1] = threads;
                 ctx->launch_info[2] = (int32_t)lds;
@@ -341,8 +372,9 @@ static int xt_grad_enqueue(extrack_ctx* ctx, const extrack_model* m, int32_t n_d
             l.ga.PJ = PJ;
             if (!xt_grad_dispatch(c.G, D, K, l)) return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "gradient kernel variant not built");
             if (l.herr != hipSuccess) return xt_fail(ctx, EXTRACK_E_HIP, std::string("gradient kernel launch: ") + hipGetErrorString(l.herr));
+            if (NP > 16) return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "more than 16 directions per pass");
             hipLaunchKernelGGL(xt_grad_reduce, dim3(NP + 1), dim3(256), 0, ctx->stream, ctx->d_gpartials + poff, l.grid, NP + 1,
-                               p0 == 0 ? d_out : nullptr, d_out + 1 + p0);
+                               p0 == 0 ? d_out : nullptr, d_out + 1, xt_grad_dst_identity(p0));
             XT_HIP(ctx, hipGetLastError());
             poff += (size_t)l.grid * (NP + 1);
             ctx->launch_info[0] = l.grid;

@@ -215,6 +215,7 @@ extern "C" void extrack_destroy(extrack_ctx* ctx)
     if (ctx->d_preds) (void)hipFree(ctx->d_preds);
     if (ctx->d_dblob) (void)hipFree(ctx->d_dblob);
     if (ctx->h_dblob) (void)hipHostFree(ctx->h_dblob);
+    if (ctx->d_dblob2) (void)hipFree(ctx->d_dblob2);
     if (ctx->ev_dblob) (void)hipEventDestroy(ctx->ev_dblob);
     if (ctx->d_gout) (void)hipFree(ctx->d_gout);
     for (int i = 0; i < extrack_ctx::RF_SLOTS; ++i)

@@ -37,6 +37,8 @@ struct XtGradArgs {
     int32_t TB;            // doubles per direction: XT_BLOB_HDR + XT_NTAB * S * G
     int32_t tan_lds;       // 1: the tangent tables are copied to LDS (small models), 0: read from global memory
     int32_t PJ;            // threads per group: thread (g, j) carries the directions j, j + PJ, ... (power of two, adjacent lanes)
+    int32_t NU;            // register-resident 2-state kernels (xt_reg2.h): "uniform" directions handled at the last position only
+    const double* udblob;  // [NU][TB] their tangent tables
 };
 // Tangent table block of one direction (TB doubles):
 //   [0..2] d l2 (global localisation error),  [3] d slope,  [4] d offset,  [8 + s] d log Fs[s]

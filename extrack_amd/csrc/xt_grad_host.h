@@ -80,3 +80,23 @@ static void xt_build_tangent_block(const XtModelHost& m, const extrack_model_tan
         }
 }
 
+
+// Register-resident 2-state kernels (xt_reg2.h): is this direction "uniform", i.e. does every weight factor of a step change by the SAME
+// relative amount for all sequences (no change of the localisation / diffusion variances, equal d log of the initial fractions, constant
+// d log T and d log (T * stay) tables)?  Then its tangent needs no per-step work: rz is the same number for every sequence, dm = du = 0.
+// Typical case: the bleaching probability pBL.  tb: the direction's tangent block (xt_build_tangent_block) of a 2-state, 1-substep model.
+static inline bool xt_r2_uniform_direction(const double* tb)
+{
+    // "equal": to 1e-13 relative (the entries are quotients of products that differ in their rounding, not in their value)
+    auto same = [](double a, double b) { return fabs(a - b) <= 1e-13 * (fabs(a) > fabs(b) ? fabs(a) : fabs(b)); };
+    for (int k = 0; k < 5; ++k)
+        if (tb[k] != 0.0) return false;          // d l2, d slope, d offset
+    if (!same(tb[8], tb[9])) return false;       // d log Fs
+    const double* T = tb + XT_BLOB_HDR;
+    for (int v = 0; v < 2; ++v)
+        for (int i = 1; i < 4; ++i)
+            if (!same(T[v * 4 + i], T[v * 4])) return false;  // d log T, d log (T * stay): constant over [prev][q]
+    for (int i = 0; i < 4; ++i)
+        if (T[4 * 4 + i] != 0.0) return false;   // d d2
+    return true;
+}

@@ -209,6 +209,8 @@ struct extrack_ctx {
     size_t th_blobs_cap = 0;        // doubles
     double* d_dblob = nullptr;      // gradient path: tangent tables [n_dir][TB]
     size_t dblob_cap = 0;           // doubles
+    double* d_dblob2 = nullptr;     // the same blocks in launch order (2-state kernels: full directions first, then the uniform ones)
+    size_t dblob2_cap = 0;
     double* h_dblob = nullptr;      // pinned staging of the tangent tables (read by an asynchronous copy)
     size_t h_dblob_cap = 0;
     hipEvent_t ev_dblob = nullptr;  // recorded after that copy: the next evaluation waits for it before refilling the staging buffer

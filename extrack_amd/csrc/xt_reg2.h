@@ -58,6 +58,7 @@ XT_HD int xt_r2_slot(int lane)
 // LDS map (bytes): [model blob 1 KiB (as xt_fast2.h: tables, T64, NaN flags)] [tangent blocks NP x TB] [staged positions] [accumulators]
 #define XT_R2_TAN0 XT_F2_TAB_BYTES
 #define XT_R2_TB 36  // xt_grad_tb_doubles(2, 2)
+#define XT_R2_MAXU 4  // uniform directions served by one launch (on top of its NP full ones)
 XT_HD int xt_r2_pos0(int NP) { return XT_R2_TAN0 + NP * XT_R2_TB * 8; }
 XT_HD int xt_r2_acc0(int NP, int D, int KS, int tpw) { return xt_r2_pos0(NP) + XT_F2_WAVES * tpw * XT_F2_CHUNK * (D + KS) * 8; }
 XT_HD int xt_r2_block_bytes(int NP, int D, int KS, int tpw) { return xt_r2_acc0(NP, D, KS, tpw) + XT_F2_WAVES * 8 * (NP + 3) * 8; }
@@ -341,6 +342,11 @@ XT_HD void xt_r2_body(const XtKernelArgs& a, const XtGradArgs& ga, Ctx& cx)
     for (int i = cx.tid(); i < ntab; i += cx.nthreads()) smem[i] = a.blob[i];
     if (NP > 0)
         for (int i = cx.tid(); i < NP * XT_R2_TB; i += cx.nthreads()) xt_at<double>(lds, XT_R2_TAN0 + i * 8) = ga.dblob[i];
+    // "uniform" directions (ga.NU of them, tangent blocks after the NP full ones): d log of every weight factor of a step is the same for
+    // all sequences (e.g. the bleaching probability pBL) - then rz stays equal over the sequences, dm = du = 0, and only the last
+    // position's factor table tells the sequences apart: no per-step work at all (see the read-out below)
+    const int NU = NP > 0 ? ga.NU : 0, NPT = NP + NU;
+    for (int i = cx.tid(); i < NU * XT_R2_TB; i += cx.nthreads()) xt_at<double>(lds, XT_R2_TAN0 + (NP * XT_R2_TB + i) * 8) = ga.udblob[i];
     cx.sync();
     const double* hdr = smem;
 
@@ -354,17 +360,17 @@ XT_HD void xt_r2_body(const XtKernelArgs& a, const XtGradArgs& ga, Ctx& cx)
     for (int k = 0; k < K; ++k) l2g[k] = hdr[k];
     const bool well_scaled = a.well_scaled != 0;
 
-    double* pos = (double*)(lds + xt_r2_pos0(NP)) + wib * TPW * XT_F2_CHUNK * (D + KS);  // [TPW][CHUNK][D]
+    double* pos = (double*)(lds + xt_r2_pos0(NPT)) + wib * TPW * XT_F2_CHUNK * (D + KS);  // [TPW][CHUNK][D]
     double* sig = pos + TPW * XT_F2_CHUNK * D;                                           // [TPW][CHUNK][KS]
     // per (wave, track slot): NP == 0 {mantissa, exponent, count} of the running likelihood product; NP > 0 {sum LL, sum dLL_p}
-    double* accp = (double*)(lds + xt_r2_acc0(NP, D, KS, TPW)) + (wib * 8 + ts) * (NP + 3);
+    double* accp = (double*)(lds + xt_r2_acc0(NPT, D, KS, TPW)) + (wib * 8 + ts) * (NPT + 3);
     if (leader) {
         if (NP == 0) {
             accp[0] = 1.0;
             accp[1] = 0.0;
             accp[2] = 0.0;
         } else {
-            for (int i = 0; i < NP + 1; ++i) accp[i] = 0.0;
+            for (int i = 0; i < NPT + 1; ++i) accp[i] = 0.0;
         }
     }
 
@@ -473,6 +479,7 @@ XT_HD void xt_r2_body(const XtKernelArgs& a, const XtGradArgs& ga, Ctx& cx)
         XtAcc tot;
         tot.clear();
         double gacc[NP ? NP : 1];  // sum over this lane's (Q, q) pairs of w * d log w, on the 2^fe scale
+        double uacc[XT_R2_MAXU];   // the same for the uniform directions (d log w = the direction's constant + d log of the last factor)
         int fe = XT_EMIN;
         int t = 1;
         if (lane < 8) xt_at<int>(lds, XT_F2_NAN_OFF + (wib * 8 + lane) * 4) = 0;
@@ -606,6 +613,16 @@ XT_HD void xt_r2_body(const XtKernelArgs& a, const XtGradArgs& ga, Ctx& cx)
                     }
                     gacc[pp] = acc;
                 }
+                XT_UNROLL
+                for (int u = 0; u < XT_R2_MAXU; ++u) {  // uniform directions: sum over the pairs of w * d log(last factor)
+                    double acc = 0.0;
+                    if (u < NU) {
+                        const int tb = XT_R2_TAN0 + (NP + u) * XT_R2_TB * 8;
+                        XT_UNROLL
+                        for (int i = 0; i < 4; ++i) acc = xt_fma(ws[i], xt_at<double>(lds, tb + XT_R2_TAB0 + vfin * 32 + (prev * 2 + (i & 1)) * 8), acc);
+                    }
+                    uacc[u] = acc;
+                }
             }
         }
         // reduce over the track's lanes (every lane ends with the same values)
@@ -627,12 +644,25 @@ XT_HD void xt_r2_body(const XtKernelArgs& a, const XtGradArgs& ga, Ctx& cx)
             double gsum[NP ? NP : 1];
             XT_UNROLL
             for (int pp = 0; pp < NP; ++pp) gsum[pp] = xt_r2_gsum<F>(cx, gacc[pp]);
+            double usum[XT_R2_MAXU];
+            XT_UNROLL
+            for (int u = 0; u < XT_R2_MAXU; ++u) usum[u] = u < NU ? xt_r2_gsum<F>(cx, uacc[u]) : 0.0;
             if (act && leader) {
                 const double ll = log(sum) + (double)fe * XT_LN2 + b.ll_const;
                 if (b.ll_out) b.ll_out[trk] = ll;
                 accp[0] += ll;
                 XT_UNROLL
                 for (int pp = 0; pp < NP; ++pp) accp[1 + pp] += gsum[pp] * rs;
+                // uniform directions: d log of the initial fraction + one constant per step (without / with the stay-in-FOV factor)
+                const int nsteps = L - 2 > 0 ? L - 2 : 0;
+                const int n1 = nsteps >= stay_from ? nsteps - stay_from + 1 : 0, n0 = nsteps - n1;
+                XT_UNROLL
+                for (int u = 0; u < XT_R2_MAXU; ++u)
+                    if (u < NU) {
+                        const int tb = XT_R2_TAN0 + (NP + u) * XT_R2_TB * 8;
+                        const double rzu = xt_at<double>(lds, tb + 8 * 8) + n0 * xt_at<double>(lds, tb + XT_R2_TAB0) + n1 * xt_at<double>(lds, tb + XT_R2_TAB0 + 32);
+                        accp[1 + NP + u] += usum[u] * rs + rzu;
+                    }
             }
         }
         cx.wave_sync();
@@ -649,12 +679,12 @@ XT_HD void xt_r2_body(const XtKernelArgs& a, const XtGradArgs& ga, Ctx& cx)
             a.partials[cx.block()] = sacc;
         }
     } else {
-        const double* acc0 = (const double*)(lds + xt_r2_acc0(NP, D, KS, TPW));
-        for (int col = cx.tid(); col < NP + 1; col += cx.nthreads()) {
+        const double* acc0 = (const double*)(lds + xt_r2_acc0(NPT, D, KS, TPW));
+        for (int col = cx.tid(); col < NPT + 1; col += cx.nthreads()) {
             double sacc = 0.0;
             for (int w = 0; w < nwb; ++w)
-                for (int i = 0; i < TPW; ++i) sacc += acc0[(w * 8 + i) * (NP + 3) + col];
-            ga.gpartials[(int64_t)cx.block() * (NP + 1) + col] = sacc;
+                for (int i = 0; i < TPW; ++i) sacc += acc0[(w * 8 + i) * (NPT + 3) + col];
+            ga.gpartials[(int64_t)cx.block() * (NPT + 1) + col] = sacc;
         }
     }
 }

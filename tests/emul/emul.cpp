@@ -725,17 +725,31 @@ extern "C" int xt_emul_grad(const double* tracks, const double* sigma, long long
             if (!emul_r2(F, D, K, 0, 0, l.a, l.ga, nblocks)) return -3;
             for (int b = 0; b < nblocks; ++b) out[0] += part[b];
         }
-        for (int p0 = 0; p0 < n_dir;) {  // passes of 3 or 8 directions (what emul_r2.cpp instantiates), padded with zero directions
-            const int NPp = n_dir - p0 > 3 ? 8 : 3, real = std::min(NPp, n_dir - p0);
-            std::vector<double> gp2((size_t)nblocks * (NPp + 1), 0.0), pad((size_t)NPp * TB, 0.0);
-            memcpy(pad.data(), dblob.data() + (size_t)p0 * TB, (size_t)real * TB * sizeof(double));
+        // like the product's launcher (extrack_grad.hip): uniform directions (xt_r2_uniform_direction) ride along with the first pass
+        std::vector<int> full, uni;
+        for (int i = 0; i < n_dir; ++i)
+            ((int)uni.size() < XT_R2_MAXU && xt_r2_uniform_direction(dblob.data() + (size_t)i * TB) ? uni : full).push_back(i);
+        if (full.empty() && !uni.empty()) {
+            full.push_back(uni.back());
+            uni.pop_back();
+        }
+        std::vector<double> ublob(std::max<size_t>(1, uni.size()) * TB, 0.0);
+        for (size_t i = 0; i < uni.size(); ++i) memcpy(ublob.data() + i * TB, dblob.data() + (size_t)uni[i] * TB, TB * sizeof(double));
+        const int NF = (int)full.size();
+        for (int p0 = 0; p0 < NF;) {  // passes of 3 or 8 directions (what emul_r2.cpp instantiates), padded with zero directions
+            const int NPp = NF - p0 > 3 ? 8 : 3, real = std::min(NPp, NF - p0), NU = p0 == 0 ? (int)uni.size() : 0, NPT = NPp + NU;
+            std::vector<double> gp2((size_t)nblocks * (NPT + 1), 0.0), pad((size_t)NPp * TB, 0.0);
+            for (int i = 0; i < real; ++i) memcpy(pad.data() + (size_t)i * TB, dblob.data() + (size_t)full[p0 + i] * TB, (size_t)TB * sizeof(double));
             l.ga.dblob = pad.data();
+            l.ga.udblob = ublob.data();
+            l.ga.NU = NU;
             l.ga.gpartials = gp2.data();
             l.ga.NP = NPp;
             if (!emul_r2(F, D, K, 0, NPp, l.a, l.ga, nblocks)) return -3;
             for (int b = 0; b < nblocks; ++b) {
-                if (p0 == 0) out[0] += gp2[(size_t)b * (NPp + 1)];
-                for (int c = 0; c < real; ++c) out[1 + p0 + c] += gp2[(size_t)b * (NPp + 1) + 1 + c];
+                if (p0 == 0) out[0] += gp2[(size_t)b * (NPT + 1)];
+                for (int c = 0; c < real; ++c) out[1 + full[p0 + c]] += gp2[(size_t)b * (NPT + 1) + 1 + c];
+                for (int c = 0; c < NU; ++c) out[1 + uni[c]] += gp2[(size_t)b * (NPT + 1) + 1 + NPp + c];
             }
             p0 += real;
         }

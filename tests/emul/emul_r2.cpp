@@ -31,7 +31,7 @@ static bool emul_r2_dk(int D, int K, int NP, const XtKernelArgs& a, const XtGrad
 }
 bool emul_r2(int F, int D, int K, int KS, int NP, const XtKernelArgs& a, const XtGradArgs& ga, int nblocks)
 {
-    const size_t lds = (size_t)xt_r2_block_bytes(NP, D, KS, 64 >> (F - 1));
+    const size_t lds = (size_t)xt_r2_block_bytes(NP + (NP ? ga.NU : 0), D, KS, 64 >> (F - 1));
     if (F == 4) return emul_r2_dk<4>(D, K, NP, a, ga, nblocks, lds);
     if (F == 5) return emul_r2_dk<5>(D, K, NP, a, ga, nblocks, lds);
     if (F == 6) return emul_r2_dk<6>(D, K, NP, a, ga, nblocks, lds);
