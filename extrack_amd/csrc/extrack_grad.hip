@@ -5,6 +5,7 @@
 #include "xt_grad.h"
 #include "xt_grad_host.h"
 #include "xt_reg2.h"
+#include "xt_gradr.h"
 
 // Waves per SIMD the register allocator is asked to allow.  Measured on C2 (1e6 x 30, 7 directions, PJ = 4): 2 -> 63 ms,
 // 3 -> 53 ms (168 VGPRs, 108 B of scratch per lane), 4 -> 60 ms (128 VGPRs, 272 B of scratch).  Three members per group (C3, 13 directions): 3 waves (232 B of
@@ -310,6 +311,80 @@ static int xt_grad_enqueue(extrack_ctx* ctx, const extrack_model* m, int32_t n_d
             }
             doff += g.size();
             continue;
+        }
+        // ---- 2 - 4 members per group, <= 256 groups per track: state and tangents in registers, LDS as the exchange medium (xt_gradr.h)
+        // Used where the LDS-resident kernel below degrades - when a track's tangent planes no longer fit next to other tracks (>= 64 groups per
+        // track, e.g. 3 states at frame_len >= 5): measured on C3 (13 directions) frame_len 6: 788 ms against 1 960 ms; frame_len 4: 84 ms against
+        // 79 ms (there the barrier per exchange round costs what the LDS traffic saves).  EXTRACK_GRADR_NPC forces it for every model it serves.
+        if (ctx->grad_reg2 && n_dir > 0 && c.G >= 2 && c.G <= 4 && c.NG <= 256 && (c.NG >= 64 || ctx->gradr_npc) && xt_gradr_kernel_ptr(c.G, D, K, 4) != nullptr) {
+            const int tpb = std::max(1, 256 / c.NG), threads = (tpb * c.NG + 63) / 64 * 64;
+            int NPC = ctx->gradr_npc ? ctx->gradr_npc : (n_dir <= 4 ? 4 : 6);
+            const int npass = (n_dir + NPC - 1) / NPC, per = (n_dir + npass - 1) / npass;
+            if (per <= 4) NPC = 4;
+            const void* kp = xt_gradr_kernel_ptr(c.G, D, K, NPC);
+            const size_t lds = xt_gradr_lds_bytes(c.S, c.G, c.E, c.EP, c.NG, c.P, D, K, per, tpb);
+            if (kp && lds <= 160 * 1024) {
+                if (lds > 64 * 1024) XT_HIP(ctx, hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                auto key = std::make_pair(kp, std::make_pair(threads, lds));
+                auto it = ctx->occ_cache.find(key);
+                if (it == ctx->occ_cache.end()) {
+                    int o = 0;
+                    XT_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, kp, threads, lds));
+                    it = ctx->occ_cache.emplace(key, o < 1 ? 1 : o).first;
+                }
+                const int occ = it->second;
+                for (int p0 = 0; p0 < n_dir; p0 += per) {
+                    const int NP = std::min(per, n_dir - p0);
+                    XtKernelArgs a;
+                    memset(&a, 0, sizeof(a));
+                    xt_fill_args_from_config(c, a);
+                    XtGradArgs ga;
+                    memset(&ga, 0, sizeof(ga));
+                    const double target = (double)occ * ctx->n_cu * 4;
+                    double wsum = 0.0;
+                    std::vector<int64_t> nbatch(descs.size());
+                    for (size_t i = 0; i < descs.size(); ++i) {
+                        nbatch[i] = (descs[i].N + tpb - 1) / tpb;
+                        wsum += (double)nbatch[i] * (descs[i].L - 1);
+                    }
+                    int64_t acc = 0;
+                    for (size_t i = 0; i < descs.size(); ++i) {
+                        int64_t n = (int64_t)ceil(target * ((double)nbatch[i] * (descs[i].L - 1)) / wsum);
+                        n = n < 1 ? 1 : (n > nbatch[i] ? nbatch[i] : n);
+                        acc += n;
+                        a.blk_end[i] = (int32_t)acc;
+                    }
+                    const int grid = (int)acc;
+                    if (poff + (size_t)grid * (NP + 1) > ctx->gpartials_cap) return xt_fail(ctx, EXTRACK_E_HIP, "gradient partial-sum buffer too small");
+                    a.desc = ctx->d_desc + doff;
+                    a.ndesc = (int32_t)descs.size();
+                    a.blob = ctx->d_blob;
+                    a.base_tab = ctx->d_base_tab;
+                    a.off_tab = ctx->d_off_tab;
+                    a.TPB = tpb;
+                    a.min_len = m->min_len;
+                    a.locerr_mode = m->locerr_mode;
+                    a.KS = b0.KS ? b0.KS : 1;
+                    ga.dblob = ctx->d_dblob + (size_t)p0 * TB;
+                    ga.gpartials = ctx->d_gpartials + poff;
+                    ga.NP = NP;
+                    ga.TB = TB;
+                    void* kargs[2] = {(void*)&a, (void*)&ga};
+                    XT_HIP(ctx, hipLaunchKernel(kp, dim3(grid), dim3(threads), kargs, lds, ctx->stream));
+                    hipLaunchKernelGGL(xt_grad_reduce, dim3(NP + 1), dim3(256), 0, ctx->stream, ctx->d_gpartials + poff, grid, NP + 1,
+                                       p0 == 0 ? d_out : nullptr, d_out + 1, xt_grad_dst_identity(p0));
+                    XT_HIP(ctx, hipGetLastError());
+                    poff += (size_t)grid * (NP + 1);
+                    ctx->launch_info[0] = grid;
+                    ctx->launch_info[1] = threads;
+                    ctx->launch_info[2] = (int32_t)lds;
+                    ctx->launch_info[3] = tpb;
+                    ctx->launch_info[4] = occ;
+                    ctx->launch_info[5] = ctx->n_cu;
+                }
+                doff += g.size();
+                continue;
+            }
         }
         for (int p0 = 0; p0 < std::max(n_dir, 1); p0 += npass_dir) {
             const int NP = n_dir == 0 ? 0 : std::min(npass_dir, n_dir - p0);

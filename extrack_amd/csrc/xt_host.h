@@ -187,7 +187,8 @@ struct extrack_ctx {
     int n_cu = 0;
     int oversub = 8;  // block generations per CU (EXTRACK_OVERSUB overrides; tuning knob)
     int ll_reg2 = 1;  // 2-state likelihood: 1 = register-resident kernel (xt_reg2.h), 0 = LDS-resident (xt_fast2.h); EXTRACK_LL_PATH=reg2|lds
-    int grad_reg2 = 1;  // 2-state gradient: register-resident kernel where built (EXTRACK_GRAD_PATH=reg2|lds)
+    int grad_reg2 = 1;  // gradient: register-resident kernels where built (xt_reg2.h, xt_gradr.h); EXTRACK_GRAD_PATH=reg2|lds
+    int gradr_npc = 0;  // directions per pass of the xt_gradr.h kernels (0: chosen by the launcher; EXTRACK_GRADR_NPC = 4 | 6)
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     std::vector<XtBucket> buckets;
@@ -305,3 +306,4 @@ size_t xt_desc_base(const extrack_ctx* ctx);
 size_t xt_max_grid(const extrack_ctx* ctx);
 __global__ void xt_reduce_partials(const double* __restrict__ partials, int n, double* __restrict__ out);
 const void* xt_r2_kernel(int F, int D, int K, int NP);  // extrack_reg2.hip: register-resident 2-state kernels, nullptr = not built
+const void* xt_gradr_kernel_ptr(int G, int D, int K, int NPC);  // extrack_gradr.hip: register-resident gradient kernels (xt_gradr.h), NPC = 4 | 6

@@ -25,6 +25,8 @@
 #define XT_UNROLL
 #endif
 
+#define XT_INL __attribute__((always_inline))  // lambdas of a kernel body: a closure that is not inlined lives in scratch memory
+
 #define XT_EMIN (-(1 << 30))          // exponent of an exactly-zero weight
 #define XT_LN2 0.693147180559945309417232121458
 #define XT_LOG2PI 1.83787706640934548356065947281
@@ -63,6 +65,15 @@ XT_HD double xt_rint(double x) { return nearbyint(x); }
 #endif
 
 XT_HD double xt_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
+// Keeps the instruction scheduler from interleaving the code before and after this point (independent per-direction blocks scheduled
+// into each other multiply the live temporaries and spill).
+XT_HD void xt_sched_fence()
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+}
 
 // Round-to-nearest-integer of |v| < 2^31 by the magic-number add: the integer lands in the low 32 bits of the double,
 // so the int conversion is free and the fp64 rounding instruction is saved (v_rndne_f64 + v_cvt_i32_f64 -> one add).

@@ -27,14 +27,6 @@
 #include "xt_fast2.h"
 #include "xt_grad.h"
 
-#define XT_INL __attribute__((always_inline))  // lambdas of the body: a closure that is not inlined lives in scratch memory
-
-XT_HD void xt_sched_fence()
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    __builtin_amdgcn_sched_barrier(0);
-#endif
-}
 
 template <int F>
 struct XtR2Geom {

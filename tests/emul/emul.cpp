@@ -18,6 +18,7 @@
 #include "../../extrack_amd/csrc/xt_hist.h"
 #include "../../extrack_amd/csrc/xt_hist_host.h"
 #include "../../extrack_amd/csrc/xt_reg2.h"
+#include "../../extrack_amd/csrc/xt_gradr.h"
 #include "../../extrack_amd/csrc/xt_tables.h"
 #include "../../extrack_amd/csrc/xt_th.h"
 
@@ -106,6 +107,7 @@ struct EmulLauncher {
 };
 
 bool emul_r2(int F, int D, int K, int KS, int NP, const XtKernelArgs& a, const XtGradArgs& ga, int nblocks);  // emul_r2.cpp
+bool emul_gradr(int G, int D, int K, int NPC, const XtKernelArgs& a, const XtGradArgs& ga, int nblocks, int threads, size_t lds_doubles);  // emul_gradr.cpp
 
 extern "C" int xt_emul_run(const double* tracks, const double* sigma, long long N, int L, int D, int KS, int S, int NS, int F,
                            int isBL, int min_len, int locerr_mode, int locerr_dims, const double* locerr, double slope,
@@ -710,6 +712,26 @@ extern "C" int xt_emul_grad(const double* tracks, const double* sigma, long long
     if (tan_lds) d += (size_t)((n_dir * TB + 1) & ~1);
     d += (size_t)tpb * ((size_t)xt_grad_region_doubles(cfg.EP, D, K, n_dir) + xt_grad_acc_doubles(n_dir, cfg.NG) + xt_stage_doubles(D));
     l.lds_doubles = d;
+    if (generic_g == 3 || generic_g == 4) {  // xt_gradr.h: state and tangents in registers, LDS exchange; generic_g - 3 selects 4 / 6 directions per pass
+        if (cfg.G < 2 || cfg.G > 4 || cfg.NG > 256) return -5;
+        const int NPC = generic_g == 3 ? 4 : 6;
+        const int tpbr = std::max(1, 256 / cfg.NG), thr = (tpbr * cfg.NG + 63) / 64 * 64;
+        l.a.TPB = tpbr;
+        for (int p0 = 0; p0 < n_dir; p0 += NPC) {
+            const int NPp = std::min(NPC, n_dir - p0);
+            std::vector<double> gp2((size_t)nblocks * (NPp + 1), 0.0);
+            l.ga.dblob = dblob.data() + (size_t)p0 * TB;
+            l.ga.gpartials = gp2.data();
+            l.ga.NP = NPp;
+            const size_t ldsd = xt_gradr_lds_bytes(S, cfg.G, cfg.E, cfg.EP, cfg.NG, cfg.P, D, K, NPp, tpbr) / 8;
+            if (!emul_gradr(cfg.G, D, K, NPC, l.a, l.ga, nblocks, thr, ldsd)) return -3;
+            for (int b = 0; b < nblocks; ++b) {
+                if (p0 == 0) out[0] += gp2[(size_t)b * (NPp + 1)];
+                for (int c = 0; c < NPp; ++c) out[1 + p0 + c] += gp2[(size_t)b * (NPp + 1) + 1 + c];
+            }
+        }
+        return 0;
+    }
     if (generic_g == 2) {  // register-resident 2-state path, passes of <= 8 directions
         if (!xt_use_reg2(S, NS, F) || locerr_mode != 0) return -5;
         double lo = INFINITY, hi = -INFINITY;
