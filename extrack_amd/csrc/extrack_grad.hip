@@ -220,7 +220,7 @@ static int xt_grad_enqueue(extrack_ctx* ctx, const extrack_model* m, int32_t n_d
         XT_HIP(ctx, hipMemcpyAsync(ctx->d_desc + doff, ctx->h_desc + doff, descs.size() * sizeof(XtBucketDesc), hipMemcpyHostToDevice, ctx->stream));
         XT_HIP(ctx, hipEventRecord(ctx->ev_blob[(ctx->blob_turn - 1u) & 1u], ctx->stream));
         // ---- two-state models: register-resident kernels (xt_reg2.h), <= 8 directions per pass, tangents in VGPRs
-        const bool r2 = ctx->grad_reg2 && xt_use_reg2(c.S, c.NS, c.F) && m->locerr_mode == 0 && n_dir > 0 && xt_r2_kernel(c.F, D, K, 1) != nullptr;
+        const bool r2 = ctx->grad_reg2 == 1 && xt_use_reg2(c.S, c.NS, c.F) && m->locerr_mode == 0 && n_dir > 0 && xt_r2_kernel(c.F, D, K, 1) != nullptr;
         if (r2) {
             const int tpw = 64 >> (c.F - 1), tpb = tpw * XT_F2_WAVES, threads = 64 * XT_F2_WAVES;
             // "uniform" directions (xt_r2_uniform_direction, e.g. pBL) cost no per-step work: they ride along with the first pass

@@ -187,7 +187,8 @@ struct extrack_ctx {
     int n_cu = 0;
     int oversub = 8;  // block generations per CU (EXTRACK_OVERSUB overrides; tuning knob)
     int ll_reg2 = 1;  // 2-state likelihood: 1 = register-resident kernel (xt_reg2.h), 0 = LDS-resident (xt_fast2.h); EXTRACK_LL_PATH=reg2|lds
-    int grad_reg2 = 1;  // gradient: register-resident kernels where built (xt_reg2.h, xt_gradr.h); EXTRACK_GRAD_PATH=reg2|lds
+    int grad_reg2 = 1;  // gradient kernels: 1 = register-resident where built (xt_reg2.h for 2 states, else xt_gradr.h), 0 = the LDS-resident xt_grad.h
+                        // only, 2 = xt_gradr.h before xt_reg2.h (tests); EXTRACK_GRAD_PATH = reg2 | lds | gradr
     int gradr_npc = 0;  // directions per pass of the xt_gradr.h kernels (0: chosen by the launcher; EXTRACK_GRADR_NPC = 4 | 6)
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
