@@ -318,7 +318,9 @@ static int xt_grad_enqueue(extrack_ctx* ctx, const extrack_model* m, int32_t n_d
         // 79 ms (there the barrier per exchange round costs what the LDS traffic saves).  EXTRACK_GRADR_NPC forces it for every model it serves.
         if (ctx->grad_reg2 && n_dir > 0 && c.G >= 2 && c.G <= 4 && c.NG <= 256 && (c.NG >= 64 || ctx->gradr_npc) && xt_gradr_kernel_ptr(c.G, D, K, 4) != nullptr) {
             const int tpb = std::max(1, 256 / c.NG), threads = (tpb * c.NG + 63) / 64 * 64;
-            int NPC = ctx->gradr_npc ? ctx->gradr_npc : (n_dir <= 4 ? 4 : 6);
+            // 4 directions per pass: with 6 the register allocator spills inside the step loop (3 states: 917 GB of scratch traffic per C3
+            // launch, r03 PMC) and the pass count saved does not pay for it (1 124 ms against 788 ms)
+            int NPC = ctx->gradr_npc ? ctx->gradr_npc : 4;
             const int npass = (n_dir + NPC - 1) / NPC, per = (n_dir + npass - 1) / npass;
             if (per <= 4) NPC = 4;
             const void* kp = xt_gradr_kernel_ptr(c.G, D, K, NPC);
