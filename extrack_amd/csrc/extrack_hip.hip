@@ -1569,7 +1569,7 @@ struct XtRefineArgs {
     const int32_t* past_cnt;
     double* mu_out;        // [N][L][D]
     double* sig_out;       // [N][L]
-    int64_t N;             // rows of this launch (the records are [L - 1][N][cap][2 + D])
+    int64_t N;             // rows of this launch (the records are [L - 1][cap][2 + D][N]: a wavefront reads 64 neighbouring tracks' values of a field)
     int32_t L, S, cap_f, cap_p;  // sequences recorded per (entry, track) by the two passes
     double l2;             // squared localisation error
     double logF[XT_MAX_STATES];
@@ -1604,49 +1604,55 @@ __global__ void __launch_bounds__(256) xt_refine_combine(XtRefineArgs a)
         for (int d = 0; d < D; ++d) smu[d] += p * mu[d];
         ssg += p * var;
     };
+    // record field f of sequence q of entry e of this thread's track: rec[((e * cap + q) * R + f) * N + x]
     if (k == 0 || k == L - 1) {
         // end positions: one pass only; the reference's last record already carries the density of this position (and the
         // initial fractions for position 0) through its in-place update (refined_localization.py:188-193), and get_pos_PDF adds the
         // overlap term once more
         const int cap = k == 0 ? a.cap_f : a.cap_p;
-        const double* rec = (k == 0 ? a.fut : a.past) + (((int64_t)(L - 2) * a.N + x) * cap) * R;
+        const double* rec = (k == 0 ? a.fut : a.past) + ((int64_t)(L - 2) * cap * R) * a.N + x;
         const uint8_t* nw = (k == 0 ? a.fut_new : a.past_new) + (int64_t)(L - 2) * cap;
         const int n = (k == 0 ? a.fut_cnt : a.past_cnt)[L - 2];
         for (int q = 0; q < n; ++q) {
-            const double lp = rec[q * R], sd = rec[q * R + 1 + D], v = sd * sd + a.l2;
+            const double* r = rec + (int64_t)q * R * a.N;
+            const double lp = r[0], sd = r[(int64_t)(1 + D) * a.N], v = sd * sd + a.l2;
             double dsq = 0.0, mu[D];
             for (int d = 0; d < D; ++d) {
-                dsq += (c[d] - rec[q * R + 1 + d]) * (c[d] - rec[q * R + 1 + d]);
-                mu[d] = (rec[q * R + 1 + d] * a.l2 + c[d] * sd * sd) / v;
+                const double m = r[(int64_t)(1 + d) * a.N];
+                dsq += (c[d] - m) * (c[d] - m);
+                mu[d] = (m * a.l2 + c[d] * sd * sd) / v;
             }
             const double lk = -0.5 * D * log(2.0 * M_PI * v) - dsq / (2.0 * v);
             add(lp + 2.0 * lk + (k == 0 ? a.logF[nw[q]] : 0.0), mu, a.l2 * sd * sd / v);
         }
     } else {
-        const double* rf = a.fut + (((int64_t)(L - 2 - k) * a.N + x) * a.cap_f) * R;
-        const double* rp = a.past + (((int64_t)(k - 1) * a.N + x) * a.cap_p) * R;
+        const double* rf = a.fut + ((int64_t)(L - 2 - k) * a.cap_f * R) * a.N + x;
+        const double* rp = a.past + ((int64_t)(k - 1) * a.cap_p * R) * a.N + x;
         const uint8_t* nf = a.fut_new + (int64_t)(L - 2 - k) * a.cap_f;
         const uint8_t* np_ = a.past_new + (int64_t)(k - 1) * a.cap_p;
         const int n1 = a.fut_cnt[L - 2 - k], n2 = a.past_cnt[k - 1];
         for (int q1 = 0; q1 < n1; ++q1) {
-            const double lp1 = rf[q1 * R], s1 = rf[q1 * R + 1 + D];
+            const double* r1 = rf + (int64_t)q1 * R * a.N;
+            const double lp1 = r1[0], s1 = r1[(int64_t)(1 + D) * a.N];
             const double v12 = s1 * s1 + a.l2, vA = s1 * s1 * a.l2 / v12;
             double muA[D], d1 = 0.0;
             for (int d = 0; d < D; ++d) {
-                const double m1 = rf[q1 * R + 1 + d];
+                const double m1 = r1[(int64_t)(1 + d) * a.N];
                 muA[d] = (m1 * a.l2 + c[d] * s1 * s1) / v12;
                 d1 += (m1 - c[d]) * (m1 - c[d]);
             }
             const double lk1 = -0.5 * D * log(2.0 * M_PI * v12) - d1 / (2.0 * v12);
             for (int q2 = 0; q2 < n2; ++q2) {
                 if (np_[q2] != nf[q1]) continue;  // pairs that agree on the state at this position
-                const double s3 = rp[q2 * R + 1 + D], v3 = vA + s3 * s3;
+                const double* r2 = rp + (int64_t)q2 * R * a.N;
+                const double s3 = r2[(int64_t)(1 + D) * a.N], v3 = vA + s3 * s3;
                 double d2 = 0.0, mu[D];
                 for (int d = 0; d < D; ++d) {
-                    d2 += (muA[d] - rp[q2 * R + 1 + d]) * (muA[d] - rp[q2 * R + 1 + d]);
-                    mu[d] = (muA[d] * s3 * s3 + rp[q2 * R + 1 + d] * vA) / v3;
+                    const double m3 = r2[(int64_t)(1 + d) * a.N];
+                    d2 += (muA[d] - m3) * (muA[d] - m3);
+                    mu[d] = (muA[d] * s3 * s3 + m3 * vA) / v3;
                 }
-                add(lp1 + rp[q2 * R] + lk1 - 0.5 * D * log(2.0 * M_PI * v3) - d2 / (2.0 * v3), mu, vA * s3 * s3 / v3);
+                add(lp1 + r2[0] + lk1 - 0.5 * D * log(2.0 * M_PI * v3) - d2 / (2.0 * v3), mu, vA * s3 * s3 / v3);
             }
         }
     }

@@ -131,11 +131,11 @@ struct XtThArgs {
     // (the whole bucket) records, after every position, each track's surviving sequences instead of reading out posteriors.
     int32_t refine;        // 1: record mode; every workgroup repeats the pilot pass (same plan) and serves its share of the other tracks
     int32_t rf_cap;        // sequences recorded per (entry, track)
-    double* rf_out;        // [L - 1][N][rf_cap][2 + D]: log-weight, mean[D], std   (nullptr: nothing is recorded - capacity probe)
+    double* rf_out;        // [L - 1][rf_cap][2 + D][rows]: log-weight, mean[D], std   (nullptr: nothing is recorded - capacity probe)
     uint8_t* rf_new;       // [L - 1][rf_cap] newest state of every recorded sequence (shared by the tracks)
     int32_t* rf_cnt;       // [L - 1] recorded sequences per entry
     int64_t rf_row0, rf_rows;  // this launch records the tracks [rf_row0, rf_row0 + rf_rows) of the bucket (row blocks bound the record memory);
-                               // rf_out is then [L - 1][rf_rows][rf_cap][2 + D], rows relative to rf_row0
+                               // rf_out is then [L - 1][rf_cap][2 + D][rf_rows], rows relative to rf_row0
 };
 
 // Pointer to read-only data that is addressed with wave-uniform indices: on the device it lives in the constant address
@@ -556,10 +556,11 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
 
         // refinement record of sequence q of entry `ent` (0 .. L-2) of chunk track xg: log-weight (constants dropped), mean, std
         auto rf_put = [&](int ent, int64_t xg, int q, double zm, int ze, const double* mv, double var0) {
-            double* o = a.rf_out + (((int64_t)ent * a.rf_rows + (xg - a.rf_row0)) * a.rf_cap + q) * (2 + D);
+            // layout [entry][sequence][field][track]: the combine kernel reads a field of one sequence for 64 neighbouring tracks at once
+            double* o = a.rf_out + (((int64_t)ent * a.rf_cap + q) * (2 + D)) * a.rf_rows + (xg - a.rf_row0);
             o[0] = zm > 0.0 ? log(zm) + (double)ze * XT_LN2 : -INFINITY;
-            for (int d = 0; d < D; ++d) o[1 + d] = mv[d];
-            o[1 + D] = sqrt(var0);
+            for (int d = 0; d < D; ++d) o[(int64_t)(1 + d) * a.rf_rows] = mv[d];
+            o[(int64_t)(1 + D) * a.rf_rows] = sqrt(var0);
         };
         auto load_l2 = [&](int x, int pos, double* l2) {
             if (a.locerr_mode == 0) {
