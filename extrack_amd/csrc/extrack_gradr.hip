@@ -22,17 +22,17 @@ static const void* gradr_dk(int D, int K)
     return nullptr;
 }
 
-// Kernel address for (members per group, dims, loc.-error dims, directions per pass: 4 or 6); nullptr: not built.
+// Kernel address for (members per group, dims, loc.-error dims, directions per pass: 3 or 4); nullptr: not built.
 const void* xt_gradr_kernel_ptr(int G, int D, int K, int NPC)
 {
     if (NPC == 4) {
         if (G == 2) return gradr_dk<2, 4>(D, K);
         if (G == 3) return gradr_dk<3, 4>(D, K);
         if (G == 4) return gradr_dk<4, 4>(D, K);
-    } else if (NPC == 6) {
-        if (G == 2) return gradr_dk<2, 6>(D, K);
-        if (G == 3) return gradr_dk<3, 6>(D, K);
-        if (G == 4) return gradr_dk<4, 6>(D, K);
+    } else if (NPC == 3) {
+        if (G == 2) return gradr_dk<2, 3>(D, K);
+        if (G == 3) return gradr_dk<3, 3>(D, K);
+        if (G == 4) return gradr_dk<4, 3>(D, K);
     }
     return nullptr;
 }

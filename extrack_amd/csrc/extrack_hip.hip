@@ -101,7 +101,7 @@ extern "C" int extrack_create(int device_id, extrack_ctx** out)
     }
     if (const char* ev = getenv("EXTRACK_LL_PATH")) c->ll_reg2 = strcmp(ev, "reg2") == 0 ? 1 : (strcmp(ev, "lds") == 0 ? 0 : c->ll_reg2);
     if (const char* ev = getenv("EXTRACK_GRAD_PATH")) c->grad_reg2 = strcmp(ev, "lds") == 0 ? 0 : (strcmp(ev, "gradr") == 0 ? 2 : 1);
-    if (const char* ev = getenv("EXTRACK_GRADR_NPC")) c->gradr_npc = atoi(ev) == 4 ? 4 : (atoi(ev) == 6 ? 6 : 0);
+    if (const char* ev = getenv("EXTRACK_GRADR_NPC")) c->gradr_npc = atoi(ev) == 4 ? 4 : (atoi(ev) == 3 ? 3 : 0);
     if (const char* ev = getenv("EXTRACK_TH_TT")) {
         int v = atoi(ev);
         if (v >= 1 && v <= 256 && (v & (v - 1)) == 0) c->th_force_tt = v;

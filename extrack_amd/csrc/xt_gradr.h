@@ -155,7 +155,8 @@ XT_HD void xt_gradr_body(const XtKernelArgs& a, const XtGradArgs& ga, Ctx& cx)
 
         stage(0);
         // ---- position 0: the members of the group of phase 0 (entry index il: the initial state in slot 0, everything else zero weight)
-        if (act) {
+        // (lanes without a track - the last, partial batch - walk track 0 of the bucket: uniform control flow in the step loop, no stores)
+        {
             double l20[K], sc0[K], sr0[K], c0[D];
             load_l2(0, l20, sc0, sr0);
             XT_UNROLL
@@ -183,7 +184,7 @@ XT_HD void xt_gradr_body(const XtKernelArgs& a, const XtGradArgs& ga, Ctx& cx)
                     for (int k = 0; k < K; ++k) tdu[p][Q][k] = p < NP ? dl2[k] : 0.0;
                 }
             }
-            if (g == 0) red_e[0] = XT_EMIN;
+            if (act && g == 0) red_e[0] = XT_EMIN;
         }
         cx.sync();
 
@@ -198,7 +199,7 @@ XT_HD void xt_gradr_body(const XtKernelArgs& a, const XtGradArgs& ga, Ctx& cx)
             bool liveW = false;
             const bool stay = t >= stay_from;
             const int tv = (stay ? 1 : 0) * SG + toff;
-            if (act) {
+            {
                 const int base = bt[ph * NG + g], baseN = bt[phn * NG + g];
                 XT_UNROLL
                 for (int q = 0; q < G; ++q) {
@@ -290,7 +291,7 @@ XT_HD void xt_gradr_body(const XtKernelArgs& a, const XtGradArgs& ga, Ctx& cx)
                 }
             }
             cx.sync();
-            if (act) {
+            {
                 const int* xz = XZ(0);
                 XT_UNROLL
                 for (int Q = 0; Q < G; ++Q) {
@@ -309,7 +310,7 @@ XT_HD void xt_gradr_body(const XtKernelArgs& a, const XtGradArgs& ga, Ctx& cx)
                 if (p >= NP) break;
                 xt_sched_fence();
                 double* xb = X[(1 + p) & 1];
-                if (act) {
+                {
                     const double* dtb = DT + p * TB;
                     double R = 0.0, dmb[D], dub[K];
                     XT_UNROLL
@@ -356,7 +357,7 @@ XT_HD void xt_gradr_body(const XtKernelArgs& a, const XtGradArgs& ga, Ctx& cx)
                     }
                 }
                 cx.sync();
-                if (act) {
+                {
                     XT_UNROLL
                     for (int Q = 0; Q < G; ++Q) {
                         trz[p][Q] = xb[ridx[Q]];

@@ -189,7 +189,7 @@ struct extrack_ctx {
     int ll_reg2 = 1;  // 2-state likelihood: 1 = register-resident kernel (xt_reg2.h), 0 = LDS-resident (xt_fast2.h); EXTRACK_LL_PATH=reg2|lds
     int grad_reg2 = 1;  // gradient kernels: 1 = register-resident where built (xt_reg2.h for 2 states, else xt_gradr.h), 0 = the LDS-resident xt_grad.h
                         // only, 2 = xt_gradr.h before xt_reg2.h (tests); EXTRACK_GRAD_PATH = reg2 | lds | gradr
-    int gradr_npc = 0;  // directions per pass of the xt_gradr.h kernels (0: chosen by the launcher; EXTRACK_GRADR_NPC = 4 | 6)
+    int gradr_npc = 0;  // directions per pass of the xt_gradr.h kernels (0: chosen by the launcher; EXTRACK_GRADR_NPC = 3 | 4 also forces these kernels for small models)
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     std::vector<XtBucket> buckets;
@@ -307,4 +307,4 @@ size_t xt_desc_base(const extrack_ctx* ctx);
 size_t xt_max_grid(const extrack_ctx* ctx);
 __global__ void xt_reduce_partials(const double* __restrict__ partials, int n, double* __restrict__ out);
 const void* xt_r2_kernel(int F, int D, int K, int NP);  // extrack_reg2.hip: register-resident 2-state kernels, nullptr = not built
-const void* xt_gradr_kernel_ptr(int G, int D, int K, int NPC);  // extrack_gradr.hip: register-resident gradient kernels (xt_gradr.h), NPC = 4 | 6
+const void* xt_gradr_kernel_ptr(int G, int D, int K, int NPC);  // extrack_gradr.hip: register-resident gradient kernels (xt_gradr.h), NPC = 3 | 4

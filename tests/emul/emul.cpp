@@ -712,9 +712,9 @@ extern "C" int xt_emul_grad(const double* tracks, const double* sigma, long long
     if (tan_lds) d += (size_t)((n_dir * TB + 1) & ~1);
     d += (size_t)tpb * ((size_t)xt_grad_region_doubles(cfg.EP, D, K, n_dir) + xt_grad_acc_doubles(n_dir, cfg.NG) + xt_stage_doubles(D));
     l.lds_doubles = d;
-    if (generic_g == 3 || generic_g == 4) {  // xt_gradr.h: state and tangents in registers, LDS exchange; generic_g - 3 selects 4 / 6 directions per pass
+    if (generic_g == 3 || generic_g == 4) {  // xt_gradr.h: state and tangents in registers, LDS exchange; generic_g = 3 / 4: that many directions per pass
         if (cfg.G < 2 || cfg.G > 4 || cfg.NG > 256) return -5;
-        const int NPC = generic_g == 3 ? 4 : 6;
+        const int NPC = generic_g;
         const int tpbr = std::max(1, 256 / cfg.NG), thr = (tpbr * cfg.NG + 63) / 64 * 64;
         l.a.TPB = tpbr;
         for (int p0 = 0; p0 < n_dir; p0 += NPC) {

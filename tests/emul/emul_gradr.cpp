@@ -17,17 +17,17 @@ static bool gradr_dk(int D, int K, const XtKernelArgs& a, const XtGradArgs& ga, 
     if (D == 3 && K == 3) return run_gradr<G_, 3, 3, NPC>(a, ga, nblocks, threads, ldsd), true;
     return false;
 }
-// NPC = 4 or 6 directions per pass (compile-time register arrays), G = 2, 3, 4 members per group
+// NPC = 3 or 4 directions per pass (compile-time register arrays), G = 2, 3, 4 members per group
 bool emul_gradr(int G, int D, int K, int NPC, const XtKernelArgs& a, const XtGradArgs& ga, int nblocks, int threads, size_t lds_doubles)
 {
     if (NPC == 4) {
         if (G == 2) return gradr_dk<2, 4>(D, K, a, ga, nblocks, threads, lds_doubles);
         if (G == 3) return gradr_dk<3, 4>(D, K, a, ga, nblocks, threads, lds_doubles);
         if (G == 4) return gradr_dk<4, 4>(D, K, a, ga, nblocks, threads, lds_doubles);
-    } else if (NPC == 6) {
-        if (G == 2) return gradr_dk<2, 6>(D, K, a, ga, nblocks, threads, lds_doubles);
-        if (G == 3) return gradr_dk<3, 6>(D, K, a, ga, nblocks, threads, lds_doubles);
-        if (G == 4) return gradr_dk<4, 6>(D, K, a, ga, nblocks, threads, lds_doubles);
+    } else if (NPC == 3) {
+        if (G == 2) return gradr_dk<2, 3>(D, K, a, ga, nblocks, threads, lds_doubles);
+        if (G == 3) return gradr_dk<3, 3>(D, K, a, ga, nblocks, threads, lds_doubles);
+        if (G == 4) return gradr_dk<4, 3>(D, K, a, ga, nblocks, threads, lds_doubles);
     }
     return false;
 }

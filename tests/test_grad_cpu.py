@@ -111,7 +111,7 @@ def test_emulated_register_resident_gradient_body(F, L, N, D, K, isBL):
 @pytest.mark.parametrize("S,ns,F,L,N,D,K,isBL,gg", [(3, 1, 3, 8, 6, 2, 1, 1, 3), (3, 1, 4, 9, 5, 2, 1, 0, 4), (2, 2, 3, 7, 6, 1, 1, 1, 4), (3, 1, 3, 8, 4, 2, 2, 1, 4),
                                                       (4, 1, 3, 7, 3, 3, 1, 1, 3), (3, 1, 3, 2, 4, 2, 1, 1, 3)])
 def test_emulated_register_resident_general_gradient_body(S, ns, F, L, N, D, K, isBL, gg):
-    """xt_gradr.h (2 - 4 members per group: state and tangents in registers, LDS exchange rounds; gg - 3 selects 4 / 6 directions per pass,
+    """xt_gradr.h (2 - 4 members per group: state and tangents in registers, LDS exchange rounds; gg = 3 / 4 directions per pass,
     17 - 26 directions: several passes) on CPU threads against Richardson differences of the pinned oracle."""
     import run_emul as E
     from extrack_amd import synth
