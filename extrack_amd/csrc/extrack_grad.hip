@@ -313,10 +313,9 @@ static int xt_grad_enqueue(extrack_ctx* ctx, const extrack_model* m, int32_t n_d
             continue;
         }
         // ---- 2 - 4 members per group, <= 256 groups per track: state and tangents in registers, LDS as the exchange medium (xt_gradr.h)
-        // Used where the LDS-resident kernel below degrades - when a track's tangent planes no longer fit next to other tracks (>= 64 groups per
-        // track, e.g. 3 states at frame_len >= 5): measured on C3 (13 directions) frame_len 6: 601 ms against 1 960 ms.  EXTRACK_GRADR_NPC forces
-        // it for every model it serves (frame_len 4: 63 ms against 79 ms - kept behind the threshold until more models are measured).
-        if (ctx->grad_reg2 && n_dir > 0 && c.G >= 2 && c.G <= 4 && c.NG <= 256 && (c.NG >= 64 || ctx->gradr_npc) && xt_gradr_kernel_ptr(c.G, D, K, 4) != nullptr) {
+        // Measured against the LDS-resident kernel below (r03): C3 (3 states, 13 directions) frame_len 6 601 ms vs 1 960 ms, frame_len 4 63 vs 79 ms;
+        // C2-type data through the general kernels (2 states, per-peak errors take this path) frame_len 6 43.8 vs 52.9 ms, frame_len 4 16.1 vs 16.4 ms.
+        if (ctx->grad_reg2 && n_dir > 0 && c.G >= 2 && c.G <= 4 && c.NG <= 256 && xt_gradr_kernel_ptr(c.G, D, K, 4) != nullptr) {
             const int tpb = std::max(1, 256 / c.NG), threads = (tpb * c.NG + 63) / 64 * 64;
             // 4 directions per pass: with 6 the register allocator spills inside the step loop (3 states: 917 GB of scratch traffic per C3
             // launch, r03 PMC) and the pass count saved does not pay for it; 3 per pass when that needs no more passes

@@ -24,7 +24,7 @@ def _params(vals):
 
 @pytest.mark.parametrize("gradr", [None, "4", "3"])
 def test_gradient_vs_oracle_central_differences_on_golden_models(kernel_cases, gradr, monkeypatch):
-    """gradr: None = the launcher's choice of kernel per model (xt_reg2.h for 2 states, xt_gradr.h from 64 groups per track, else xt_grad.h);
+    """gradr: None = the launcher's choice of kernel per model (xt_reg2.h for 2 states with a global error, xt_gradr.h up to 4 members per group and 256 groups per track, else xt_grad.h);
     "4" / "3" = the register-resident general kernels (xt_gradr.h) forced for every model they serve, 4 / 3 directions per pass.
     Golden kernel cases (reference-generated inputs: 2-4 states, nb_substeps 1-2, 1-3 dims, scalar / per-dim localisation error,
     isBL 0/1, tracks shorter and longer than the window): LL must equal the golden LP_C, the gradient along EVERY model direction
