@@ -37,9 +37,35 @@ try:
     p0 = T.generate_params(nb_states=2, LocErr_type=1, LocErr_bounds=[0.005, 0.1], D_max=3, estimated_Ds=[0.0001, 0.1], estimated_Fs=[0.5],
                            estimated_transition_rates=0.05)
     with contextlib.redirect_stdout(io.StringIO()):
-        fit_c = T.param_fitting(tr, 0.02, params=p0, nb_states=2, frame_len=4, verbose=0, method="bfgs", cell_dims=[1], comm=comm)
-        fit_s = T.param_fitting(tr, 0.02, params=p0, nb_states=2, frame_len=4, verbose=0, method="bfgs", cell_dims=[1])
+        # (gradient given explicitly: the default is decided by a timing probe, which two runs need not answer alike)
+        fit_c = T.param_fitting(tr, 0.02, params=p0, nb_states=2, frame_len=4, verbose=0, method="bfgs", cell_dims=[1], comm=comm, gradient="fd")
+        fit_s = T.param_fitting(tr, 0.02, params=p0, nb_states=2, frame_len=4, verbose=0, method="bfgs", cell_dims=[1], gradient="fd")
+        fit_ca = T.param_fitting(tr, 0.02, params=p0, nb_states=2, frame_len=4, verbose=0, method="bfgs", cell_dims=[1], comm=comm, gradient="analytic")
+        fit_sa = T.param_fitting(tr, 0.02, params=p0, nb_states=2, frame_len=4, verbose=0, method="bfgs", cell_dims=[1], gradient="analytic")
+        fit_d = T.param_fitting(tr, 0.02, params=p0, nb_states=2, frame_len=4, verbose=0, method="bfgs", cell_dims=[1], comm=comm)  # probe + collective agreement
     assert fit_c.nfev == fit_s.nfev and fit_c.residual[0] == fit_s.residual[0], (fit_c.nfev, fit_s.nfev, fit_c.residual, fit_s.residual)
+    # objective + gradient: the 1 + nvar doubles are written by the kernels into the buffer RCCL reduces (extrack_loglik_grad_async)
+    assert fit_ca.nfev == fit_sa.nfev and fit_ca.residual[0] == fit_sa.residual[0] and fit_ca.ngev > 0, (fit_ca.nfev, fit_sa.nfev)
+    assert abs(fit_d.residual[0] - fit_s.residual[0]) < 1e-6 * abs(fit_s.residual[0])
+    from extrack_amd import gradient
+    ts = comm.shard_trackset(lst)
+    names = gradient.free_names(p0)
+    v1, g1 = gradient.objective_and_gradient(p0, ts, 0.02, [1], 2, 1, 6, comm=comm, names=names)
+    v2, g2 = gradient.objective_and_gradient(p0, ts, 0.02, [1], 2, 1, 6, names=names)
+    assert v1 == v2 and np.array_equal(g1, g2), (v1, v2, g1, g2)
+    # a failure while enqueueing this rank's kernels travels through the collective as a flag and is raised after it; the next evaluation works
+    real = ts.ctx.loglik_async
+    def boom(*a_, **k_):
+        raise RuntimeError("injected enqueue failure")
+    ts.ctx.loglik_async = boom
+    try:
+        T.cum_Proba_Cs(p, ts, 0.02, [1], None, 2, 1, 6, verbose=0, comm=comm)
+        raise SystemExit("the injected failure was swallowed")
+    except RuntimeError as e:
+        assert "injected" in str(e)
+    ts.ctx.loglik_async = real
+    assert T.cum_Proba_Cs(p, ts, 0.02, [1], None, 2, 1, 6, verbose=0, comm=comm) == b
+    ts.close()
     # threshold-fusion objective through the communicator: chunk-aligned shards, same value as the single-GPU call
     ts = comm.shard_trackset(lst, chunk=2000)
     a_th = T.cum_Proba_Cs(p, ts, 0.02, [1], None, 2, 1, 6, verbose=0, comm=comm, fusion="threshold")

@@ -211,7 +211,7 @@ def test_full_size_properties():
 def test_rccl_single_rank_allreduce_path():
     """The multi-GPU code path (kernels and the RCCL all-reduce enqueued on one stream, scalar left in device memory)
     exercised with a 1-rank nccl group - all this box has.  Runs in a subprocess with a hard timeout: an RCCL bootstrap
-    that stalls on the host's network configuration must not hang the suite (it is then reported as skipped)."""
+    that stalls on the host's network configuration must not hang the suite (reported as a FAILURE)."""
     import os
     import subprocess
     import sys
@@ -221,7 +221,11 @@ def test_rccl_single_rank_allreduce_path():
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "rccl_single_rank_check.py")], env=env, capture_output=True,
                            text=True, timeout=240)
     except subprocess.TimeoutExpired:
-        pytest.skip("RCCL bootstrap did not complete within 240 s on this host")
+        # the only nccl-backend coverage of the suite: a stall is a failure to look at, not a skip (set EXTRACK_ALLOW_RCCL_SKIP=1 on a host
+        # whose network configuration is known to stall the bootstrap)
+        if os.environ.get("EXTRACK_ALLOW_RCCL_SKIP") == "1":
+            pytest.skip("RCCL bootstrap did not complete within 240 s on this host")
+        pytest.fail("RCCL bootstrap / single-rank communicator check did not complete within 240 s")
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "RCCL_PATH_OK" in r.stdout
 
