@@ -200,8 +200,6 @@ static int xt_grad_enqueue(extrack_ctx* ctx, const extrack_model* m, int32_t n_d
         // directions per pass: as many as keep one track's state within the LDS of a CU (all of them for the usual models)
         int npass_dir = std::max(n_dir, 1);
         while (npass_dir > 1 && (npass_dir > 16 || xt_grad_lds_bytes(c, D, K, npass_dir, 1, false) > 150 * 1024)) npass_dir = (npass_dir + 1) / 2;
-        if (xt_grad_lds_bytes(c, D, K, std::min(npass_dir, std::max(n_dir, 0)), 1, false) > 160 * 1024)
-            return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "sequence state with one tangent direction does not fit the 160 KiB LDS of a CU");
         // bucket descriptors of this group (shared by its passes)
         std::vector<XtBucketDesc> descs;
         for (XtBucket* b : g) {
@@ -387,6 +385,9 @@ static int xt_grad_enqueue(extrack_ctx* ctx, const extrack_model* m, int32_t n_d
                 continue;
             }
         }
+        // ---- everything else: the LDS-resident kernel (xt_grad.h)
+        if (xt_grad_lds_bytes(c, D, K, std::min(npass_dir, std::max(n_dir, 0)), 1, false) > 160 * 1024)
+            return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "sequence state with one tangent direction does not fit the 160 KiB LDS of a CU");
         for (int p0 = 0; p0 < std::max(n_dir, 1); p0 += npass_dir) {
             const int NP = n_dir == 0 ? 0 : std::min(npass_dir, n_dir - p0);
             GradLauncher l;
