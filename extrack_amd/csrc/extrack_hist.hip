@@ -4,8 +4,8 @@
 #include "xt_hist.h"
 #include "xt_hist_host.h"
 
-template <int D, int K>
-__global__ void __launch_bounds__(256) xt_hist_kernel(XtHistArgs a)
+template <int D, int K, int MAXT>
+__global__ void __launch_bounds__(MAXT) xt_hist_kernel(XtHistArgs a)
 {
     DevCtx cx;
     xt_hist_body<D, K>(a, cx);
@@ -22,14 +22,16 @@ __global__ void __launch_bounds__(256) xt_hist_reduce(const double* __restrict__
 }
 
 template <int D, int K>
-static hipError_t xt_hist_launch(extrack_ctx* ctx, const XtHistArgs& a, int grid, size_t lds)
+static hipError_t xt_hist_launch(extrack_ctx* ctx, const XtHistArgs& a, int grid, size_t lds, int threads)
 {
+    const void* kp = threads > 256 ? (const void*)xt_hist_kernel<D, K, 512> : (const void*)xt_hist_kernel<D, K, 256>;
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)xt_hist_kernel<D, K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((xt_hist_kernel<D, K>), dim3(grid), dim3(256), lds, ctx->stream, a);
-    return hipGetLastError();
+    void* kargs[1] = {(void*)&a};
+    hipError_t e = hipLaunchKernel(kp, dim3(grid), dim3(threads), kargs, lds, ctx->stream);
+    return e != hipSuccess ? e : hipGetLastError();
 }
 
 extern "C" int extrack_segment_len_hist(extrack_ctx* ctx, const extrack_model* m, int32_t bucket_id, int32_t max_nb_states, double* hist)
@@ -79,9 +81,13 @@ extern "C" int extrack_segment_len_hist(extrack_ctx* ctx, const extrack_model* m
     a.isBL = (L != m->max_len) ? 1 : 0;
     a.min_l = m->min_len;
     const int KSl = m->locerr_mode ? a.KS : 0;
-    size_t lds = xt_hist_lds_doubles(S, L, D, K, KSl, a.PC, a.NC, a.HW, 256, true) * sizeof(double);
+    // workgroup size 256; 512 threads (2 candidates per thread at max_nb_states 500) were measured SLOWER: 104 vs 79 ms per 1e5 x 30 - twice the
+    // stages cross wavefronts (LDS + barrier) and a CU holds the same two tracks (EXTRACK_HIST_THREADS=512 keeps the variant reachable)
+    int threads = 256;
+    if (const char* ev = getenv("EXTRACK_HIST_THREADS")) threads = atoi(ev) == 512 ? 512 : 256;
+    size_t lds = xt_hist_lds_doubles(S, L, D, K, KSl, a.PC, a.NC, a.HW, threads, true) * sizeof(double);
     a.par_lds = lds <= 150 * 1024 ? 1 : 0;
-    if (!a.par_lds) lds = xt_hist_lds_doubles(S, L, D, K, KSl, a.PC, a.NC, a.HW, 256, false) * sizeof(double);
+    if (!a.par_lds) lds = xt_hist_lds_doubles(S, L, D, K, KSl, a.PC, a.NC, a.HW, threads, false) * sizeof(double);
     if (lds > 160 * 1024) return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "candidate arrays do not fit the 160 KiB LDS of a CU: lower max_nb_states");
     const int per_cu = std::max(1, std::min(8, (int)((160 * 1024) / lds)));
     const int grid = (int)std::min<int64_t>(b.N, (int64_t)ctx->n_cu * per_cu * 2);
@@ -103,11 +109,11 @@ extern "C" int extrack_segment_len_hist(extrack_ctx* ctx, const extrack_model* m
     a.partials = ctx->d_partials;
     XT_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     hipError_t e;
-    if (D == 1 && K == 1) e = xt_hist_launch<1, 1>(ctx, a, grid, lds);
-    else if (D == 2 && K == 1) e = xt_hist_launch<2, 1>(ctx, a, grid, lds);
-    else if (D == 2 && K == 2) e = xt_hist_launch<2, 2>(ctx, a, grid, lds);
-    else if (D == 3 && K == 1) e = xt_hist_launch<3, 1>(ctx, a, grid, lds);
-    else if (D == 3 && K == 3) e = xt_hist_launch<3, 3>(ctx, a, grid, lds);
+    if (D == 1 && K == 1) e = xt_hist_launch<1, 1>(ctx, a, grid, lds, threads);
+    else if (D == 2 && K == 1) e = xt_hist_launch<2, 1>(ctx, a, grid, lds, threads);
+    else if (D == 2 && K == 2) e = xt_hist_launch<2, 2>(ctx, a, grid, lds, threads);
+    else if (D == 3 && K == 1) e = xt_hist_launch<3, 1>(ctx, a, grid, lds, threads);
+    else if (D == 3 && K == 3) e = xt_hist_launch<3, 3>(ctx, a, grid, lds, threads);
     else return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "histogram kernel variant not built");
     if (e != hipSuccess) return xt_fail(ctx, EXTRACK_E_HIP, std::string("histogram kernel launch: ") + hipGetErrorString(e));
     XT_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
@@ -118,7 +124,7 @@ extern "C" int extrack_segment_len_hist(extrack_ctx* ctx, const extrack_model* m
     XT_HIP(ctx, hipMemcpyAsync(hist, d_out, (size_t)nbins * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     XT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->launch_info[0] = grid;
-    ctx->launch_info[1] = 256;
+    ctx->launch_info[1] = threads;
     ctx->launch_info[2] = (int32_t)lds;
     ctx->launch_info[3] = 1;
     ctx->launch_info[4] = per_cu;
