@@ -424,13 +424,19 @@ def _pick_gradient(params, fargs, explicit, comm=None):
     with contextlib.redirect_stdout(sink):
         try:
             cum_Proba_Cs(params, *a)  # warm-up: tables, workspaces, clocks
-            cum_Proba_Cs_grad(params, names, *a)
             t0 = time.perf_counter()
             cum_Proba_Cs(params, *a)
             t_ll = time.perf_counter() - t0
             t0 = time.perf_counter()
-            cum_Proba_Cs_grad(params, names, *a)
+            cum_Proba_Cs_grad(params, names, *a)  # first call: includes one-time allocations
             t_g = time.perf_counter() - t0
+            clear = t_g > 1.5 * (len(names) + 1) * t_ll  # already far on the wrong side: spare the second (warm) gradient call
+            if comm is not None:
+                clear = comm.allreduce_scalar(1.0 if clear else 0.0, "min") > 0.5
+            if not clear:
+                t0 = time.perf_counter()
+                cum_Proba_Cs_grad(params, names, *a)
+                t_g = time.perf_counter() - t0
         except Exception:  # e.g. a model the gradient kernels do not serve: the objective itself decides later
             return False
     if comm is not None:
