@@ -405,7 +405,7 @@ XT_HD void xt_r2_body(const XtKernelArgs& a, const XtGradArgs& ga, Ctx& cx)
             for (int d = 0; d < D; ++d) c[d] = pos[(ts * XT_F2_CHUNK + r) * D + d];
             if (KS == 0) {
                 XT_UNROLL
-                for (int k = 0; k < K; ++k) l2[k] = l2g[k];
+                for (int k = 0; k < K; ++k) l2[k] = xt_at<double>(lds, k * 8);  // broadcast read of the blob header (two fewer live VGPRs per k than a register copy)
             } else {
                 XT_UNROLL
                 for (int k = 0; k < K; ++k) {
