@@ -129,10 +129,11 @@ def test_c3_three_state_fit_recovers_simulated_parameters(capsys):
     tracks = _c3_tracks(6e4, seed0=500)
     p0 = T.generate_params(nb_states=3, LocErr_type=1, LocErr_bounds=[0.005, 0.1], D_max=3, estimated_Ds=[0.0001, 0.02, 0.4],
                            estimated_Fs=[0.3, 0.3], estimated_transition_rates=0.1)
-    fit = T.param_fitting(tracks, 0.02, params=p0, nb_states=3, nb_substeps=1, frame_len=4, verbose=0, method="bfgs", cell_dims=[1])
+    # frame_len 6: the reference's default (extrack/tracking.py:1304); gradient=None: the timing probe decides (finite differences for 3 states today)
+    fit = T.param_fitting(tracks, 0.02, params=p0, nb_states=3, nb_substeps=1, frame_len=6, verbose=0, method="bfgs", cell_dims=[1])
     capsys.readouterr()
     v = {k: fit.params[k].value for k in fit.params}
-    truth = T.cum_Proba_Cs(_params(dict(C3_VALS, pBL=0.0001)), T.engine.sort_buckets(tracks)[1], 0.02, [1], None, 3, 1, 4, verbose=0)
+    truth = T.cum_Proba_Cs(_params(dict(C3_VALS, pBL=0.0001)), T.engine.sort_buckets(tracks)[1], 0.02, [1], None, 3, 1, 6, verbose=0)
     capsys.readouterr()
     assert fit.residual[0] <= truth + 1e-6  # at least as good as (nearly) the generating parameters
     assert v["D0"] < 2e-3 and abs(v["D1"] - 0.04) < 0.006 and abs(v["D2"] - 0.25) < 0.02
