@@ -6,6 +6,7 @@
 #include "xt_grad_host.h"
 #include "xt_reg2.h"
 #include "xt_gradr.h"
+#include "xt_rev.h"
 
 // Waves per SIMD the register allocator is asked to allow.  Measured on C2 (1e6 x 30, 7 directions, PJ = 4): 2 -> 63 ms,
 // 3 -> 53 ms (168 VGPRs, 108 B of scratch per lane), 4 -> 60 ms (128 VGPRs, 272 B of scratch).  Three members per group (C3, 13 directions): 3 waves (232 B of
@@ -219,6 +220,77 @@ static int xt_grad_enqueue(extrack_ctx* ctx, const extrack_model* m, int32_t n_d
         XT_HIP(ctx, hipEventRecord(ctx->ev_blob[(ctx->blob_turn - 1u) & 1u], ctx->stream));
         // ---- two-state models: register-resident kernels (xt_reg2.h), <= 8 directions per pass, tangents in VGPRs
         const bool r2 = ctx->grad_reg2 == 1 && xt_use_reg2(c.S, c.NS, c.F) && m->locerr_mode == 0 && n_dir > 0 && xt_r2_kernel(c.F, D, K, 1) != nullptr;
+        // ---- reverse mode (xt_rev.h): one forward + one backward sweep whatever the number of directions; the adjoint of the model blob
+        // is contracted with the tangent blocks by a small kernel.  3 / 4 members per group by default (r03: C3, 13 directions)
+        {
+            const void* kp = n_dir > 0 && xt_rev_supported(c.G, c.NG) ? xt_rev_kernel_ptr(c.G, D, K) : nullptr;
+            const int tpb = std::max(1, 256 / c.NG), threads = (tpb * c.NG + 63) / 64 * 64;
+            const size_t lds = xt_rev_lds_bytes(c.S, c.G, c.EP, D, K, tpb, threads);
+            const bool use_rev = kp && lds <= 160 * 1024 && (ctx->grad_rev == 2 || (ctx->grad_rev == 1 && ctx->grad_reg2 == 1 && !r2));
+            if (use_rev) {
+                if (lds > 64 * 1024) XT_HIP(ctx, hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                auto key = std::make_pair(kp, std::make_pair(threads, lds));
+                auto it = ctx->occ_cache.find(key);
+                if (it == ctx->occ_cache.end()) {
+                    int o = 0;
+                    XT_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, kp, threads, lds));
+                    it = ctx->occ_cache.emplace(key, o < 1 ? 1 : o).first;
+                }
+                const int occ = it->second;
+                XtKernelArgs a;
+                memset(&a, 0, sizeof(a));
+                xt_fill_args_from_config(c, a);
+                XtRevArgs ra;
+                memset(&ra, 0, sizeof(ra));
+                const double target = (double)occ * ctx->n_cu * ctx->rev_oversub;
+                double wsum = 0.0;
+                int Lmax = 2;
+                std::vector<int64_t> nbatch(descs.size());
+                for (size_t i = 0; i < descs.size(); ++i) {
+                    nbatch[i] = (descs[i].N + tpb - 1) / tpb;
+                    wsum += (double)nbatch[i] * (descs[i].L - 1);
+                    Lmax = std::max(Lmax, (int)descs[i].L);
+                }
+                int64_t acc = 0;
+                for (size_t i = 0; i < descs.size(); ++i) {
+                    int64_t n = (int64_t)ceil(target * ((double)nbatch[i] * (descs[i].L - 1)) / wsum);
+                    n = n < 1 ? 1 : (n > nbatch[i] ? nbatch[i] : n);
+                    acc += n;
+                    a.blk_end[i] = (int32_t)acc;
+                }
+                const int grid = (int)acc;
+                ra.TB = TB;
+                ra.log_stride = (int64_t)std::max(Lmax - 2, 1) * xt_rev_step_doubles(c.NG, D, K);
+                if ((rc = xt_grad_reserve(ctx, &ctx->d_revlog, &ctx->revlog_cap, (size_t)grid * tpb * (size_t)ra.log_stride))) return rc;
+                if ((rc = xt_grad_reserve(ctx, &ctx->d_revadj, &ctx->revadj_cap, (size_t)TB))) return rc;
+                if ((rc = xt_grad_reserve(ctx, &ctx->d_gpartials, &ctx->gpartials_cap, poff + (size_t)grid * (TB + 1)))) return rc;
+                a.desc = ctx->d_desc + doff;
+                a.ndesc = (int32_t)descs.size();
+                a.blob = ctx->d_blob;
+                a.TPB = tpb;
+                a.min_len = m->min_len;
+                a.locerr_mode = m->locerr_mode;
+                a.KS = b0.KS ? b0.KS : 1;
+                ra.gpartials = ctx->d_gpartials + poff;
+                ra.log = ctx->d_revlog;
+                void* kargs[2] = {(void*)&a, (void*)&ra};
+                XT_HIP(ctx, hipLaunchKernel(kp, dim3(grid), dim3(threads), kargs, lds, ctx->stream));
+                hipLaunchKernelGGL(xt_grad_reduce, dim3(TB + 1), dim3(256), 0, ctx->stream, ctx->d_gpartials + poff, grid, TB + 1, d_out, ctx->d_revadj,
+                                   xt_grad_dst_identity(0));
+                XT_HIP(ctx, hipGetLastError());
+                xt_rev_project(ctx->stream, ctx->d_revadj, ctx->d_dblob, TB, n_dir, d_out + 1);
+                XT_HIP(ctx, hipGetLastError());
+                poff += (size_t)grid * (TB + 1);
+                ctx->launch_info[0] = grid;
+                ctx->launch_info[1] = threads;
+                ctx->launch_info[2] = (int32_t)lds;
+                ctx->launch_info[3] = tpb;
+                ctx->launch_info[4] = occ;
+                ctx->launch_info[5] = ctx->n_cu;
+                doff += g.size();
+                continue;
+            }
+        }
         if (r2) {
             const int tpw = 64 >> (c.F - 1), tpb = tpw * XT_F2_WAVES, threads = 64 * XT_F2_WAVES;
             // "uniform" directions (xt_r2_uniform_direction, e.g. pBL) cost no per-step work: they ride along with the first pass

@@ -101,6 +101,8 @@ extern "C" int extrack_create(int device_id, extrack_ctx** out)
     }
     if (const char* ev = getenv("EXTRACK_LL_PATH")) c->ll_reg2 = strcmp(ev, "reg2") == 0 ? 1 : (strcmp(ev, "lds") == 0 ? 0 : c->ll_reg2);
     if (const char* ev = getenv("EXTRACK_GRAD_PATH")) c->grad_reg2 = strcmp(ev, "lds") == 0 ? 0 : (strcmp(ev, "gradr") == 0 ? 2 : 1);
+    if (const char* ev = getenv("EXTRACK_GRAD_PATH")) c->grad_rev = strcmp(ev, "rev") == 0 ? 2 : (strcmp(ev, "auto") == 0 ? 1 : 0);
+    if (const char* ev = getenv("EXTRACK_REV_OVERSUB")) c->rev_oversub = std::max(1, atoi(ev));
     if (const char* ev = getenv("EXTRACK_GRADR_NPC")) c->gradr_npc = atoi(ev) == 4 ? 4 : (atoi(ev) == 3 ? 3 : 0);
     if (const char* ev = getenv("EXTRACK_TH_TT")) {
         int v = atoi(ev);
@@ -219,6 +221,8 @@ extern "C" void extrack_destroy(extrack_ctx* ctx)
     if (ctx->d_dblob2) (void)hipFree(ctx->d_dblob2);
     if (ctx->ev_dblob) (void)hipEventDestroy(ctx->ev_dblob);
     if (ctx->d_gout) (void)hipFree(ctx->d_gout);
+    if (ctx->d_revlog) (void)hipFree(ctx->d_revlog);
+    if (ctx->d_revadj) (void)hipFree(ctx->d_revadj);
     for (int i = 0; i < extrack_ctx::RF_SLOTS; ++i)
         if (ctx->rf_buf[i]) (void)hipFree(ctx->rf_buf[i]);
     if (ctx->evg0) (void)hipEventDestroy(ctx->evg0);

@@ -189,6 +189,12 @@ struct extrack_ctx {
     int ll_reg2 = 1;  // 2-state likelihood: 1 = register-resident kernel (xt_reg2.h), 0 = LDS-resident (xt_fast2.h); EXTRACK_LL_PATH=reg2|lds
     int grad_reg2 = 1;  // gradient kernels: 1 = register-resident where built (xt_reg2.h for 2 states, else xt_gradr.h), 0 = the LDS-resident xt_grad.h
                         // only, 2 = xt_gradr.h before xt_reg2.h (tests); EXTRACK_GRAD_PATH = reg2 | lds | gradr
+    int grad_rev = 1;   // reverse-mode kernels (xt_rev.h) for 3 / 4 members per group: 1 = where they win, 0 = never, 2 = wherever built; EXTRACK_GRAD_PATH = rev
+    int rev_oversub = 1;  // block generations per CU of the reverse-mode launch (each block owns a log region: fewer blocks, smaller cache footprint)
+    double* d_revlog = nullptr;  // merged-state logs of the reverse-mode kernels
+    size_t revlog_cap = 0;       // doubles
+    double* d_revadj = nullptr;  // adjoint of the model blob [TB]
+    size_t revadj_cap = 0;
     int gradr_npc = 0;  // directions per pass of the xt_gradr.h kernels (0: chosen by the launcher; EXTRACK_GRADR_NPC = 3 | 4 also forces these kernels for small models)
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
@@ -307,4 +313,6 @@ size_t xt_desc_base(const extrack_ctx* ctx);
 size_t xt_max_grid(const extrack_ctx* ctx);
 __global__ void xt_reduce_partials(const double* __restrict__ partials, int n, double* __restrict__ out);
 const void* xt_r2_kernel(int F, int D, int K, int NP);  // extrack_reg2.hip: register-resident 2-state kernels, nullptr = not built
+const void* xt_rev_kernel_ptr(int G, int D, int K);  // extrack_rev.hip: reverse-mode gradient kernels (xt_rev.h)
+void xt_rev_project(hipStream_t st, const double* adj, const double* dblob, int TB, int n_dir, double* out);  // out[i] = <adj, dblob[i]>
 const void* xt_gradr_kernel_ptr(int G, int D, int K, int NPC);  // extrack_gradr.hip: register-resident gradient kernels (xt_gradr.h), NPC = 3 | 4

@@ -19,6 +19,7 @@
 #include "../../extrack_amd/csrc/xt_hist_host.h"
 #include "../../extrack_amd/csrc/xt_reg2.h"
 #include "../../extrack_amd/csrc/xt_gradr.h"
+#include "../../extrack_amd/csrc/xt_rev.h"
 #include "../../extrack_amd/csrc/xt_tables.h"
 #include "../../extrack_amd/csrc/xt_th.h"
 
@@ -108,6 +109,7 @@ struct EmulLauncher {
 
 bool emul_r2(int F, int D, int K, int KS, int NP, const XtKernelArgs& a, const XtGradArgs& ga, int nblocks);  // emul_r2.cpp
 bool emul_gradr(int G, int D, int K, int NPC, const XtKernelArgs& a, const XtGradArgs& ga, int nblocks, int threads, size_t lds_doubles);  // emul_gradr.cpp
+bool emul_rev(int G, int D, int K, const XtKernelArgs& a, const XtRevArgs& ra, int nblocks, int threads, size_t lds_doubles);  // emul_rev.cpp
 
 extern "C" int xt_emul_run(const double* tracks, const double* sigma, long long N, int L, int D, int KS, int S, int NS, int F,
                            int isBL, int min_len, int locerr_mode, int locerr_dims, const double* locerr, double slope,
@@ -712,6 +714,32 @@ extern "C" int xt_emul_grad(const double* tracks, const double* sigma, long long
     if (tan_lds) d += (size_t)((n_dir * TB + 1) & ~1);
     d += (size_t)tpb * ((size_t)xt_grad_region_doubles(cfg.EP, D, K, n_dir) + xt_grad_acc_doubles(n_dir, cfg.NG) + xt_stage_doubles(D));
     l.lds_doubles = d;
+    if (generic_g == 5) {  // xt_rev.h: reverse mode - adjoint of the model blob, contracted with the tangent blocks here (the product: a small kernel)
+        if (!xt_rev_supported(cfg.G, cfg.NG)) return -5;
+        const int tpbr = std::max(1, 256 / cfg.NG), thr = (tpbr * cfg.NG + 63) / 64 * 64;
+        l.a.TPB = tpbr;
+        XtRevArgs ra;
+        memset(&ra, 0, sizeof(ra));
+        std::vector<double> gp2((size_t)nblocks * (1 + TB), 0.0);
+        ra.log_stride = (int64_t)std::max(L - 2, 1) * xt_rev_step_doubles(cfg.NG, D, K);
+        std::vector<double> logbuf((size_t)nblocks * tpbr * ra.log_stride, 0.0);
+        ra.gpartials = gp2.data();
+        ra.log = logbuf.data();
+        ra.TB = TB;
+        const size_t ldsd = xt_rev_lds_bytes(S, cfg.G, cfg.EP, D, K, tpbr, thr) / 8;
+        if (!emul_rev(cfg.G, D, K, l.a, ra, nblocks, thr, ldsd)) return -3;
+        std::vector<double> adj(TB, 0.0);
+        for (int b = 0; b < nblocks; ++b) {
+            out[0] += gp2[(size_t)b * (1 + TB)];
+            for (int c = 0; c < TB; ++c) adj[c] += gp2[(size_t)b * (1 + TB) + 1 + c];
+        }
+        for (int i = 0; i < n_dir; ++i) {
+            double s2 = 0.0;
+            for (int c = 0; c < TB; ++c) s2 += adj[c] * dblob[(size_t)i * TB + c];
+            out[1 + i] = s2;
+        }
+        return 0;
+    }
     if (generic_g == 3 || generic_g == 4) {  // xt_gradr.h: state and tangents in registers, LDS exchange; generic_g = 3 / 4: that many directions per pass
         if (cfg.G < 2 || cfg.G > 4 || cfg.NG > 256) return -5;
         const int NPC = generic_g;

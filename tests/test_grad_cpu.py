@@ -130,6 +130,31 @@ def test_emulated_register_resident_general_gradient_body(S, ns, F, L, N, D, K, 
     assert rel.max() < 1e-6, [(d[0], a, b) for d, a, b, r in zip(dirs, g, fd, rel) if r > 1e-6]
 
 
+@pytest.mark.parametrize("S,ns,F,L,N,D,K,isBL", [(3, 1, 3, 8, 6, 2, 1, 1), (3, 1, 4, 9, 5, 2, 1, 0), (2, 2, 4, 7, 6, 1, 1, 1), (3, 1, 3, 8, 4, 2, 2, 1),
+                                                   (4, 1, 3, 7, 3, 3, 1, 1), (3, 1, 3, 2, 4, 2, 1, 1), (3, 1, 3, 3, 4, 2, 1, 0), (2, 1, 5, 36, 3, 3, 3, 1),
+                                                   (3, 1, 5, 12, 7, 2, 1, 1)])
+def test_emulated_reverse_mode_gradient_body(S, ns, F, L, N, D, K, isBL):
+    """xt_rev.h (reverse mode: forward sweep logging the merged state of every group, backward sweep of adjoints, adjoint of the model
+    blob contracted with the tangent blocks) on CPU threads against Richardson differences of the pinned oracle along every model
+    direction; N is not a multiple of the tracks per workgroup (partial last batch), 2- and 3-position tracks, a track longer than
+    the staging block of 32 positions."""
+    import run_emul as E
+    from extrack_amd import synth
+    from oracle import oracle_np as O
+    Ds, T, Fs = _model(S, S * 10 + F)
+    Cs = synth.brownian_tracks(N, L, Ds, T, Fs, seed=S + F, dims=D)
+    ds2, cell, pBL, min_len = 2 * Ds * 0.02, [1.0], 0.1, 3
+    le = np.array([0.02, 0.025, 0.03][:K])
+    dirs = model_directions(S, K, ns, ds2, T, le, cell)
+    ll, tot, g = E.run_grad(Cs, le[None, None], np.sqrt(ds2), Fs, T, pBL, isBL, O.p_stay_table(np.sqrt(ds2), S, ns, cell), ns, F, min_len,
+                            [d[1] for d in dirs], generic_g=5)
+    ref = O.proba_cs(Cs, le[None, None], np.sqrt(ds2), Fs, T, pBL, isBL, cell, ns, F, min_len)
+    assert np.abs(ll - ref).max() < 1e-10 and abs(tot - ref.sum()) < 1e-12 * abs(tot)
+    fd = oracle_fd_gradient(Cs, le, ds2, Fs, T, pBL, isBL, cell, ns, F, min_len, dirs)
+    rel = np.abs(g - fd) / np.maximum(np.abs(fd), 1e-3 * np.abs(fd).max())
+    assert rel.max() < 1e-6, [(d[0], a, b) for d, a, b, r in zip(dirs, g, fd, rel) if r > 1e-6]
+
+
 def test_host_chain_rule_matches_finite_differences():
     """params (with expr constraints and bounds) -> model arrays: the complex-step tangents against central differences, for every
     Matrix_type and a D0 sitting exactly at 0 (where d ds / d D is infinite but d ds^2 / d D is not)."""

@@ -22,7 +22,7 @@ def _params(vals):
     return p
 
 
-@pytest.mark.parametrize("gradr", [None, "4", "3"])
+@pytest.mark.parametrize("gradr", [None, "4", "3", "rev"])
 def test_gradient_vs_oracle_central_differences_on_golden_models(kernel_cases, gradr, monkeypatch):
     """gradr: None = the launcher's choice of kernel per model (xt_reg2.h for 2 states with a global error, xt_gradr.h up to 4 members per group and 256 groups per track, else xt_grad.h);
     "4" / "3" = the register-resident general kernels (xt_gradr.h) forced for every model they serve, 4 / 3 directions per pass.
@@ -31,7 +31,9 @@ def test_gradient_vs_oracle_central_differences_on_golden_models(kernel_cases, g
     must match central differences of the oracle to 1e-6 relative."""
     from extrack_amd import tracking as T
     from oracle import oracle_np as O
-    if gradr:
+    if gradr == "rev":
+        monkeypatch.setenv("EXTRACK_GRAD_PATH", "rev")  # the reverse-mode kernels (xt_rev.h) for every model they serve (default: 3 / 4 members per group)
+    elif gradr:
         monkeypatch.setenv("EXTRACK_GRADR_NPC", gradr)  # read when a context is created
         monkeypatch.setenv("EXTRACK_GRAD_PATH", "gradr")
     meta, data = kernel_cases
