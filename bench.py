@@ -199,15 +199,21 @@ def other_configs(device):
     names = gradient.free_names(pg)
     for _ in range(2):
         gv, gg = gradient.objective_and_gradient(pg, ts, DT, CELL, 3, 1, 4, names=names)
-    out["c3_loglik_grad_F4"] = {"what": "configs[2], frame_len 4: -sum(LL) AND its exact gradient (13 free parameters) in one pass", "kernel_ms": ts.ctx.last_grad_ms(),
+    out["c3_loglik_grad_F4"] = {"what": "configs[2], frame_len 4: -sum(LL) AND its exact gradient (13 free parameters) by the reverse-mode kernel "
+                                        "(xt_rev.h: one forward + one backward sweep)", "kernel_ms": ts.ctx.last_grad_ms(),
                                 "n_directions": len(names), "fd_equivalent_ms": (len(names) + 1) * out["c3_loglik_F4"]["kernel_ms"],
                                 "grad_inf_norm": float(np.abs(gg).max())}
     for _ in range(2):
         gv, gg = gradient.objective_and_gradient(pg, ts, DT, CELL, 3, 1, 6, names=names)
-    out["c3_loglik_grad_F6"] = {"what": "configs[2], frame_len 6 (the reference's default): the same one-pass gradient - tangents in LDS, several passes; slower than "
-                                        "the finite differences it would replace, so param_fitting's timing probe keeps finite differences for this model",
+    step_b = 243 * 36  # merged-state log of a step: 243 groups x (W mantissa, exponent, mean[2], variance)
+    log_bytes = int(sum((L - 2) * n for L, n in lc) * step_b)
+    out["c3_loglik_grad_F6"] = {"what": "configs[2], frame_len 6 (the reference's default): the same gradient by the reverse-mode kernel - its cost does not depend on "
+                                        "the number of parameters; the forward-mode kernels (xt_gradr.h, r03: 600 ms) are kept for EXTRACK_GRAD_PATH=gradr",
                                 "kernel_ms": ts.ctx.last_grad_ms(), "n_directions": len(names),
-                                "fd_equivalent_ms": (len(names) + 1) * out["c3_loglik_F6"]["kernel_ms"]}
+                                "fd_equivalent_ms": (len(names) + 1) * out["c3_loglik_F6"]["kernel_ms"],
+                                "algorithmic_bytes": nbytes + 2 * log_bytes,
+                                "byte_model": "tracks once + the merged-state log written by the forward sweep and read back by the backward sweep",
+                                "hbm_gbs": (nbytes + 2 * log_bytes) / (ts.ctx.last_grad_ms() * 1e-3) / 1e9}
     model = tracking._objective_model(P(vals), ts, DT, CELL, None, 3, 1, 6, 1)
     # two untimed evaluations: the first learns the sequence counts (LDS sizing), the second allocates the second stream's launch buffers
     wall, kms, v = timed(lambda: ts.loglik_th(model, 0.2, 120, 2000), 5, warm=2)
@@ -221,13 +227,19 @@ def other_configs(device):
     tracks = {str(L): synth.brownian_tracks(n, L, Ds, Tm, [0.3, 0.3, 0.4], seed=1000 + L) for L, n in sizes.items() if n > 0}
     p0 = tracking.generate_params(nb_states=3, LocErr_type=1, LocErr_bounds=[0.005, 0.1], D_max=3, estimated_Ds=[0.0001, 0.02, 0.4],
                                   estimated_Fs=[0.3, 0.3], estimated_transition_rates=0.1)
-    with contextlib.redirect_stdout(io.StringIO()):
-        t0 = time.perf_counter()
-        r = tracking.param_fitting(tracks, DT, params=p0, nb_states=3, frame_len=6, cell_dims=CELL, verbose=0, device=device)
-        t_fit = time.perf_counter() - t0
-    out["c3_full_fit_F6"] = {"what": "configs[2]: param_fitting on 1e6 tracks, 3 states, 46 buckets, frame_len 6, BFGS from a generic start (incl. the upload)",
-                             "seconds": t_fit, "objective_calls": int(r.nfev), "gradient_calls": int(getattr(r, "ngev", 0)), "neg_loglik": float(r.residual[0]),
-                             "fitted": {k: float(r.params[k].value) for k in ("D1", "D2", "LocErr", "F0", "F1")},
+    fits3 = {}
+    for grad in (None, "fd"):
+        with contextlib.redirect_stdout(io.StringIO()):
+            t0 = time.perf_counter()
+            r = tracking.param_fitting(tracks, DT, params=p0, nb_states=3, frame_len=6, cell_dims=CELL, verbose=0, device=device, gradient=grad)
+            t_fit = time.perf_counter() - t0
+        fits3["default" if grad is None else grad] = {"seconds": t_fit, "objective_calls": int(r.nfev), "gradient_calls": int(getattr(r, "ngev", 0)),
+                                                       "neg_loglik": float(r.residual[0]),
+                                                       "fitted": {k: float(r.params[k].value) for k in ("D1", "D2", "LocErr", "F0", "F1")}}
+    out["c3_full_fit_F6"] = {"what": "configs[2]: param_fitting on 1e6 tracks, 3 states, 46 buckets, frame_len 6, BFGS from a generic start (incl. the upload); "
+                                     "'default' = gradient=None (timing probe -> reverse-mode gradient), 'fd' = finite differences like the reference",
+                             "seconds": fits3["default"]["seconds"], "objective_calls": fits3["default"]["objective_calls"],
+                             "gradient_calls": fits3["default"]["gradient_calls"], "neg_loglik": fits3["default"]["neg_loglik"], "fit": fits3,
                              "simulated": {"D1": 0.04, "D2": 0.25, "LocErr": LOCERR, "F0": 0.3, "F1": 0.3}}
     del tracks
     # the same for the headline dataset (configs[1]: 1e6 x 30, 2 states, 7 free parameters): analytic gradient vs finite differences

@@ -404,9 +404,10 @@ def _pick_gradient(params, fargs, explicit, comm=None):
     """Should ``param_fitting`` hand the optimiser the analytic gradient (one ``extrack_loglik_grad`` pass per iteration) rather than
     let it difference the objective (nvar + 1 evaluations per iteration, what the reference does, extrack/tracking.py:1371)?
     Yes when (a) every constraint expression is complex-differentiable and (b) - unless the caller asked for it explicitly - a timing
-    probe on this dataset says a gradient call costs less than the nvar + 1 objective calls it replaces: the gradient kernels beat finite
-    differences for two-state models (tangents in registers, xt_reg2.h) but not yet for >= 3 states, and on datasets of a few
-    thousand tracks the comparison is decided by host overheads.  With ``comm`` the decision is taken on the slowest rank's timings."""
+    probe on this dataset says a gradient call costs less than the nvar + 1 objective calls it replaces: on large datasets the gradient
+    kernels beat finite differences (two states: tangents in registers, xt_reg2.h; 3 / 4 states: reverse mode, xt_rev.h - about the cost
+    of four objective calls whatever nvar is), on datasets of a few thousand tracks the comparison is decided by host overheads, and models
+    only the LDS-resident forward-mode kernel serves (xt_grad.h) are slower than differences.  With ``comm`` the decision is taken on the slowest rank's timings."""
     import time
     from . import gradient
     names = gradient.free_names(params)

@@ -162,8 +162,9 @@ def test_gradient_full_size_properties():
 
 def test_default_gradient_choice_follows_the_timing_probe(capsys):
     """``param_fitting(gradient=None)``: the optimiser gets the analytic gradient only where a gradient call is cheaper than the nvar + 1
-    objective calls it replaces on THIS dataset (tracking._pick_gradient).  Two-state models (tangents in registers) -> analytic; the
-    3-state model at frame_len 6 (tangents in LDS, slower than finite differences today) -> finite differences, same optimum."""
+    objective calls it replaces on THIS dataset (tracking._pick_gradient).  Two-state models (tangents in registers, xt_reg2.h) -> analytic; the
+    3-state model at frame_len 6 (the reference's default window) -> analytic too since the reverse-mode kernels (xt_rev.h): same optimum as
+    the finite-difference fit, in less time."""
     import time
     from extrack_amd import synth, tracking as T
     from test_hip_configs import _c3_tracks
@@ -179,10 +180,16 @@ def test_default_gradient_choice_follows_the_timing_probe(capsys):
     tracks = _c3_tracks(3e4, seed0=900)
     p3 = T.generate_params(nb_states=3, LocErr_type=1, LocErr_bounds=[0.005, 0.1], D_max=3, estimated_Ds=[0.0001, 0.02, 0.4],
                            estimated_Fs=[0.3, 0.3], estimated_transition_rates=0.1)
+    t0 = time.perf_counter()
     f3 = T.param_fitting(tracks, 0.02, params=p3, nb_states=3, frame_len=6, verbose=0, method="bfgs", cell_dims=[1])
+    t3_auto = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    f3fd = T.param_fitting(tracks, 0.02, params=p3, nb_states=3, frame_len=6, verbose=0, method="bfgs", cell_dims=[1], gradient="fd")
+    t3_fd = time.perf_counter() - t0
     capsys.readouterr()
-    print("2 states: default fit %.2f s (ngev %d, nfev %d) vs fd fit %.2f s (nfev %d); 3 states F=6: ngev %d" % (
-        t_auto, f2.ngev, f2.nfev, t_fd, f2fd.nfev, f3.ngev))
+    print("2 states: default fit %.2f s (ngev %d, nfev %d) vs fd fit %.2f s (nfev %d); 3 states F=6: default %.2f s (ngev %d, nfev %d) vs fd %.2f s (nfev %d)" % (
+        t_auto, f2.ngev, f2.nfev, t_fd, f2fd.nfev, t3_auto, f3.ngev, f3.nfev, t3_fd, f3fd.nfev))
     assert f2.ngev > 0 and f2.residual[0] <= f2fd.residual[0] + 1e-6 * abs(f2fd.residual[0])
     assert t_auto < t_fd  # the probe's promise: never the slower way
-    assert f3.ngev == 0
+    assert f3.ngev > 0 and f3.residual[0] <= f3fd.residual[0] + 1e-6 * abs(f3fd.residual[0])
+    assert t3_auto < t3_fd
