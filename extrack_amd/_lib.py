@@ -17,6 +17,7 @@ EXPORTS = [
     "extrack_loglik", "extrack_loglik_async", "extrack_predict", "extrack_last_kernel_ms",
     "extrack_last_launch_info", "extrack_p_stay_table", "extrack_loglik_th", "extrack_loglik_th_async", "extrack_th_plan_step",
     "extrack_predict_th", "extrack_loglik_grad", "extrack_loglik_grad_async", "extrack_last_grad_ms", "extrack_segment_len_hist", "extrack_refine_positions",
+    "extrack_sequence_columns", "extrack_sequence_matrix",
 ]
 
 _dp = C.POINTER(C.c_double)
@@ -107,7 +108,10 @@ def load():
     lib.extrack_segment_len_hist.argtypes = [vp, C.POINTER(ExtrackModel), i32, i32, vp]
     lib.extrack_refine_positions.argtypes = [vp, C.POINTER(ExtrackModel), i32, C.c_double, i32, vp, vp]
     lib.extrack_last_grad_ms.argtypes = [vp, C.POINTER(C.c_float)]
-    if lib.extrack_abi_version() != 4:
+    lib.extrack_sequence_columns.argtypes = [i32, i32, i32, i32, i32]
+    lib.extrack_sequence_columns.restype = i64
+    lib.extrack_sequence_matrix.argtypes = [vp, C.POINTER(ExtrackModel), i32, vp, i64]
+    if lib.extrack_abi_version() != 5:
         raise ImportError("libextrack_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -343,6 +347,18 @@ class Context:
         N, L, D, KS = self.buckets[bucket_id]
         out = np.empty((N, L, model.c.n_states))
         self._check(self._lib.extrack_predict(self._h, C.byref(model.c), int(bucket_id), out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def sequence_matrix(self, model, bucket_id):
+        """LP[N, nB]: log-probability of every sequence of states still distinguished at the last position, in the reference's column
+        order (first return value of P_Cs_inter_bound_stats, extrack/tracking.py:318)."""
+        N, L, D, KS = self.buckets[bucket_id]
+        m = model.c
+        nb = int(self._lib.extrack_sequence_columns(m.n_states, L, m.nb_substeps, m.frame_len, int(L != m.max_len)))
+        if nb < 1:
+            raise ValueError("sequence matrix: invalid model / track length")
+        out = np.empty((N, nb))
+        self._check(self._lib.extrack_sequence_matrix(self._h, C.byref(m), int(bucket_id), out.ctypes.data_as(C.c_void_p), nb))
         return out
 
     def last_kernel_ms(self):

@@ -3,6 +3,7 @@
 #include "xt_host.h"
 
 #include "xt_dispatch.h"
+#include "xt_seqmat.h"
 #include "xt_entry.h"
 #include "xt_fast2.h"
 #include "xt_reg2.h"
@@ -549,7 +550,7 @@ int xt_reserve_partials(extrack_ctx* ctx, size_t n)
 
 // Launches ONE kernel for a set of buckets that share (dims, sigma dims): partial sums go to d_partials[poff .. poff+grid).
 static int xt_launch_group(extrack_ctx* ctx, const extrack_model* m, const std::vector<XtBucket*>& bks, bool preds, bool per_track,
-                           double* d_preds, size_t poff, size_t desc_off, int* grid_out)
+                           double* d_preds, size_t poff, size_t desc_off, int* grid_out, double* d_seq = nullptr)
 {
     const XtConfig& c = ctx->cfg;
     const XtBucket& b0 = *bks[0];
@@ -567,8 +568,9 @@ static int xt_launch_group(extrack_ctx* ctx, const extrack_model* m, const std::
     memset(&l.a, 0, sizeof(l.a));
     xt_fill_args_from_config(c, l.a);
     int tpb, threads;
-    const bool fast2 = xt_use_fast2(c.S, c.NS, c.F, preds);
-    const bool entry = !fast2 && xt_use_entry(c.NS, c.G, c.NG, preds);
+    // d_seq (extrack_sequence_matrix): the general kernel writes the log-weight of every sequence of the last position, without the leaving term
+    const bool fast2 = !d_seq && xt_use_fast2(c.S, c.NS, c.F, preds);
+    const bool entry = !d_seq && !fast2 && xt_use_entry(c.NS, c.G, c.NG, preds);
     if (entry) {
         xt_entry_geometry(c.S, c.G, c.E, c.NG, D, K, tpb, threads, l.lds);
     } else if (fast2) {
@@ -618,8 +620,9 @@ static int xt_launch_group(extrack_ctx* ctx, const extrack_model* m, const std::
         d.preds_out = d_preds;
         d.N = b->N;
         d.L = b->L;
-        d.isBL = (b->L != m->max_len) ? 1 : 0;  // tracking.py:1037-1040
+        d.isBL = (!d_seq && b->L != m->max_len) ? 1 : 0;  // tracking.py:1037-1040
         d.ll_const = -(double)(b->L - 1) * D * 0.5 * XT_LOG2PI;
+        d.seq_out = d_seq;
         l.descs.push_back(d);
     }
     l.a.blob = ctx->d_blob;
@@ -739,6 +742,43 @@ extern "C" int extrack_predict(extrack_ctx* ctx, const extrack_model* m, int32_t
         if (e != hipSuccess) rc = xt_fail(ctx, EXTRACK_E_HIP, std::string("predict: ") + hipGetErrorString(e));
     }
     return rc;
+}
+
+// Per-sequence log-probabilities of one bucket in the reference's layout (P_Cs_inter_bound_stats' first return value,
+// extrack/tracking.py:300-318): raw kernel output -> host -> column order of the reference (xt_seqmat.h).  For small inputs:
+// N * S^(frame_len + nb_substeps) doubles go through host memory.
+extern "C" int64_t extrack_sequence_columns(int32_t n_states, int32_t len, int32_t nb_substeps, int32_t frame_len, int32_t isBL)
+{
+    if (n_states < 2 || len < 2 || nb_substeps < 1 || frame_len <= nb_substeps) return -1;
+    return xt_seq_columns(n_states, len, nb_substeps, frame_len, isBL);
+}
+
+extern "C" int extrack_sequence_matrix(extrack_ctx* ctx, const extrack_model* m, int32_t bucket_id, double* lp, int64_t n_cols)
+{
+    if (!ctx || !lp) return xt_fail(ctx, EXTRACK_E_INVALID, "null argument");
+    int rc = xt_validate_model(ctx, m);
+    if (rc) return rc;
+    if (bucket_id < 0 || bucket_id >= (int)ctx->buckets.size()) return xt_fail(ctx, EXTRACK_E_INVALID, "bucket id out of range");
+    XT_HIP(ctx, hipSetDevice(ctx->device));
+    if ((rc = xt_prepare(ctx, m))) return rc;
+    if ((rc = xt_reserve_partials(ctx, xt_max_grid(ctx)))) return rc;
+    XtBucket& b = ctx->buckets[bucket_id];
+    const XtConfig& c = ctx->cfg;
+    const int isBL = (b.L != m->max_len) ? 1 : 0;
+    if (n_cols != xt_seq_columns(c.S, b.L, c.NS, c.F, isBL)) return xt_fail(ctx, EXTRACK_E_INVALID, "sequence matrix: n_cols must be extrack_sequence_columns(...)");
+    const size_t nraw = (size_t)b.N * c.E * c.G;
+    if (nraw > ((size_t)1 << 31)) return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "sequence matrix: more than 2^31 entries (it exists for small inputs; the likelihood needs no matrix)");
+    if ((rc = xt_reserve_preds(ctx, nraw * sizeof(double)))) return rc;
+    int grid = 0;
+    std::vector<XtBucket*> one(1, &b);
+    if ((rc = xt_launch_group(ctx, m, one, false, false, nullptr, 0, xt_desc_base(ctx), &grid, ctx->d_preds))) return rc;
+    std::vector<double> raw(nraw);
+    XT_HIP(ctx, hipMemcpyAsync(raw.data(), ctx->d_preds, nraw * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    XT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    XtModelHost mh;
+    xt_model_host(m, mh);
+    xt_seq_reorder(c, mh, b.N, b.L, isBL, raw.data(), lp);
+    return EXTRACK_OK;
 }
 
 // ------------------------------------------------------------------------------------------------

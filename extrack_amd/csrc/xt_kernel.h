@@ -43,6 +43,7 @@ struct XtBucketDesc {
     int64_t N;
     int32_t L, isBL;
     double ll_const;       // -(L-1)*D/2*log(2*pi)
+    double* seq_out = nullptr;  // [N][E][G] log-weight of every (stored sequence, new digits) at the last position, or nullptr (xt_seqmat.h)
 };
 
 struct XtKernelArgs {
@@ -57,6 +58,7 @@ struct XtKernelArgs {
     double* ll_out;           // [N] per-track log-likelihood or nullptr
     double* partials;         // [nblocks] per-block sum of LL
     double* preds_out;        // [N][L][S] (PREDS kernels)
+    double* seq_out;          // [N][E][G] per-sequence log-weights at the last position (general kernel only) or nullptr
     int64_t N;
     int32_t L, S, NS, F, G, E, NG, P;
     int32_t EP;               // padded sequence-array length (E, or E + E/32 + E/1024 + 1 with the bank-conflict skew)
@@ -92,6 +94,7 @@ XT_HD XtBucketDesc xt_bind_bucket(const XtKernelArgs& a, int block, int nblocks,
         d.sigma = a.sigma;
         d.ll_out = a.ll_out;
         d.preds_out = a.preds_out;
+        d.seq_out = a.seq_out;
         d.N = a.N;
         d.L = a.L;
         d.isBL = a.isBL;
@@ -416,7 +419,11 @@ XT_HD void xt_track_body(const XtKernelArgs& a, Ctx& cx)
             for (int Q = 0; Q < G; ++Q) {
                 const int idx = xt_skew(base + off[Q], a.skew);
                 const double zq = zm[idx];
-                if (zq == 0.0) continue;
+                if (zq == 0.0) {
+                    if (b.seq_out)
+                        for (int q = 0; q < G; ++q) b.seq_out[((int64_t)trk * E + base + off[Q]) * G + q] = -INFINITY;
+                    continue;
+                }
                 const int eq = ze[idx];
                 double dq[D], uq[K], dsq = 0.0;
                 for (int d = 0; d < D; ++d) {
@@ -446,6 +453,7 @@ XT_HD void xt_track_body(const XtKernelArgs& a, Ctx& cx)
                     const double wm = zq * TF[q] * (gf * T64[j]) * p;
                     const int we = eq + n;
                     tot.add(wm, we);
+                    if (b.seq_out) b.seq_out[((int64_t)trk * E + base + off[Q]) * G + q] = wm > 0.0 ? log(wm) + (double)we * XT_LN2 + b.ll_const : (wm == 0.0 ? -INFINITY : NAN);
                     if (PREDS) {
                         accQ[Q].add(wm, we);
                         accq[q].add(wm, we);

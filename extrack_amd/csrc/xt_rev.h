@@ -184,9 +184,9 @@ XT_HD void xt_rev_body(const XtKernelArgs& a, const XtRevArgs& ra, Ctx& cx)
             } else {
                 XT_UNROLL
                 for (int k = 0; k < K; ++k) {
-                    const double v = act ? al2[k] * sc[k] : 0.0;
-                    acc[A_SL] = xt_fma(v, sraw[k], acc[A_SL]);
-                    acc[A_OF] += v;
+                    const double v = al2[k] * sc[k];  // (a lane without a track holds stale, possibly non-finite values: select, do not multiply)
+                    acc[A_SL] += act ? v * sraw[k] : 0.0;
+                    acc[A_OF] += act ? v : 0.0;
                 }
             }
         };

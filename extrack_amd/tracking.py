@@ -247,21 +247,34 @@ def Proba_Cs(Cs, LocErr, ds, Fs, TrMat, pBL, isBL, cell_dims, nb_substeps, frame
         ts.close()
 
 
+def get_all_Bs(nb_Cs, nb_states):
+    """Matrix [nb_states**nb_Cs, nb_Cs] of all state sequences: digit k of row i is (i // nb_states**k) % nb_states (k = 0: the newest
+    state) - the layout of ``cur_Bs`` and of the columns of ``LP`` in the reference (extrack/tracking.py:746-757)."""
+    i = np.arange(int(nb_states) ** int(nb_Cs))
+    return np.stack([(i // nb_states ** k) % nb_states for k in range(int(nb_Cs))], axis=1).astype(int)
+
+
 def P_Cs_inter_bound_stats(Cs, LocErr, ds, Fs, TrMat, pBL=0.1, isBL=1, cell_dims=[0.5], nb_substeps=1, frame_len=4, do_preds=0,
-                           min_len=3, device=0):
-    """Mirror of extrack/tracking.py:109-318 with one documented difference: the per-sequence matrix
-    ``LP[N, nB]`` is never materialised on the GPU (it is reduced in-kernel), so the first return value is
-    ``LP_C[:, None]`` - its logsumexp over axis 1 is what Proba_Cs computes from the reference's matrix.
-    Returns ``(LP_C[:, None], None, preds)``; ``preds`` is ``[]`` when ``do_preds`` is 0."""
+                           min_len=3, device=0, return_matrix=False):
+    """Mirror of extrack/tracking.py:109-318.  The likelihood kernels reduce the per-sequence matrix ``LP[N, nB]`` in place, so by
+    default the first return value is ``LP_C[:, None]`` (its logsumexp over axis 1 is what Proba_Cs computes from the reference's
+    matrix) and ``cur_Bs`` is None.  ``return_matrix=True`` gives the reference's contract, ``(LP[N, nB], cur_Bs[1, nB, n], preds)``
+    with the reference's column order (``get_all_Bs``) - for small inputs: the matrix goes through host memory.
+    ``preds`` is ``[]`` when ``do_preds`` is 0."""
     ts, le = _one_bucket(Cs, LocErr, isBL, min_len, device)
     try:
         model = ts.make_model(le, ds, Fs, TrMat, pBL, cell_dims, nb_substeps, frame_len)
-        lpc = ts.loglik(model, per_track=True)[1]
         preds = []
         if do_preds:
             if nb_substeps != 1:
                 raise ValueError("state predictions require nb_substeps == 1")
             preds = ts.predict(model)[0]
+        if return_matrix:
+            LP = ts.ctx.sequence_matrix(model, 0)
+            S = len(np.asarray(ds))
+            n = int(round(np.log(LP.shape[1]) / np.log(S)))
+            return LP, get_all_Bs(n, S)[None], preds
+        lpc = ts.loglik(model, per_track=True)[1]
         return lpc[:, None], None, preds
     finally:
         ts.close()

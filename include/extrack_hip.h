@@ -50,7 +50,7 @@
 extern "C" {
 #endif
 
-#define EXTRACK_ABI_VERSION 4
+#define EXTRACK_ABI_VERSION 5
 
 #define EXTRACK_OK 0
 #define EXTRACK_E_INVALID (-1)     /* bad argument / unsupported configuration */
@@ -121,6 +121,14 @@ int extrack_loglik(extrack_ctx* ctx, const extrack_model* model, double* total_l
 /* Enqueues the evaluation on the context's stream and leaves the scalar in device memory
  * (d_total_ll, 8 bytes, device pointer) without synchronising - for a following RCCL all-reduce. */
 int extrack_loglik_async(extrack_ctx* ctx, const extrack_model* model, double* d_total_ll);
+
+/* Per-sequence log-probabilities of one bucket, the first return value of P_Cs_inter_bound_stats (extrack/tracking.py:109-318, returned
+ * at :318): lp host [n][n_cols], column i = the sequence of states whose digit c is (i / n_states^c) % n_states, c = 0 the newest state
+ * (get_all_Bs, tracking.py:746-757); n_cols = extrack_sequence_columns(n_states, len, nb_substeps, frame_len, isBL) with isBL =
+ * (len != model->max_len).  The likelihood path never forms this matrix (it is reduced in the kernel): this entry point exists for
+ * callers of the reference function that read it, on small inputs (n * n_states^(frame_len + nb_substeps) doubles cross the host). */
+int64_t extrack_sequence_columns(int32_t n_states, int32_t len, int32_t nb_substeps, int32_t frame_len, int32_t isBL);
+int extrack_sequence_matrix(extrack_ctx* ctx, const extrack_model* model, int32_t bucket_id, double* lp, int64_t n_cols);
 
 /* State posteriors of one bucket: preds host [n][len][S].  model->nb_substeps must be 1
  * (predict_Bs forces it, extrack/tracking.py:839). */

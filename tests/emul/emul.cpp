@@ -20,6 +20,7 @@
 #include "../../extrack_amd/csrc/xt_reg2.h"
 #include "../../extrack_amd/csrc/xt_gradr.h"
 #include "../../extrack_amd/csrc/xt_rev.h"
+#include "../../extrack_amd/csrc/xt_seqmat.h"
 #include "../../extrack_amd/csrc/xt_tables.h"
 #include "../../extrack_amd/csrc/xt_th.h"
 
@@ -111,6 +112,20 @@ bool emul_r2(int F, int D, int K, int KS, int NP, const XtKernelArgs& a, const X
 bool emul_gradr(int G, int D, int K, int NPC, const XtKernelArgs& a, const XtGradArgs& ga, int nblocks, int threads, size_t lds_doubles);  // emul_gradr.cpp
 bool emul_rev(int G, int D, int K, const XtKernelArgs& a, const XtRevArgs& ra, int nblocks, int threads, size_t lds_doubles);  // emul_rev.cpp
 
+// per-sequence matrix (xt_seqmat.h): raw output buffer [N][E][G] of the NEXT xt_emul_run call, which then runs the general kernel body
+static double* g_seq_raw = nullptr;
+extern "C" void xt_emul_set_seq_out(double* raw) { g_seq_raw = raw; }
+extern "C" long long xt_emul_seq_columns(int S, int L, int NS, int F, int isBL) { return xt_seq_columns(S, L, NS, F, isBL); }
+extern "C" int xt_emul_seq_reorder(int S, int NS, int F, long long N, int L, int isBL, double pBL, const double* TrMat, const double* p_stay,
+                                   const double* raw, double* lp)
+{
+    XtConfig cfg;
+    if (!xt_build_config(S, NS, F, cfg).empty()) return -1;
+    XtModelHost m{S, NS, 1, {0, 0, 0}, 0.0, 0.0, pBL, nullptr, nullptr, TrMat, p_stay};
+    xt_seq_reorder(cfg, m, N, L, isBL, raw, lp);
+    return 0;
+}
+
 extern "C" int xt_emul_run(const double* tracks, const double* sigma, long long N, int L, int D, int KS, int S, int NS, int F,
                            int isBL, int min_len, int locerr_mode, int locerr_dims, const double* locerr, double slope,
                            double offset, double pBL, const double* ds, const double* Fs, const double* TrMat,
@@ -177,7 +192,12 @@ extern "C" int xt_emul_run(const double* tracks, const double* sigma, long long 
         info[2] = (int)l.lds_bytes;
         info[3] = cfg.E;
     }
-    if (xt_use_reg2(S, NS, F) && !preds && getenv("XT_EMUL_REG2")) {
+    double* const seq_raw = g_seq_raw;
+    g_seq_raw = nullptr;
+    l.a.seq_out = seq_raw;
+    if (seq_raw) {
+        if (!xt_dispatch(cfg.G, D, K, preds != 0, l)) return -3;
+    } else if (xt_use_reg2(S, NS, F) && !preds && getenv("XT_EMUL_REG2")) {
         XtGradArgs ga;
         memset(&ga, 0, sizeof(ga));
         if (info) {
@@ -722,7 +742,7 @@ extern "C" int xt_emul_grad(const double* tracks, const double* sigma, long long
         memset(&ra, 0, sizeof(ra));
         std::vector<double> gp2((size_t)nblocks * (1 + TB), 0.0);
         ra.log_stride = (int64_t)std::max(L - 2, 1) * xt_rev_step_doubles(cfg.NG, D, K);
-        std::vector<double> logbuf((size_t)nblocks * tpbr * ra.log_stride, 0.0);
+        std::vector<double> logbuf((size_t)nblocks * tpbr * ra.log_stride, xt_emul_poison() ? NAN : 0.0);
         ra.gpartials = gp2.data();
         ra.log = logbuf.data();
         ra.TB = TB;

@@ -1,6 +1,7 @@
 // TEST INFRASTRUCTURE ONLY: the CPU-thread execution context the kernel bodies are compiled against in tests/emul (one std::thread per
 // GPU thread, pthread barriers for __syncthreads and for the lock-step of a wavefront).  Shared by emul.cpp and emul_r2.cpp.
 #pragma once
+#include <math.h>
 #include <pthread.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -8,6 +9,12 @@
 
 #include <thread>
 #include <vector>
+
+static inline bool xt_emul_poison()
+{
+    const char* e = getenv("XT_EMUL_POISON");
+    return !(e && e[0] == '0');
+}
 
 struct HostCtx {
     int tid_, nthreads_, block_, nblocks_;
@@ -128,7 +135,7 @@ static void th_emul_blocks(int nblocks, int threads, size_t lds_doubles, Body bo
 {
     const int nw = threads / 64;
     for (int b = 0; b < nblocks; ++b) {
-        std::vector<double> smem(lds_doubles + 16, 0.0);
+        std::vector<double> smem(lds_doubles + 16, xt_emul_poison() ? NAN : 0.0);  // the device does not clear LDS: start from NaN (XT_EMUL_POISON=0: from zeros)
         pthread_barrier_t bar;
         pthread_barrier_init(&bar, nullptr, threads);
         std::vector<pthread_barrier_t> wb(nw);

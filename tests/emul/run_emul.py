@@ -14,7 +14,7 @@ def lib():
         so = os.path.join(HERE, "libxt_emul.so")
         src = os.path.join(HERE, "emul.cpp")
         hdrs = [os.path.join(HERE, "..", "..", "extrack_amd", "csrc", h) for h in ("xt_kernel.h", "xt_math.h", "xt_tables.h", "xt_dispatch.h", "xt_th.h", "xt_entry.h", "xt_fast2.h", "xt_grad.h",
-                                                                                             "xt_grad_host.h", "xt_hist.h", "xt_hist_host.h", "xt_reg2.h", "xt_gradr.h", "xt_rev.h")]
+                                                                                             "xt_grad_host.h", "xt_hist.h", "xt_hist_host.h", "xt_reg2.h", "xt_gradr.h", "xt_rev.h", "xt_seqmat.h")]
         if not os.path.exists(so) or any(os.path.getmtime(f) > os.path.getmtime(so) for f in [src, os.path.join(HERE, "emul_r2.cpp"), os.path.join(HERE, "emul_gradr.cpp"), os.path.join(HERE, "emul_rev.cpp"), os.path.join(HERE, "emul_ctx.h")] + hdrs):
             import subprocess
             units = ["emul.cpp", "emul_r2.cpp", "emul_gradr.cpp", "emul_rev.cpp"]  # compiled side by side: emul_r2.cpp unrolls the whole step loop per instance
@@ -55,6 +55,26 @@ def run(Cs, LE, ds, Fs, T, pBL, isBL, p_stay, ns, F, min_len, preds=False, nbloc
     if rc != 0:
         raise RuntimeError("emul rc=%d" % rc)
     return ll, pr, tot.value, list(info)
+
+
+def run_seq_matrix(Cs, LE, ds, Fs, T, pBL, isBL, p_stay, ns, F, min_len):
+    """Per-sequence log-probabilities LP[N, nB] in the reference's column order (P_Cs_inter_bound_stats' first return value): the general
+    kernel body with the raw per-(sequence, new digits) output, then the host mapping of csrc/xt_seqmat.h."""
+    Cs = np.ascontiguousarray(Cs, float)
+    N, L, D = Cs.shape
+    S = len(ds)
+    G, E = S ** ns, S ** F
+    raw = np.full((N, E, G), np.nan)
+    lib().xt_emul_set_seq_out(dp(raw))
+    run(Cs, LE, ds, Fs, T, pBL, 0, p_stay, ns, F, min_len)  # without the leaving term: the mapping adds it per expanded sequence
+    lib().xt_emul_seq_columns.restype = C.c_longlong
+    nb = lib().xt_emul_seq_columns(S, L, ns, F, int(isBL))
+    lp = np.zeros((N, nb))
+    T, p_stay = np.ascontiguousarray(T, float), np.ascontiguousarray(p_stay, float)
+    rc = lib().xt_emul_seq_reorder(S, ns, F, C.c_longlong(N), L, int(isBL), C.c_double(pBL), dp(T), dp(p_stay), dp(raw), dp(lp))
+    if rc != 0:
+        raise RuntimeError("emul seq reorder rc=%d" % rc)
+    return lp
 
 
 def run_multi(buckets, locerr, ds, Fs, T, pBL, p_stay, ns, F, min_len, max_len, blocks_per_bucket):

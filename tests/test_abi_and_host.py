@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert sorted(_lib.EXPORTS) == declared
-    assert lib.extrack_abi_version() == 4
+    assert lib.extrack_abi_version() == 5
 
 
 def test_no_silent_cpu_fallback():

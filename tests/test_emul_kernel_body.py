@@ -205,3 +205,31 @@ def test_multi_bucket_single_launch(S, ns, F, monkeypatch):
     for o, r in zip(outs, ref):
         assert np.abs(o - r).max() < 1e-10
     assert abs(tot - sum(r.sum() for r in ref)) < 1e-9
+
+
+def test_sequence_matrix_on_golden_cases(kernel_cases):
+    """P_Cs_inter_bound_stats' per-sequence matrix LP[N, nB] (the reference's first return value, extrack/tracking.py:318): the general
+    kernel body's raw per-(sequence, new digits) output mapped to the reference's column order by csrc/xt_seqmat.h, against the matrices
+    the reference produced (stored in the golden cases with nB <= 256): 2-4 states, nb_substeps 1-2, isBL 0 / 1, tracks shorter and
+    longer than the window.  Entries are compared where the reference is finite; -inf / underflowed entries must be <= -700."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "emul"))
+    import run_emul as E
+    meta, data = kernel_cases
+    n, worst, seen = 0, 0.0, set()
+    for row in meta:
+        x = case_inputs(row, data)
+        if x["LP"] is None or row["S"] ** row["F"] > 300:
+            continue
+        key = (row["S"], row["ns"], row["F"], row["isBL"], x["Cs"].shape[1], x["Cs"].shape[2], x["LE"].shape[1:])
+        if key in seen:
+            continue
+        seen.add(key)
+        ps = O.p_stay_table(x["ds"], row["S"], row["ns"], row["cell_dims"])
+        lp = E.run_seq_matrix(x["Cs"], x["LE"], x["ds"], x["Fs"], x["T"], row["pBL"], row["isBL"], ps, row["ns"], row["F"], row["min_len"])
+        assert lp.shape == x["LP"].shape, (row, lp.shape, x["LP"].shape)
+        fin = np.isfinite(x["LP"]) & (x["LP"] > -650)
+        worst = max(worst, np.abs(lp[fin] - x["LP"][fin]).max())
+        assert np.all(lp[~fin] < -600)
+        n += 1
+    assert n >= 40 and worst < 1e-9, (n, worst)

@@ -155,6 +155,45 @@ def test_emulated_reverse_mode_gradient_body(S, ns, F, L, N, D, K, isBL):
     assert rel.max() < 1e-6, [(d[0], a, b) for d, a, b, r in zip(dirs, g, fd, rel) if r > 1e-6]
 
 
+@pytest.mark.parametrize("S,F,L,N,D,KS,affine,gg", [(2, 4, 9, 7, 2, 1, True, 0), (2, 4, 9, 7, 2, 1, True, 4), (2, 4, 9, 7, 2, 1, True, 5), (3, 3, 8, 5, 2, 2, True, 5),
+                                                     (3, 3, 8, 5, 2, 2, False, 5), (3, 3, 8, 5, 2, 2, True, 3), (2, 5, 35, 3, 1, 1, True, 5)])
+def test_emulated_gradient_bodies_with_per_peak_localisation_errors(S, F, L, N, D, KS, affine, gg):
+    """Per-peak localisation errors (input_LocErr; affine = LocErr_type 4: clip(sigma * slope + offset, 1e-6), extrack/tracking.py:
+    946-955): the gradient bodies - gg 0: xt_grad.h, 3 / 4: xt_gradr.h, 5: reverse mode xt_rev.h - against Richardson differences of the
+    pinned oracle along every model direction plus slope and offset (some peaks sit below the clip, where the derivative is 0)."""
+    import run_emul as E
+    from extrack_amd import synth
+    from oracle import oracle_np as O
+    Ds, T, Fs = _model(S, S * 10 + F)
+    Cs = synth.brownian_tracks(N, L, Ds, T, Fs, seed=S + F, dims=D)
+    rng = np.random.default_rng(5)
+    sig = rng.uniform(0.01, 0.04, (N, L, KS))
+    sig[0, 1] = 1e-9  # below the clip of the affine mode
+    slope, offset = (1.2, -0.003) if affine else (None, None)
+    ds2, cell, pBL, min_len, ns, isBL = 2 * Ds * 0.02, [1.0], 0.1, 3, 1, 1
+
+    def le_of(sl, of):
+        return np.maximum(sig * sl + of, 1e-6) if affine else sig
+
+    dirs = [d for d in model_directions(S, 1, ns, ds2, T, np.array([0.02]), cell) if not d[0].startswith("le")]
+    tang = [d[1] for d in dirs] + ([dict(slope=1.0), dict(offset=1.0)] if affine else [])
+    ll, tot, g = E.run_grad(Cs, sig, np.sqrt(ds2), Fs, T, pBL, isBL, O.p_stay_table(np.sqrt(ds2), S, ns, cell), ns, F, min_len, tang, generic_g=gg,
+                            slope=slope, offset=offset)
+    ref = O.proba_cs(Cs, le_of(slope or 1.0, offset or 0.0), np.sqrt(ds2), Fs, T, pBL, isBL, cell, ns, F, min_len)
+    assert np.abs(ll - ref).max() < 1e-10 and abs(tot - ref.sum()) < 1e-12 * abs(tot)
+
+    def total(x, d, dsl=0.0, dof=0.0):
+        return O.proba_cs(Cs, le_of((slope or 1.0) + x * dsl, (offset or 0.0) + x * dof), np.sqrt(ds2 + x * d.get("ds2", 0.0)), Fs + x * d.get("Fs", 0.0),
+                          T + x * d.get("T", 0.0), pBL + x * d.get("pBL", 0.0), isBL, cell, ns, F, min_len).sum()
+
+    fd = [_richardson(lambda x: total(x, d), h) for _, _, d, h in dirs]
+    if affine:
+        fd += [_richardson(lambda x: total(x, {}, dsl=1.0), 1e-4), _richardson(lambda x: total(x, {}, dof=1.0), 1e-6)]
+    fd = np.array(fd)
+    rel = np.abs(g - fd) / np.maximum(np.abs(fd), 1e-3 * np.abs(fd).max())
+    assert rel.max() < 1e-6, (g, fd)
+
+
 def test_host_chain_rule_matches_finite_differences():
     """params (with expr constraints and bounds) -> model arrays: the complex-step tangents against central differences, for every
     Matrix_type and a D0 sitting exactly at 0 (where d ds / d D is infinite but d ds^2 / d D is not)."""

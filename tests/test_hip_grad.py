@@ -96,6 +96,47 @@ def test_parameter_gradient_of_the_fit_objective_c1():
         assert abs(gi - fd) < 1e-6 * max(abs(fd), 1e-3 * np.abs(g).max()), (n, gi, fd)
 
 
+@pytest.mark.parametrize("path", [None, "gradr", "lds"])
+@pytest.mark.parametrize("S", [2, 3])
+def test_parameter_gradient_with_per_peak_errors(S, path, monkeypatch):
+    """input_LocErr + LocErr_type 4 (error = clip(sigma * slope + offset), extrack/tracking.py:946-955): d(-sum LL)/d(free parameters) incl.
+    slope and offset from one gradient evaluation - path None: the launcher's choice (reverse mode xt_rev.h), "gradr" / "lds": the
+    forward-mode kernel families - against Richardson central differences of the SAME context's objective (whose values the parity
+    tests pin to the oracle)."""
+    from extrack_amd import gradient, synth, tracking as T
+    if path:
+        monkeypatch.setenv("EXTRACK_GRAD_PATH", path)
+    rng = np.random.default_rng(S)
+    Ds = [0.0, 0.05, 0.3][:S] if S == 3 else [0.0, 0.25]
+    Tm = np.full((S, S), 0.06) + np.eye(S) * (1 - 0.06 * S)
+    tr, sg = {}, {}
+    for L in (6, 9, 14):
+        tr[str(L)] = synth.brownian_tracks(40, L, Ds, Tm, [1.0 / S] * S, seed=L)
+        sg[str(L)] = rng.uniform(0.012, 0.03, (40, L, 1))
+    p = T.generate_params(nb_states=S, LocErr_type=4, estimated_Ds=[1e-4, 0.05, 0.3][:S] if S == 3 else [1e-4, 0.25], estimated_Fs=[1.0 / S] * (S - 1),
+                          estimated_transition_rates=0.07, slope_offsets_estimates=[1.1, 0.002])
+    names = gradient.free_names(p)
+    assert "slope_LocErr" in names and "offset_LocErr" in names
+    _, lst, sig = T.engine.sort_buckets(tr, sg)
+    ts = T.TrackSet(lst, sig)
+    try:
+        v, g = gradient.objective_and_gradient(p, ts, 0.02, [1.0], S, 1, 5, names=names)
+
+        def f(n, x):
+            q = p.copy()
+            q[n].value = p[n].value + x
+            q.update_constraints()
+            return -ts.loglik(T._objective_model(q, ts, 0.02, [1.0], sig, S, 1, 5, 1))
+
+        assert abs(v - f(names[0], 0.0)) < 1e-12 * abs(v)
+        for n, gi in zip(names, g):
+            h = 1e-3 * max(abs(p[n].value), 1e-3)
+            fd = (4 * (f(n, h / 2) - f(n, -h / 2)) / h - (f(n, h) - f(n, -h)) / (2 * h)) / 3
+            assert abs(gi - fd) < 2e-6 * max(abs(fd), 1e-3 * np.abs(g).max()), (n, gi, fd)
+    finally:
+        ts.close()
+
+
 def test_c1_fit_analytic_gradient_same_optimum_fewer_calls(capsys):
     """configs[0] end to end: param_fitting with the analytic gradient vs the reference-style finite-difference BFGS on the same
     data and starting point: same optimum (objective within 1e-6 relative, parameters within 1 %), >= 5x fewer objective calls."""

@@ -23,7 +23,7 @@ def _params(vals):
 def test_library_loaded_and_device():
     from extrack_amd import _lib
     ctx = _lib.Context(0)
-    assert ctx._lib.extrack_abi_version() == 4
+    assert ctx._lib.extrack_abi_version() == 5
     ctx.close()
 
 
@@ -62,6 +62,35 @@ def test_kernel_cases_golden(kernel_cases):
             worst_pr = max(worst_pr, dp)
         n += 1
     print("cases", n, "worst |dLL|", worst_ll, "worst |dpred|", worst_pr)
+
+
+def test_sequence_matrix_and_cur_Bs_golden(kernel_cases):
+    """P_Cs_inter_bound_stats(return_matrix=True): the reference's full return contract (extrack/tracking.py:318) - LP[N, nB] against every
+    matrix the reference produced for the golden cases (those with nB <= 256: 2-5 states, nb_substeps 1-3, isBL 0/1, per-dim and
+    per-peak errors, tracks shorter and longer than the window), cur_Bs against the reference's digit layout (get_all_Bs, tracking.py:
+    746-757) and the matrix's logsumexp against LP_C."""
+    from extrack_amd import tracking as T
+    meta, data = kernel_cases
+    n, worst = 0, 0.0
+    for row in meta:
+        x = case_inputs(row, data)
+        if x["LP"] is None:
+            continue
+        LP, cur_Bs, _ = T.P_Cs_inter_bound_stats(x["Cs"], x["LE"], x["ds"], x["Fs"], x["T"], row["pBL"], row["isBL"], row["cell_dims"],
+                                                 row["ns"], row["F"], 0, row["min_len"], return_matrix=True)
+        assert LP.shape == x["LP"].shape, (row, LP.shape)
+        fin = np.isfinite(x["LP"]) & (x["LP"] > -650)
+        worst = max(worst, np.abs(LP[fin] - x["LP"][fin]).max())
+        assert np.all(LP[~fin] < -600)
+        S, nd = row["S"], cur_Bs.shape[2]
+        assert cur_Bs.shape == (1, LP.shape[1], nd) and S ** nd == LP.shape[1]
+        i = np.arange(LP.shape[1])
+        assert all(np.array_equal(cur_Bs[0, :, k], (i // S ** k) % S) for k in range(nd))
+        mx = LP.max(1, keepdims=True)
+        assert np.abs(np.log(np.exp(LP - mx).sum(1)) + mx[:, 0] - x["LPC"]).max() < TOL_LL
+        n += 1
+    print("sequence matrices checked:", n, "worst |dLP|", worst)
+    assert n >= 200 and worst < 1e-9, (n, worst)
 
 
 def _tracks(data, pre, keys):
