@@ -1,6 +1,7 @@
-"""Differential fuzz of the gradient kernel families on the GPU box: the launcher's choice (xt_reg2.h / xt_gradr.h) against the LDS-resident
-kernel (xt_grad.h, itself pinned to Richardson differences of the oracle in tests/test_hip_grad.py) on random models, random DENSE tangent
-directions, all localisation-error modes, lengths around the window.  usage: gpu_grad_fuzz.py [seed] [cases]"""
+"""Differential fuzz of the gradient kernel families on the GPU box: the launcher's choice (xt_reg2.h / xt_rev.h / xt_gradr.h) - or the family
+named by the third argument (EXTRACK_GRAD_PATH value: rev, gradr, reg2) - against the LDS-resident kernel (xt_grad.h, itself pinned to Richardson
+differences of the oracle in tests/test_hip_grad.py) on random models, random DENSE tangent directions, all localisation-error modes, lengths
+around the window.  usage: gpu_grad_fuzz.py [seed] [cases] [path]"""
 import os
 import sys
 import time
@@ -13,6 +14,7 @@ from oracle import oracle_np as O  # noqa: E402
 
 seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 ncases = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+other = sys.argv[3] if len(sys.argv) > 3 else None
 rng = np.random.default_rng(seed)
 t0 = time.time()
 bad = done = 0
@@ -67,6 +69,8 @@ for case in range(ncases):
             os.environ.pop("EXTRACK_GRAD_PATH", None)
             if path == "lds":
                 os.environ["EXTRACK_GRAD_PATH"] = "lds"
+            elif other:
+                os.environ["EXTRACK_GRAD_PATH"] = other
             ts = T.TrackSet([Cs], None if sig is None else [sig], min_len=min(min_len, L), max_len=max_len)
             model = ts.make_model(LE, ds, Fs, Tm, pBL, cell, ns, F, slope_offset=so)
             try:
