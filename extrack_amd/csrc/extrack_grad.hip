@@ -226,7 +226,14 @@ static int xt_grad_enqueue(extrack_ctx* ctx, const extrack_model* m, int32_t n_d
             const void* kp = n_dir > 0 && xt_rev_supported(c.G, c.NG) ? xt_rev_kernel_ptr(c.G, D, K) : nullptr;
             const int tpb = std::max(1, 256 / c.NG), threads = (tpb * c.NG + 63) / 64 * 64;
             const size_t lds = xt_rev_lds_bytes(c.S, c.G, c.EP, D, K, tpb, threads);
-            const bool use_rev = kp && lds <= 160 * 1024 && (ctx->grad_rev == 2 || (ctx->grad_rev == 1 && ctx->grad_reg2 == 1 && !r2));
+            // the merged-state logs (one region per track slot of every block) must fit the budget with at least one block per two CUs:
+            // very long tracks go to the forward-mode kernels instead
+            int Lmax0 = 2;
+            for (auto& d : descs) Lmax0 = std::max(Lmax0, (int)d.L);
+            const size_t slot_doubles = (size_t)tpb * std::max(Lmax0 - 2, 1) * xt_rev_step_doubles(c.NG, D, K);
+            const size_t max_blocks = (ctx->rev_log_mb << 20) / (slot_doubles * sizeof(double));
+            const bool use_rev = kp && lds <= 160 * 1024 && max_blocks >= (size_t)ctx->n_cu / 2 &&
+                                 (ctx->grad_rev == 2 || (ctx->grad_rev == 1 && ctx->grad_reg2 == 1 && !r2));
             if (use_rev) {
                 if (lds > 64 * 1024) XT_HIP(ctx, hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 auto key = std::make_pair(kp, std::make_pair(threads, lds));
@@ -242,7 +249,7 @@ static int xt_grad_enqueue(extrack_ctx* ctx, const extrack_model* m, int32_t n_d
                 xt_fill_args_from_config(c, a);
                 XtRevArgs ra;
                 memset(&ra, 0, sizeof(ra));
-                const double target = (double)occ * ctx->n_cu * ctx->rev_oversub;
+                const double target = std::min((double)occ * ctx->n_cu * ctx->rev_oversub, (double)max_blocks);
                 double wsum = 0.0;
                 int Lmax = 2;
                 std::vector<int64_t> nbatch(descs.size());

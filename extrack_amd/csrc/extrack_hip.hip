@@ -104,6 +104,7 @@ extern "C" int extrack_create(int device_id, extrack_ctx** out)
     if (const char* ev = getenv("EXTRACK_GRAD_PATH")) c->grad_reg2 = strcmp(ev, "lds") == 0 ? 0 : (strcmp(ev, "gradr") == 0 ? 2 : 1);
     if (const char* ev = getenv("EXTRACK_GRAD_PATH")) c->grad_rev = strcmp(ev, "rev") == 0 ? 2 : (strcmp(ev, "auto") == 0 ? 1 : 0);
     if (const char* ev = getenv("EXTRACK_REV_OVERSUB")) c->rev_oversub = std::max(1, atoi(ev));
+    if (const char* ev = getenv("EXTRACK_REV_LOG_MB")) c->rev_log_mb = (size_t)std::max(1, atoi(ev));
     if (const char* ev = getenv("EXTRACK_GRADR_NPC")) c->gradr_npc = atoi(ev) == 4 ? 4 : (atoi(ev) == 3 ? 3 : 0);
     if (const char* ev = getenv("EXTRACK_TH_TT")) {
         int v = atoi(ev);

@@ -137,6 +137,30 @@ def test_parameter_gradient_with_per_peak_errors(S, path, monkeypatch):
         ts.close()
 
 
+def test_reverse_mode_log_budget_falls_back_to_forward_mode(monkeypatch):
+    """The reverse-mode kernels log the merged state of every step per track slot (device memory proportional to the track length); when
+    the budget (EXTRACK_REV_LOG_MB) does not hold one block per two CUs the launcher takes the forward-mode kernels: same gradient."""
+    from extrack_amd import gradient, synth, tracking as T
+    Tm = np.full((3, 3), 0.05) + np.eye(3) * 0.85
+    tr = {"200": synth.brownian_tracks(64, 200, [0.0, 0.05, 0.3], Tm, [0.3, 0.3, 0.4], seed=4)}
+    p = T.generate_params(nb_states=3, LocErr_type=1, estimated_Ds=[1e-4, 0.05, 0.3], estimated_LocErr=[0.02], estimated_Fs=[0.3, 0.3], estimated_transition_rates=0.06)
+    names = gradient.free_names(p)
+    _, lst, _ = T.engine.sort_buckets(tr)
+    out = {}
+    for mb in ("16384", "1"):
+        monkeypatch.setenv("EXTRACK_REV_LOG_MB", mb)
+        ts = T.TrackSet(lst)
+        try:
+            out[mb] = gradient.objective_and_gradient(p, ts, 0.02, [1.0], 3, 1, 5, names=names)
+            info = ts.ctx.last_launch_info()
+        finally:
+            ts.close()
+        out[mb + "lds"] = info["lds_bytes"]
+    assert out["16384lds"] != out["1lds"]  # two different kernel families served the two calls
+    assert abs(out["1"][0] - out["16384"][0]) < 1e-12 * abs(out["1"][0])
+    assert np.abs(out["1"][1] - out["16384"][1]).max() < 1e-9 * np.abs(out["1"][1]).max()
+
+
 def test_c1_fit_analytic_gradient_same_optimum_fewer_calls(capsys):
     """configs[0] end to end: param_fitting with the analytic gradient vs the reference-style finite-difference BFGS on the same
     data and starting point: same optimum (objective within 1e-6 relative, parameters within 1 %), >= 5x fewer objective calls."""
