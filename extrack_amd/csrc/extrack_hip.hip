@@ -8,8 +8,18 @@
 #include "xt_fast2.h"
 #include "xt_reg2.h"
 
+// Waves per SIMD the register allocator is asked to allow (workgroups of 256 threads).  Likelihood kernels: 4, except 4 members per group
+// (4 states: 66 ms unbounded against 74 ms at 3 on the 5e5 x 60 set, frame_len 5).  Posterior kernels (226 VGPRs unbounded = 2 waves):
+// 3 waves (168 VGPRs, 27-60 spilled dwords) - measured r03: C5 (4 states, 5e5 x 60, frame_len 5) 318 -> 265 ms, 4 waves 365 ms;
+// 2 states 1e6 x 30 frame_len 6 18.3 -> 15.2 ms; 3 states 2e5 x 30 frame_len 6 49.6 -> 44.2 ms.
+#ifndef XT_G4_WAVES
+#define XT_G4_WAVES 1
+#endif
+#ifndef XT_PREDS_WAVES
+#define XT_PREDS_WAVES 3
+#endif
 template <int G_, int D, int K, bool PREDS, int MAXT>
-__global__ void __launch_bounds__(MAXT, (MAXT == 256 && !PREDS && G_ != 4 ? 4 : 1)) xt_track_kernel(XtKernelArgs a)
+__global__ void __launch_bounds__(MAXT, (MAXT == 256 && !PREDS ? (G_ != 4 ? 4 : XT_G4_WAVES) : (MAXT == 256 && PREDS ? XT_PREDS_WAVES : 1))) xt_track_kernel(XtKernelArgs a)
 {
     DevCtx cx;
     xt_track_body<G_, D, K, PREDS>(a, cx);
