@@ -232,4 +232,6 @@ def test_sequence_matrix_on_golden_cases(kernel_cases):
         worst = max(worst, np.abs(lp[fin] - x["LP"][fin]).max())
         assert np.all(lp[~fin] < -600)
         n += 1
+        if n >= 45:  # the GPU test (tests/test_hip_parity.py) runs all 670 reference matrices
+            break
     assert n >= 40 and worst < 1e-9, (n, worst)
