@@ -223,9 +223,12 @@ static int xt_grad_enqueue(extrack_ctx* ctx, const extrack_model* m, int32_t n_d
         // ---- reverse mode (xt_rev.h): one forward + one backward sweep whatever the number of directions; the adjoint of the model blob
         // is contracted with the tangent blocks by a small kernel.  3 / 4 members per group by default (r03: C3, 13 directions)
         {
-            const void* kp = n_dir > 0 && xt_rev_supported(c.G, c.NG) ? xt_rev_kernel_ptr(c.G, D, K) : nullptr;
             const int tpb = std::max(1, 256 / c.NG), threads = (tpb * c.NG + 63) / 64 * 64;
-            const size_t lds = xt_rev_lds_bytes(c.S, c.G, c.EP, D, K, tpb, threads);
+            // one exchange buffer (two barriers per step) where two do not leave room for a second workgroup on the CU
+            const size_t lds2 = xt_rev_lds_bytes(c.S, c.G, c.EP, D, K, tpb, threads, 2), lds1 = xt_rev_lds_bytes(c.S, c.G, c.EP, D, K, tpb, threads, 1);
+            const int nbuf = (2 * lds2 > 160 * 1024 && 2 * lds1 <= 160 * 1024) ? 1 : 2;
+            const size_t lds = nbuf == 1 ? lds1 : lds2;
+            const void* kp = n_dir > 0 && xt_rev_supported(c.G, c.NG) ? xt_rev_kernel_ptr(c.G, D, K, nbuf) : nullptr;
             // the merged-state logs (one region per track slot of every block) must fit the budget with at least one block per two CUs:
             // very long tracks go to the forward-mode kernels instead
             int Lmax0 = 2;

@@ -7,30 +7,36 @@
 #ifndef XT_REV_WAVES
 #define XT_REV_WAVES 2
 #endif
-template <int G_, int D, int K>
+template <int G_, int D, int K, int NBUF>
 __global__ void __launch_bounds__(256, XT_REV_WAVES) xt_rev_kernel(XtKernelArgs a, XtRevArgs ra)
 {
     DevCtx cx;
-    xt_rev_body<G_, D, K>(a, ra, cx);
+    xt_rev_body<G_, D, K, NBUF>(a, ra, cx);
 }
 
-template <int G_>
+template <int G_, int NBUF>
 static const void* rev_dk(int D, int K)
 {
-    if (D == 1 && K == 1) return (const void*)xt_rev_kernel<G_, 1, 1>;
-    if (D == 2 && K == 1) return (const void*)xt_rev_kernel<G_, 2, 1>;
-    if (D == 2 && K == 2) return (const void*)xt_rev_kernel<G_, 2, 2>;
-    if (D == 3 && K == 1) return (const void*)xt_rev_kernel<G_, 3, 1>;
-    if (D == 3 && K == 3) return (const void*)xt_rev_kernel<G_, 3, 3>;
+    if (D == 1 && K == 1) return (const void*)xt_rev_kernel<G_, 1, 1, NBUF>;
+    if (D == 2 && K == 1) return (const void*)xt_rev_kernel<G_, 2, 1, NBUF>;
+    if (D == 2 && K == 2) return (const void*)xt_rev_kernel<G_, 2, 2, NBUF>;
+    if (D == 3 && K == 1) return (const void*)xt_rev_kernel<G_, 3, 1, NBUF>;
+    if (D == 3 && K == 3) return (const void*)xt_rev_kernel<G_, 3, 3, NBUF>;
     return nullptr;
 }
 
-// Kernel address for (members per group, dims, loc.-error dims); nullptr: not built.
-const void* xt_rev_kernel_ptr(int G, int D, int K)
+// Kernel address for (members per group, dims, loc.-error dims, exchange buffers per track: 1 | 2); nullptr: not built.
+const void* xt_rev_kernel_ptr(int G, int D, int K, int nbuf)
 {
-    if (G == 2) return rev_dk<2>(D, K);
-    if (G == 3) return rev_dk<3>(D, K);
-    if (G == 4) return rev_dk<4>(D, K);
+    if (nbuf == 2) {
+        if (G == 2) return rev_dk<2, 2>(D, K);
+        if (G == 3) return rev_dk<3, 2>(D, K);
+        if (G == 4) return rev_dk<4, 2>(D, K);
+    } else if (nbuf == 1) {
+        if (G == 2) return rev_dk<2, 1>(D, K);
+        if (G == 3) return rev_dk<3, 1>(D, K);
+        if (G == 4) return rev_dk<4, 1>(D, K);
+    }
     return nullptr;
 }
 

@@ -314,6 +314,6 @@ size_t xt_desc_base(const extrack_ctx* ctx);
 size_t xt_max_grid(const extrack_ctx* ctx);
 __global__ void xt_reduce_partials(const double* __restrict__ partials, int n, double* __restrict__ out);
 const void* xt_r2_kernel(int F, int D, int K, int NP);  // extrack_reg2.hip: register-resident 2-state kernels, nullptr = not built
-const void* xt_rev_kernel_ptr(int G, int D, int K);  // extrack_rev.hip: reverse-mode gradient kernels (xt_rev.h)
+const void* xt_rev_kernel_ptr(int G, int D, int K, int nbuf);  // extrack_rev.hip: reverse-mode gradient kernels (xt_rev.h), 1 | 2 exchange buffers
 void xt_rev_project(hipStream_t st, const double* adj, const double* dblob, int TB, int n_dir, double* out);  // out[i] = <adj, dblob[i]>
 const void* xt_gradr_kernel_ptr(int G, int D, int K, int NPC);  // extrack_gradr.hip: register-resident gradient kernels (xt_gradr.h), NPC = 3 | 4

@@ -42,13 +42,15 @@ XT_HD int xt_rev_step_doubles(int NG, int D, int K) { return (1 + D + K) * NG + 
 XT_HD int xt_rev_xbuf_doubles(int EP, int D, int K) { return EP * (1 + D + K) + (EP + 1) / 2 + 1; }
 #define XT_REV_PART 16  // partial sums of the per-track total (two-level fixed-order sum)
 // per track slot: two exchange buffers, the partial sums, 2 ints
-XT_HD int xt_rev_track_doubles(int EP, int D, int K) { return 2 * xt_rev_xbuf_doubles(EP, D, K) + XT_REV_PART + 2; }
+// nbuf exchange buffers: 2 = one barrier per step; 1 = two barriers per step and half the LDS (taken when that lets a second workgroup on the CU:
+// 4 states, 5e5 x 60, frame_len 4: 136 -> 106 ms; where two workgroups fit anyway the second barrier costs 3 %)
+XT_HD int xt_rev_track_doubles(int EP, int D, int K, int nbuf) { return nbuf * xt_rev_xbuf_doubles(EP, D, K) + XT_REV_PART + 2; }
 // per-lane accumulators: log T (v = 0, 1, final), d2, l2[K], slope, offset, log Fs
 XT_HD constexpr int xt_rev_nacc(int G, int K) { return 4 * G + K + 3; }
-XT_HD size_t xt_rev_lds_bytes(int S, int G, int EP, int D, int K, int tpb, int threads)
+XT_HD size_t xt_rev_lds_bytes(int S, int G, int EP, int D, int K, int tpb, int threads, int nbuf)
 {
     const size_t fixed = (size_t)((xt_tab_doubles(S, G) + 1) & ~1);
-    size_t per = (size_t)tpb * ((size_t)xt_rev_track_doubles(EP, D, K) + xt_stage_doubles(D));
+    size_t per = (size_t)tpb * ((size_t)xt_rev_track_doubles(EP, D, K, nbuf) + xt_stage_doubles(D));
     const size_t red = (size_t)(xt_rev_nacc(G, K) + 1) * threads;  // block-level reduction of the accumulators (aliases the slots)
     if (red > per) per = red;
     return (fixed + per) * sizeof(double);
@@ -56,7 +58,7 @@ XT_HD size_t xt_rev_lds_bytes(int S, int G, int EP, int D, int K, int tpb, int t
 // the shift-register exchange needs whole sender groups: S^(F - NS) divisible by S^NS
 XT_HD bool xt_rev_supported(int G, int NG) { return G >= 2 && G <= 4 && NG >= G && NG % G == 0 && NG <= 256; }
 
-template <int G_, int D, int K, class Ctx>
+template <int G_, int D, int K, int NBUF, class Ctx>
 XT_HD void xt_rev_body(const XtKernelArgs& a, const XtRevArgs& ra, Ctx& cx)
 {
     int lb, nb;
@@ -77,10 +79,10 @@ XT_HD void xt_rev_body(const XtKernelArgs& a, const XtRevArgs& ra, Ctx& cx)
     const int g = tid - slot * NG;
     const bool tvalid = slot < a.TPB;
     const int xdoubles = xt_rev_xbuf_doubles(EP, D, K);
-    const int tdoubles = xt_rev_track_doubles(EP, D, K);
+    const int tdoubles = xt_rev_track_doubles(EP, D, K, NBUF);
     double* tr0 = smem + reg0 + (tvalid ? slot : 0) * tdoubles;
-    double* X[2] = {tr0, tr0 + xdoubles};
-    double* part = tr0 + 2 * xdoubles;            // [XT_REV_PART]
+    double* X[2] = {tr0, tr0 + (NBUF - 1) * xdoubles};
+    double* part = tr0 + NBUF * xdoubles;  // [XT_REV_PART]
     int* red_e = (int*)(part + XT_REV_PART);      // [0] exponent of the track total, [1] NaN-input flag
     double* spos = smem + reg0 + a.TPB * tdoubles + (tvalid ? slot : 0) * xt_stage_doubles(D);
     double* ssig = spos + XT_STAGE * D;
@@ -325,6 +327,7 @@ XT_HD void xt_rev_body(const XtKernelArgs& a, const XtRevArgs& ra, Ctx& cx)
                 XT_UNROLL
                 for (int k = 0; k < K; ++k) uu[Q][k] = xb[(1 + D + k) * EP + ridx[Q]];
             }
+            if (NBUF == 1) cx.sync();
         }
 
         // =========================== last position (+ leaving / bleaching term): LL of the track and the seeds of the backward sweep
@@ -560,6 +563,7 @@ XT_HD void xt_rev_body(const XtKernelArgs& a, const XtRevArgs& ra, Ctx& cx)
                 XT_UNROLL
                 for (int k = 0; k < K; ++k) nu[Q][k] = aj[Q] * U[k];
             }
+            if (NBUF == 1) cx.sync();
         }
         // ---- position 0: initial fractions and the localisation error of the first position
         if (L >= 3) {

@@ -110,7 +110,7 @@ struct EmulLauncher {
 
 bool emul_r2(int F, int D, int K, int KS, int NP, const XtKernelArgs& a, const XtGradArgs& ga, int nblocks);  // emul_r2.cpp
 bool emul_gradr(int G, int D, int K, int NPC, const XtKernelArgs& a, const XtGradArgs& ga, int nblocks, int threads, size_t lds_doubles);  // emul_gradr.cpp
-bool emul_rev(int G, int D, int K, const XtKernelArgs& a, const XtRevArgs& ra, int nblocks, int threads, size_t lds_doubles);  // emul_rev.cpp
+bool emul_rev(int G, int D, int K, int nbuf, const XtKernelArgs& a, const XtRevArgs& ra, int nblocks, int threads, size_t lds_doubles);  // emul_rev.cpp
 
 // per-sequence matrix (xt_seqmat.h): raw output buffer [N][E][G] of the NEXT xt_emul_run call, which then runs the general kernel body
 static double* g_seq_raw = nullptr;
@@ -746,8 +746,9 @@ extern "C" int xt_emul_grad(const double* tracks, const double* sigma, long long
         ra.gpartials = gp2.data();
         ra.log = logbuf.data();
         ra.TB = TB;
-        const size_t ldsd = xt_rev_lds_bytes(S, cfg.G, cfg.EP, D, K, tpbr, thr) / 8;
-        if (!emul_rev(cfg.G, D, K, l.a, ra, nblocks, thr, ldsd)) return -3;
+        const int nbuf = getenv("XT_EMUL_REV_NBUF") ? atoi(getenv("XT_EMUL_REV_NBUF")) : 2;  // the launcher picks 1 where two buffers leave no room for a second workgroup
+        const size_t ldsd = xt_rev_lds_bytes(S, cfg.G, cfg.EP, D, K, tpbr, thr, nbuf) / 8;
+        if (!emul_rev(cfg.G, D, K, nbuf, l.a, ra, nblocks, thr, ldsd)) return -3;
         std::vector<double> adj(TB, 0.0);
         for (int b = 0; b < nblocks; ++b) {
             out[0] += gp2[(size_t)b * (1 + TB)];
