@@ -190,7 +190,7 @@ struct extrack_ctx {
     int grad_reg2 = 1;  // gradient kernels: 1 = register-resident where built (xt_reg2.h for 2 states, else xt_gradr.h), 0 = the LDS-resident xt_grad.h
                         // only, 2 = xt_gradr.h before xt_reg2.h (tests); EXTRACK_GRAD_PATH = reg2 | lds | gradr
     int grad_rev = 1;   // reverse-mode kernels (xt_rev.h) for 3 / 4 members per group: 1 = where they win, 0 = never, 2 = wherever built; EXTRACK_GRAD_PATH = rev
-    int rev_oversub = 8;  // block generations per CU of the reverse-mode launch (each block owns a log region: fewer blocks, smaller cache footprint)
+    int rev_oversub = 16;  // block generations per CU of the reverse-mode launch (each block owns a log region: fewer blocks, smaller cache footprint)
     size_t rev_log_mb = 16384;   // budget of those log regions (EXTRACK_REV_LOG_MB): the launch uses fewer blocks to stay within it
     double* d_revlog = nullptr;  // merged-state logs of the reverse-mode kernels
     size_t revlog_cap = 0;       // doubles
