@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""configs[4] posteriors (5e5 tracks x 60, 4 states, frame_len 5) and the 4-state likelihood through the general kernel: kernel times with the
-shift-register LDS addressing (default) and with circular digit slots (EXTRACK_TRACK_SHIFT=0), results compared.
-usage: gpu_pred_c5.py [scale]"""
+"""configs[4] posteriors (5e5 tracks x 60, 4 states, frame_len 5) and the 4-state likelihood through the general kernel (frame_len 4, 5, 6):
+kernel times, two rounds.  (Used in round 3 for the waves-per-SIMD A/B of the posterior kernels and for the shift-register addressing
+experiment)  usage: gpu_pred_c5.py [scale]"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -22,15 +22,14 @@ for k, v in vals.items():
     p.add(k, value=v)
 res = {}
 for rnd in range(2):
-    for sh in ("1", "0"):
-        os.environ["EXTRACK_TRACK_SHIFT"] = sh
+    for sh in ("-",):
         ts = T.TrackSet([Cs])
         m5 = T._objective_model(p, ts, 0.02, [1.0], None, 4, 1, 5, 1)
         for _ in range(2):
             pr = ts.predict(m5)[0]
         kp, info = ts.ctx.last_kernel_ms(), ts.ctx.last_launch_info()
         out = {"pred": pr[:2000].copy()}
-        line = "shift=%s predict F=5: kernel %.1f ms (lds %d, blocks/CU %d)" % (sh, kp, info["lds_bytes"], info["blocks_per_cu"])
+        line = "predict F=5: kernel %.1f ms (lds %d, blocks/CU %d)" % (kp, info["lds_bytes"], info["blocks_per_cu"])
         for F in (4, 5, 6):
             m = T._objective_model(p, ts, 0.02, [1.0], None, 4, 1, F, 1)
             for _ in range(3):
@@ -40,5 +39,3 @@ for rnd in range(2):
         print(line, flush=True)
         ts.close()
         res[sh] = out
-print("shift vs circular: max |d posterior| %.2e, rel d LL %s" % (np.abs(res["1"]["pred"] - res["0"]["pred"]).max(),
-      ["%.1e" % (abs(res["1"]["ll%d" % F] - res["0"]["ll%d" % F]) / abs(res["0"]["ll%d" % F])) for F in (4, 5, 6)]))
