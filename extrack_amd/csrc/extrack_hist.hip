@@ -4,8 +4,13 @@
 #include "xt_hist.h"
 #include "xt_hist_host.h"
 
+// Waves per SIMD asked of the register allocator (256-thread workgroups): unbounded the kernel takes 136 VGPRs = 3 workgroups per CU; measured r03
+// (1e5 x 30, max_nb_states 500 / 120): 3 -> 68.2 / 24.8 ms, 4 -> 62.0 / 21.2, 5 -> 61.4 / 19.9, 6 -> 74.0 / 21.8.
+#ifndef XT_HIST_WAVES
+#define XT_HIST_WAVES 5
+#endif
 template <int D, int K, int MAXT>
-__global__ void __launch_bounds__(MAXT) xt_hist_kernel(XtHistArgs a)
+__global__ void __launch_bounds__(MAXT, (MAXT == 256 ? XT_HIST_WAVES : 1)) xt_hist_kernel(XtHistArgs a)
 {
     DevCtx cx;
     xt_hist_body<D, K>(a, cx);
@@ -86,8 +91,14 @@ extern "C" int extrack_segment_len_hist(extrack_ctx* ctx, const extrack_model* m
     int threads = 256;
     if (const char* ev = getenv("EXTRACK_HIST_THREADS")) threads = atoi(ev) == 512 ? 512 : 256;
     size_t lds = xt_hist_lds_doubles(S, L, D, K, KSl, a.PC, a.NC, a.HW, threads, true) * sizeof(double);
-    a.par_lds = lds <= 150 * 1024 ? 1 : 0;
-    if (!a.par_lds) lds = xt_hist_lds_doubles(S, L, D, K, KSl, a.PC, a.NC, a.HW, threads, false) * sizeof(double);
+    // parent arrays (the surviving sequences of the previous position) in LDS, or in a per-workgroup region of global memory when that
+    // lets more workgroups share a CU: at max_nb_states 500 the LDS copy leaves room for 2 (78 KB each), the global one for 5 - measured
+    // r03, 1e5 x 30: 78.3 -> 68.1 ms (then 61.4 ms with the register bound below); at 120 the LDS copy already allows 8 and is the faster one (24.5 vs 26.3 ms)
+    const size_t lds_g = xt_hist_lds_doubles(S, L, D, K, KSl, a.PC, a.NC, a.HW, threads, false) * sizeof(double);
+    auto per_cu_of = [](size_t bytes) { return (int)std::min<size_t>(8, (160 * 1024) / std::max<size_t>(bytes, 1)); };
+    a.par_lds = (lds <= 150 * 1024 && std::min(XT_HIST_WAVES, per_cu_of(lds_g)) <= std::min(XT_HIST_WAVES, per_cu_of(lds))) ? 1 : 0;  // XT_HIST_WAVES workgroups per CU is what the registers allow
+    if (const char* ev = getenv("EXTRACK_HIST_PAR_LDS")) a.par_lds = (lds <= 150 * 1024 && atoi(ev) != 0) ? 1 : 0;
+    if (!a.par_lds) lds = lds_g;
     if (lds > 160 * 1024) return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "candidate arrays do not fit the 160 KiB LDS of a CU: lower max_nb_states");
     const int per_cu = std::max(1, std::min(8, (int)((160 * 1024) / lds)));
     const int grid = (int)std::min<int64_t>(b.N, (int64_t)ctx->n_cu * per_cu * 2);
