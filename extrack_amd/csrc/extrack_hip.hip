@@ -11,7 +11,14 @@
 // Waves per SIMD the register allocator is asked to allow (workgroups of 256 threads).  Likelihood kernels: 4, except 4 members per group
 // (4 states: 66 ms unbounded against 74 ms at 3 on the 5e5 x 60 set, frame_len 5).  Posterior kernels (226 VGPRs unbounded = 2 waves):
 // 3 waves (168 VGPRs, 27-60 spilled dwords) - measured r03: C5 (4 states, 5e5 x 60, frame_len 5) 318 -> 265 ms, 4 waves 365 ms;
-// 2 states 1e6 x 30 frame_len 6 18.3 -> 15.2 ms; 3 states 2e5 x 30 frame_len 6 49.6 -> 44.2 ms.
+// 2 states 1e6 x 30 frame_len 6 18.3 -> 15.2 ms; 3 states 2e5 x 30 frame_len 6 49.6 -> 44.2 ms.  3-state likelihood at 5 waves: frame_len 6 unchanged,
+// frame_len 4 3.06 -> 3.94 ms (kept at 4).  Entry-parallel kernel (94 VGPRs unbounded = 5 waves): C5 (nb_substeps 3) 48.6 ms, 6 waves 46.9, 7 waves 46.2.
+#ifndef XT_ENTRY_WAVES
+#define XT_ENTRY_WAVES 7
+#endif
+#ifndef XT_LL_WAVES
+#define XT_LL_WAVES 4
+#endif
 #ifndef XT_G4_WAVES
 #define XT_G4_WAVES 1
 #endif
@@ -19,7 +26,7 @@
 #define XT_PREDS_WAVES 3
 #endif
 template <int G_, int D, int K, bool PREDS, int MAXT>
-__global__ void __launch_bounds__(MAXT, (MAXT == 256 && !PREDS ? (G_ != 4 ? 4 : XT_G4_WAVES) : (MAXT == 256 && PREDS ? XT_PREDS_WAVES : 1))) xt_track_kernel(XtKernelArgs a)
+__global__ void __launch_bounds__(MAXT, (MAXT == 256 && !PREDS ? (G_ != 4 ? XT_LL_WAVES : XT_G4_WAVES) : (MAXT == 256 && PREDS ? XT_PREDS_WAVES : 1))) xt_track_kernel(XtKernelArgs a)
 {
     DevCtx cx;
     xt_track_body<G_, D, K, PREDS>(a, cx);
@@ -33,7 +40,7 @@ __global__ void __launch_bounds__(64 * XT_F2_WAVES) xt_ll_s2_kernel(XtKernelArgs
 }
 
 template <int GP, int D, int K, int MAXT>
-__global__ void __launch_bounds__(MAXT) xt_entry_kernel(XtKernelArgs a)
+__global__ void __launch_bounds__(MAXT, (MAXT == 256 ? XT_ENTRY_WAVES : 1)) xt_entry_kernel(XtKernelArgs a)
 {
     DevCtx cx;
     xt_entry_body<GP, D, K>(a, cx);
