@@ -340,8 +340,11 @@ def other_configs(device):
     nb30 = big["30"].nbytes
     out["len_hist_1e5x30"] = {"what": "histograms.len_hist, 1e5 tracks x 30, 2 states, max_nb_states 500 (the reference's default)", "seconds": t_h,
                               "tracks_per_s": 1e5 / t_h, "hist_sum": float(h.sum()),
-                              "algorithmic_bytes": nb30 + h.nbytes, "byte_model": "one read of the tracks (480 B / track) + the [29, 2] histogram; the "
-                              "<= 500 surviving sequences of a track (state, ranking keys) never leave the LDS of its workgroup",
+                              "algorithmic_bytes": nb30 + h.nbytes, "byte_model": "algorithmic: one read of the tracks (480 B / track) + the [29, 2] histogram.  The <= 500 surviving "
+                              "sequences of a track (parent arrays, ~25 KB per copy) live in a per-workgroup region of global memory at this max_nb_states "
+                              "(that frees LDS for 5 workgroups per CU instead of 2: 78 -> 62 ms); the region is rewritten every position and stays in "
+                              "L2 / Infinity Cache (1 280 workgroups x 50 KB), the counters see ~114 GB of L2 <-> fabric traffic per 1e5 tracks "
+                              "(profiles/r03_pmc_summary.txt)",
                               "hbm_gbs": (nb30 + h.nbytes) / t_h / 1e9}
     out["position_refinement_1e5x30"] = {"what": "refined_localization.position_refinement, 1e5 tracks x 30, 2 states, frame_len 6, threshold 0.1",
                                          "seconds": t_r, "tracks_per_s": 1e5 / t_r, "mean_sigma": float(sg["30"].mean()),
