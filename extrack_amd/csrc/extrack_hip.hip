@@ -46,8 +46,12 @@ __global__ void __launch_bounds__(MAXT, (MAXT == 256 ? XT_ENTRY_WAVES : 1)) xt_e
     xt_entry_body<GP, D, K>(a, cx);
 }
 
-template <int D, int K, bool PREDS, int WS = -1>
-__global__ void __launch_bounds__(1024) xt_th_plan_kernel(XtThArgs a)
+// Posterior / recording mode (PREDS) is launched with 64 or 256 threads per chunk: bounded by 256 threads, PW waves per SIMD asked of the register
+// allocator (the fit-mode plan walks with up to 1024 threads: 128 VGPRs).  Measured r03 (kernel ms; 2 states 2e5 x 30 | 4 states 5e4 x 60, nb_max 1):
+// 3 waves 77.6 | 433, 4 waves 99.0 | 354, 5 waves 93.3 | 382, 6 waves 87.5 | 365, 8 waves 97.2 | 446 -> 3 for two states (168 VGPRs, no spills), else 4.
+static inline int xt_th_pred_waves(int S) { return S == 2 ? 3 : 4; }
+template <int D, int K, bool PREDS, int WS = -1, int PW = 4>
+__global__ void __launch_bounds__(PREDS ? 256 : 1024, PREDS ? PW : 1) xt_th_plan_kernel(XtThArgs a)
 {
     DevCtx cx;
     xt_th_plan_body<D, K, PREDS, WS>(a, cx);
@@ -1422,9 +1426,15 @@ extern "C" int extrack_loglik_th(extrack_ctx* ctx, const extrack_model* m, doubl
 template <int D, int K>
 static hipError_t xt_th_launch_predict(extrack_ctx* ctx, const XtThArgs& a, int grid, int threads, size_t lds)
 {
-    hipError_t e = xt_th_set_lds(ctx, xt_th_plan_kernel<D, K, true>, lds);
+    if (xt_th_pred_waves(a.S) == 3) {
+        hipError_t e = xt_th_set_lds(ctx, xt_th_plan_kernel<D, K, true, -1, 3>, lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((xt_th_plan_kernel<D, K, true, -1, 3>), dim3(grid), dim3(threads), lds, ctx->stream, a);
+        return hipGetLastError();
+    }
+    hipError_t e = xt_th_set_lds(ctx, xt_th_plan_kernel<D, K, true, -1, 4>, lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((xt_th_plan_kernel<D, K, true>), dim3(grid), dim3(threads), lds, ctx->stream, a);
+    hipLaunchKernelGGL((xt_th_plan_kernel<D, K, true, -1, 4>), dim3(grid), dim3(threads), lds, ctx->stream, a);
     return hipGetLastError();
 }
 
@@ -1542,7 +1552,7 @@ extern "C" int extrack_predict_th(extrack_ctx* ctx, const extrack_model* m, int3
             }
         }
         const int threads = nb_max <= 2 ? 64 : 256;
-        const int grid = (int)std::min<int64_t>(a.nchunks, (int64_t)ctx->n_cu * (threads == 64 ? 16 : 4));
+        const int grid = (int)std::min<int64_t>(a.nchunks, (int64_t)ctx->n_cu * (threads == 64 ? 4 : 1) * xt_th_pred_waves(S));
         a.ws_stride = xt_th_hist_doubles(a.wsE, a.pcap, true, b.L) + (a.ws_lds ? 0 : xt_th_ws_doubles(a.wsP, a.wsE, D, K, F, 1, S, a.pcap, true));
         const size_t need = (size_t)a.ws_stride * grid * sizeof(double);
         if (need > ctx->th_ws_cap) {
@@ -1798,7 +1808,7 @@ static int xt_refine_launch(extrack_ctx* ctx, const extrack_model* m, const doub
         a.cmat_words = 0;
         const int64_t first = std::max<int64_t>(row0, a.pcap), last = std::min<int64_t>(N, row0 + rows);
         const int64_t nbatch = (!probe && last > first) ? (last - first + a.pcap - 1) / a.pcap : 0;
-        const int grid = probe ? 1 : (int)std::max<int64_t>(1, std::min<int64_t>(nbatch, (int64_t)ctx->n_cu * 4));
+        const int grid = probe ? 1 : (int)std::max<int64_t>(1, std::min<int64_t>(nbatch, (int64_t)ctx->n_cu * xt_th_pred_waves(S)));
         const size_t lds = (size_t)xt_th_plan_lds_doubles(S, G, capE, D, 1) * sizeof(double);
         a.ws_stride = xt_th_hist_doubles(a.wsE, a.pcap, true, L) + xt_th_ws_doubles(a.wsP, a.wsE, D, 1, F, 1, S, a.pcap, true);
         const size_t need = (size_t)a.ws_stride * grid * sizeof(double);
