@@ -5,7 +5,7 @@
 #include "xt_reg2.h"
 
 #ifndef XT_R2_LL_WAVES
-#define XT_R2_LL_WAVES 4  // waves per SIMD asked of the register allocator for the likelihood-only kernels: 127 VGPRs + 12 B scratch; its own choice (131 VGPRs, 3 waves) ran 2.5 % slower (A/B, C2)
+#define XT_R2_LL_WAVES 4  // waves per SIMD asked of the register allocator for the likelihood-only kernels: 124 VGPRs, no scratch; its own choice (131 VGPRs, 3 waves) ran 2.5 % slower, 5 waves 0.3 % slower (same-box A/B, C2)
 #endif
 template <int F, int D, int K>
 __global__ void __launch_bounds__(64 * XT_F2_WAVES, XT_R2_LL_WAVES) xt_ll_r2_kernel(XtKernelArgs a)
