@@ -130,18 +130,18 @@ def test_emulated_register_resident_general_gradient_body(S, ns, F, L, N, D, K, 
     assert rel.max() < 1e-6, [(d[0], a, b) for d, a, b, r in zip(dirs, g, fd, rel) if r > 1e-6]
 
 
-@pytest.mark.parametrize("S,ns,F,L,N,D,K,isBL", [(3, 1, 3, 8, 6, 2, 1, 1), (3, 1, 4, 9, 5, 2, 1, 0), (2, 2, 4, 7, 6, 1, 1, 1), (3, 1, 3, 8, 4, 2, 2, 1),
-                                                   (4, 1, 3, 7, 3, 3, 1, 1), (3, 1, 3, 2, 4, 2, 1, 1), (3, 1, 3, 3, 4, 2, 1, 0), (2, 1, 5, 36, 3, 3, 3, 1),
-                                                   (3, 1, 5, 12, 7, 2, 1, 1)])
-@pytest.mark.parametrize("nbuf", [2, 1])
+_REV_CASES = [(3, 1, 3, 8, 6, 2, 1, 1), (3, 1, 4, 9, 5, 2, 1, 0), (2, 2, 4, 7, 6, 1, 1, 1), (3, 1, 3, 8, 4, 2, 2, 1), (4, 1, 3, 7, 3, 3, 1, 1),
+              (3, 1, 3, 2, 4, 2, 1, 1), (3, 1, 3, 3, 4, 2, 1, 0), (2, 1, 5, 36, 3, 3, 3, 1), (3, 1, 5, 12, 7, 2, 1, 1)]
+
+
+@pytest.mark.parametrize("S,ns,F,L,N,D,K,isBL,nbuf", [c + (2,) for c in _REV_CASES] + [c + (1,) for c in _REV_CASES if (c[0], c[2], c[3]) in
+                                                                                        ((3, 3, 8), (4, 3, 7), (2, 5, 36), (3, 3, 2))])
 def test_emulated_reverse_mode_gradient_body(S, ns, F, L, N, D, K, isBL, nbuf, monkeypatch):
     """xt_rev.h (reverse mode: forward sweep logging the merged state of every group, backward sweep of adjoints, adjoint of the model
     blob contracted with the tangent blocks) on CPU threads against Richardson differences of the pinned oracle along every model
     direction; N is not a multiple of the tracks per workgroup (partial last batch), 2- and 3-position tracks, a track longer than
     the staging block of 32 positions.  nbuf: exchange buffers per track (1 = the variant with two barriers per step the launcher takes
     where a second buffer would cost the second workgroup per CU)."""
-    if nbuf == 1 and (S, F, L) not in ((3, 3, 8), (4, 3, 7), (2, 5, 36), (3, 3, 2)):
-        pytest.skip("single-buffer variant: a subset of the configurations")
     monkeypatch.setenv("XT_EMUL_REV_NBUF", str(nbuf))
     import run_emul as E
     from extrack_amd import synth
