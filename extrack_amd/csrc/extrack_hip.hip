@@ -789,7 +789,7 @@ extern "C" int extrack_sequence_matrix(extrack_ctx* ctx, const extrack_model* m,
     const int isBL = (b.L != m->max_len) ? 1 : 0;
     if (n_cols != xt_seq_columns(c.S, b.L, c.NS, c.F, isBL)) return xt_fail(ctx, EXTRACK_E_INVALID, "sequence matrix: n_cols must be extrack_sequence_columns(...)");
     const size_t nraw = (size_t)b.N * c.E * c.G;
-    if (nraw > ((size_t)1 << 31)) return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "sequence matrix: more than 2^31 entries (it exists for small inputs; the likelihood needs no matrix)");
+    if (nraw > ((size_t)1 << 28)) return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "sequence matrix: more than 2^28 entries = 2 GiB through host memory (it exists for small inputs; the likelihood needs no matrix: split the tracks)");
     if ((rc = xt_reserve_preds(ctx, nraw * sizeof(double)))) return rc;
     int grid = 0;
     std::vector<XtBucket*> one(1, &b);
