@@ -211,7 +211,7 @@ def test_sequence_matrix_on_golden_cases(kernel_cases):
     """P_Cs_inter_bound_stats' per-sequence matrix LP[N, nB] (the reference's first return value, extrack/tracking.py:318): the general
     kernel body's raw per-(sequence, new digits) output mapped to the reference's column order by csrc/xt_seqmat.h, against the matrices
     the reference produced (stored in the golden cases with nB <= 256): 2-4 states, nb_substeps 1-2, isBL 0 / 1, tracks shorter and
-    longer than the window.  Entries are compared where the reference is finite; -inf / underflowed entries must be <= -700."""
+    longer than the window (the first 25 distinct configurations here; all 670 matrices on the GPU).  Entries are compared where the reference is finite; -inf / underflowed entries must be <= -700."""
     import sys, os
     sys.path.insert(0, os.path.join(os.path.dirname(__file__), "emul"))
     import run_emul as E
@@ -232,6 +232,6 @@ def test_sequence_matrix_on_golden_cases(kernel_cases):
         worst = max(worst, np.abs(lp[fin] - x["LP"][fin]).max())
         assert np.all(lp[~fin] < -600)
         n += 1
-        if n >= 45:  # the GPU test (tests/test_hip_parity.py) runs all 670 reference matrices
+        if n >= 25:  # the GPU test (tests/test_hip_parity.py) runs all 670 reference matrices
             break
-    assert n >= 40 and worst < 1e-9, (n, worst)
+    assert n >= 25 and worst < 1e-9, (n, worst)
