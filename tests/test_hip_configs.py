@@ -91,6 +91,33 @@ def test_c3_mixed_lengths_objective_vs_oracle():
     assert abs(got - want) < 1e-12 * abs(want), (got, want)
 
 
+def test_c3_gradient_reverse_vs_forward_mode(monkeypatch):
+    """configs[2]-shaped data (46 buckets, 6e4 tracks, 3 states, 13 free parameters) at frame_len 6: the gradient of the fit objective from the
+    reverse-mode kernels (the default for 3 states, xt_rev.h) against the forward-mode register kernels (xt_gradr.h) - two independent
+    derivations of the same derivative - and the objective of both against the likelihood kernel."""
+    from extrack_amd import gradient, tracking as T
+    tracks = _c3_tracks(6e4, seed0=500)
+    p = T.generate_params(nb_states=3, LocErr_type=1, estimated_Ds=[1e-4, 0.04, 0.25], estimated_LocErr=[0.02], estimated_Fs=[0.3, 0.3],
+                          estimated_transition_rates=0.06)
+    names = gradient.free_names(p)
+    assert len(names) == 13
+    _, lst, _ = T.engine.sort_buckets(tracks)
+    out = {}
+    for path in ("auto", "gradr"):
+        monkeypatch.setenv("EXTRACK_GRAD_PATH", path)
+        ts = T.TrackSet(lst)
+        try:
+            out[path] = gradient.objective_and_gradient(p, ts, 0.02, [1], 3, 1, 6, names=names)
+            out[path + "_lds"] = ts.ctx.last_launch_info()["lds_bytes"]
+            ll = ts.loglik(T._objective_model(p, ts, 0.02, [1], None, 3, 1, 6, 1))
+        finally:
+            ts.close()
+        assert abs(out[path][0] + ll) < 1e-12 * abs(ll)
+    assert out["auto_lds"] != out["gradr_lds"]  # two different kernel families
+    g0, g1 = out["auto"][1], out["gradr"][1]
+    assert np.abs(g0 - g1).max() < 1e-10 * np.abs(g1).max(), (g0, g1)
+
+
 def test_c3_full_size_properties():
     """configs[2] at full size (1e6 tracks, 3 states, 46 buckets, frame_len 6): total == sum of per-track values, additivity over
     two row shards with the dataset-global min/max length (what the multi-GPU path relies on), first 8 tracks of the shortest,
