@@ -1,18 +1,20 @@
 #!/usr/bin/env python3
 """Headline benchmark: log-likelihood evaluations per second on synthetic track batches.
 
-Workload at N GPUs, default ``--config c2`` (weak scaling): every rank holds BASELINE.json configs[1] - 1e6 tracks, 2 states,
-length 30, 2-D, nb_substeps=1, frame_len=6 - resident in HBM; a "step" is one evaluation of -sum(LL) over all ranks' tracks
-(local kernel + one all-reduce of the fp64 scalar over RCCL).  `value` = (N x 1e6-track evaluations) / s, i.e. in
-units of "1e6-track log-likelihood evaluations per second".
-``--config c4`` (strong scaling): BASELINE.json configs[3] - 1e7 tracks of the same shape IN TOTAL, sharded by rows over the N
-ranks (1.25e6 per rank at N = 8); `value` is in the same unit (1e6-track evaluations per second = 10 x whole-dataset
-evaluations per second).
-At N = 1 with the default config, an `extra` block (outside the timed region) reports the other BASELINE configs on the same
-GPU: configs[2] (3 states, 46 length buckets) per evaluation, configs[4] (4 states, nb_substeps 3) per evaluation and its
-predict_Bs annotation, each with algorithmic bytes and the flop model of SURVEY.md section 8(d).
+A "step" is one evaluation of -sum(LL) over the whole dataset (local kernel on every rank + one all-reduce of the fp64 scalar over
+RCCL); `value` is in units of "1e6-track log-likelihood evaluations per second" (whole job, all GPUs).
+
+Workloads (all BASELINE.json shapes: 2 states, length 30, 2-D, nb_substeps=1, frame_len=6, resident in HBM before the timed region):
+  c2   configs[1], 1e6 tracks PER GPU (weak scaling)              - the headline on ONE GPU
+  c2s  configs[1], 1e6 tracks IN TOTAL, row-sharded (strong)      - the headline on N > 1 GPUs (what BASELINE.json's metric names)
+  c4   configs[3], 1e7 tracks in total, row-sharded (strong)
+Without ``--config``, an N > 1 run measures all three back to back (`scaling_runs`), each with ms_per_step, kernel_ms and
+comm_ms = step - kernel; with ``--config`` only that one.  At N = 1 an `extra` block (outside the timed region) reports the other
+BASELINE configs on the same GPU: configs[2] (3 states, 46 length buckets), configs[4] (4 states, nb_substeps 3) and its predict_Bs
+annotation, configs[3] on one GPU, each with algorithmic bytes and the flop model of SURVEY.md section 8(d).
 
     python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus N ...            # starts its own N rank processes (one per GPU) and relays rank 0's JSON line
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 """
 import argparse
@@ -26,7 +28,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-N_TRACKS, LEN, DIMS, S, NS, FRAME = 1000000, 30, 2, 2, 1, 6
+N_TRACKS, LEN, DIMS, S, NS, FRAME = int(os.environ.get("EXTRACK_BENCH_N_TRACKS", "1000000")), 30, 2, 2, 1, 6  # (the env override: CPU rehearsal sizes)
 DS_COEF, TRMAT, FS, LOCERR, DT, PBL, CELL = [0.0, 0.25], [[0.9, 0.1], [0.1, 0.9]], [0.6, 0.4], 0.02, 0.02, 0.1, [1.0]
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP64_VALU_PEAK_TF = 78.6   # 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
@@ -145,7 +147,7 @@ def _flop_model(lengths_counts, S, F, ns, D):
     return float(sum(n * max(L - 2, 0) for L, n in lengths_counts)) * (S ** F) * per_entry
 
 
-def other_configs(device):
+def other_configs(device, no_cpu_baseline=False):
     """configs[2] and configs[4] on the same GPU (N = 1 only, outside the timed region): ms per evaluation / tracks per second with
     the HIP-event kernel time, algorithmic bytes (one read of the tracks; posteriors add their output) and the flop model."""
     import torch
@@ -290,6 +292,8 @@ def other_configs(device):
     ts.close()
     # CPU side of the same configs (plain-C restatement, OpenMP, bounded samples)
     try:
+        if no_cpu_baseline:
+            raise RuntimeError("skipped (--no-cpu-baseline)")
         from oracle import oracle_c, oracle_np as O
         cores = _one_socket_cores()
         LocErr, ds, Fs, T, pBL = O.extract_params(vals, DT, nb_substeps=3, Matrix_type=1)  # the ORACLE's signature (values, dt, nb_substeps, Matrix_type)
@@ -352,6 +356,8 @@ def other_configs(device):
                                          "byte_model": "tracks in (480 B / track) + refined positions and stds out (720 B / track); the per-position records of the "
                                          "forward and backward pass (~24 sequences x 4 doubles per position and pass) go through HBM once each way on top of that",
                                          "hbm_gbs": (2 * nb30 + sg["30"].nbytes) / t_r / 1e9}
+    if no_cpu_baseline:  # e.g. under rocprofv3: no fork pools, no CPU legs
+        return out
     try:  # CPU side: the numpy restatements (pinned to the reference's fixtures) on bounded samples, one socket's cores
         import multiprocessing as mp
         cores = _one_socket_cores()
@@ -373,20 +379,89 @@ def other_configs(device):
     return out
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _launch_ranks(n, argv):
+    """``python bench.py --gpus N`` without a launcher: start N fresh rank processes of this script (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* in their environment, exactly what torch.distributed.run would set), relay rank 0's JSON line as the LAST stdout line and
+    return the first non-zero exit code.  Runs before anything in this process has touched torch or the GPU; the children are fresh
+    interpreters (Popen of a new program from a process that never initialised HIP), never an exec of a GPU-initialised process."""
+    import subprocess
+    import threading
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+        # rank 0's stdout is parsed here; the other ranks print nothing on stdout by contract, whatever they do print goes to stderr
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0) or None))
+    result = []
+
+    def pump():
+        for line in procs[0].stdout:
+            t = line.strip()
+            if t.startswith("{") and t.endswith("}") and '"metric"' in t:
+                result.append(t)       # held back: printed last
+            else:
+                sys.stdout.write(line)
+                sys.stdout.flush()
+    th = threading.Thread(target=pump, daemon=True)
+    th.start()
+    rc, alive = 0, set(range(n))
+    while alive:
+        for r in sorted(alive):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            alive.discard(r)
+            if code != 0 and rc == 0:
+                rc = code
+                for o in alive:       # a rank died: its peers would wait in the next collective for ever
+                    procs[o].terminate()
+        time.sleep(0.05)
+    th.join(10)
+    if result:
+        print(result[-1], flush=True)
+    elif rc == 0:
+        rc = 1
+    return rc
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", choices=("c2", "c4"), default="c2",
-                    help="c2: BASELINE configs[1], 1e6 tracks per GPU (weak scaling); c4: configs[3], 1e7 tracks in total sharded over the GPUs")
-    ap.add_argument("--tracks", type=int, default=None, help="tracks per GPU (c2) / in total (c4); default = the BASELINE config")
+    ap.add_argument("--config", choices=("c2", "c2s", "c4"), default=None,
+                    help="c2: BASELINE configs[1], 1e6 tracks PER GPU (weak scaling); c2s: the same 1e6 tracks IN TOTAL, row-sharded (strong "
+                         "scaling - what BASELINE.json's metric names); c4: configs[3], 1e7 tracks in total, row-sharded (strong).  Default: "
+                         "c2 on one GPU; on N > 1 GPUs c2s is the headline and c2 (weak) + c4 (strong) are measured in the same run (`scaling_runs`)")
+    ap.add_argument("--tracks", type=int, default=None, help="tracks per GPU (c2) / in total (c2s, c4); default = the BASELINE config")
     ap.add_argument("--no-extra", action="store_true", help="skip the configs[2] / configs[4] measurements after the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
                     help="process-group backend: nccl = RCCL over xGMI (the measurement); gloo = rehearsal of the multi-rank control flow on a box "
-                         "without GPUs (tests/test_bench_gloo.py substitutes the device context; nothing it prints is a measurement)")
+                         "without GPUs (needs --rehearsal-context; nothing it prints is a measurement)")
+    ap.add_argument("--rehearsal-context", default=None, metavar="MODULE:CLASS",
+                    help="gloo rehearsal only (tests/test_bench_gloo.py): class under tests/ that stands in for the device context")
+    argv = list(sys.argv[1:] if argv is None else argv)
     a = ap.parse_args(argv)
+    if a.backend == "nccl" and a.rehearsal_context:
+        raise SystemExit("--rehearsal-context is only valid with --backend gloo: the measurement always runs the HIP library")
+    if a.backend == "gloo" and not a.rehearsal_context:
+        raise SystemExit("--backend gloo is a CPU rehearsal of the control flow and needs --rehearsal-context (there is no CPU fallback)")
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        raise SystemExit(_launch_ranks(a.gpus, argv))
 
     import torch
     from extrack_amd import synth, tracking
@@ -396,12 +471,18 @@ def main(argv=None):
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % a.gpus)
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch one rank per GPU (or plainly: python bench.py --gpus N)" % (a.gpus, world))
     on_gpu = a.backend == "nccl"
+    if not on_gpu:
+        import importlib
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        mod, cls = a.rehearsal_context.split(":")
+        from extrack_amd import _lib as _xl
+        _xl.Context = getattr(importlib.import_module(mod), cls)
     if on_gpu:
         torch.cuda.set_device(local)
     comm = None
+    rccl = None
     if world > 1 or os.environ.get("EXTRACK_BENCH_FORCE_COMM") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -416,28 +497,14 @@ def main(argv=None):
             dist.init_process_group("gloo")
         from extrack_amd.distributed import Comm
         comm = Comm()
+        names = [None] * world
+        dist.all_gather_object(names, "cuda:%d %s" % (local, torch.cuda.get_device_name(local)) if on_gpu else "cpu (rehearsal)")
+        rccl = {"backend": dist.get_backend(), "world": world, "devices": names,
+                "collective": "one all-reduce(sum) of {sum LL, failure flag} (2 doubles) per evaluation, on the kernels' stream"}
 
-    # synthetic data of the BASELINE shape, resident in HBM before the timed region
-    if a.config == "c4":
-        from extrack_amd.distributed import shard_plan
-        total_tracks = a.tracks if a.tracks else 10 * N_TRACKS
-        lo_, hi_ = shard_plan([total_tracks], [LEN], world)[0][rank]
-        a.tracks = hi_ - lo_   # this rank's rows of the one 1e7-track bucket
-        scaling = "strong"
-    else:
-        a.tracks = a.tracks if a.tracks else N_TRACKS
-        total_tracks = a.tracks * world
-        scaling = "weak"
-    Cs = synth.brownian_tracks(a.tracks, LEN, DS_COEF, TRMAT, FS, LOCERR, DT, DIMS, seed=rank)
-    ts = tracking.TrackSet([Cs], device=local, min_len=LEN, max_len=LEN)
-    del Cs
     p = Parameters()
     for k, v in dict(D0=DS_COEF[0], D1=DS_COEF[1], LocErr=LOCERR, F0=FS[0], F1=FS[1], p01=0.1, p10=0.1, pBL=PBL).items():
         p.add(k, value=v)
-    model = tracking._objective_model(p, ts, DT, CELL, None, S, NS, FRAME, 1)
-
-    def step():
-        return ts.loglik(model) if comm is None else comm.allreduce_loglik(ts, model)
 
     def barrier():
         if comm is not None:
@@ -445,20 +512,57 @@ def main(argv=None):
         if on_gpu:
             torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        val = step()
-    kernel_ms = []
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        val = step()
-        kernel_ms.append(ts.ctx.last_kernel_ms())
-    barrier()
-    dt_loc = time.perf_counter() - t0
-    if comm is not None:
-        dt_all = comm.allreduce_scalar(dt_loc, "max")
-    else:
-        dt_all = dt_loc
+    def run_config(cfg, tracks_arg, keep=False):
+        """One workload: this rank's rows resident in HBM, `warmup` untimed steps, then exactly `steps` steps between two
+        barrier + synchronize brackets; the time is the MAX over the ranks."""
+        from extrack_amd.distributed import shard_plan
+        if cfg == "c2":
+            n_loc = tracks_arg if tracks_arg else N_TRACKS
+            total, scaling = n_loc * world, "weak"
+        else:
+            total = tracks_arg if tracks_arg else (N_TRACKS if cfg == "c2s" else 10 * N_TRACKS)
+            lo_, hi_ = shard_plan([total], [LEN], world)[0][rank]   # this rank's rows of the one bucket
+            n_loc, scaling = hi_ - lo_, "strong"
+        Cs = synth.brownian_tracks(n_loc, LEN, DS_COEF, TRMAT, FS, LOCERR, DT, DIMS, seed=rank)
+        ts = tracking.TrackSet([Cs], device=local, min_len=LEN, max_len=LEN, allow_empty=True)
+        del Cs
+        model = tracking._objective_model(p, ts, DT, CELL, None, S, NS, FRAME, 1)
+        step = (lambda: ts.loglik(model)) if comm is None else (lambda: comm.allreduce_loglik(ts, model))
+        for _ in range(a.warmup):
+            val = step()
+        kernel_ms = []
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            val = step()
+            kernel_ms.append(ts.ctx.last_kernel_ms() if n_loc else 0.0)
+        barrier()
+        dt_loc = time.perf_counter() - t0
+        dt_all = comm.allreduce_scalar(dt_loc, "max") if comm is not None else dt_loc
+        k_ms = float(np.mean(kernel_ms))
+        k_max = comm.allreduce_scalar(k_ms, "max") if comm is not None else k_ms
+        res = {"config": cfg, "scaling": scaling, "total_tracks": total, "tracks_per_gpu": n_loc, "ms_per_step": dt_all / a.steps * 1e3,
+               "kernel_ms": k_ms, "kernel_ms_max_over_ranks": k_max, "comm_ms": dt_all / a.steps * 1e3 - k_max,
+               "value": (total / N_TRACKS) * a.steps / dt_all, "unit": "1e6-track LL evals/s", "neg_loglik": -val,
+               "launch": ts.ctx.last_launch_info() if n_loc else {}}
+        if keep:
+            return res, ts, model
+        ts.close()
+        return res, None, None
+
+    # the headline workload (resident in HBM before the timed region); N > 1 without --config: all three scaling workloads in this run
+    primary = a.config if a.config else ("c2" if world == 1 else "c2s")
+    scaling_runs = {}
+    if a.config is None and world > 1:
+        for cfg in ("c2", "c4"):
+            scaling_runs[cfg] = run_config(cfg, None)[0]
+    head, ts, model = run_config(primary, a.tracks, keep=True)
+    scaling_runs[primary] = dict(head)
+    a.tracks, total_tracks, scaling = head["tracks_per_gpu"], head["total_tracks"], head["scaling"]
+    dt_all = head["ms_per_step"] * 1e-3 * a.steps
+    kernel_ms = [head["kernel_ms"]]
+    val = -head["neg_loglik"]
+    a.config = primary
     # secondary measurement (outside the timed region, one GPU only): the threshold-fusion kernel that the reference's
     # current param_fitting calls (tracking.py:427-743), same data, v1.6.3 defaults (threshold 0.2, max_nb_states 120,
     # 2000-track chunks): plan kernel + apply kernel per evaluation
@@ -492,7 +596,9 @@ def main(argv=None):
     ts.close()
     extra = None
     if on_gpu and world == 1 and a.config == "c2" and a.tracks == N_TRACKS and not a.no_extra:
-        extra = other_configs(local)
+        extra = other_configs(local, a.no_cpu_baseline)
+        # configs[3] on ONE GPU: the N = 1 point of the strong-scaling curve `scaling_runs.c4` reports at N > 1
+        scaling_runs["c4"] = run_config("c4", None)[0]
     if comm is not None:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
@@ -503,11 +609,12 @@ def main(argv=None):
     k_ms = float(np.mean(kernel_ms))
     alg_bytes = a.tracks * LEN * DIMS * 8          # one read of the track, LL reduced in-kernel
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0  # no device timer in the gloo rehearsal
-    traffic = None   # HBM bytes per launch from the committed rocprofv3 PMC passes (tools/gpu_pmc.sh -> profiles/hbm_traffic.json)
+    traffic, traffic_round = None, None   # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/hbm_traffic.json)
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if os.path.exists(tpath) and a.tracks == N_TRACKS:
         try:
-            traffic = json.load(open(tpath)).get("bytes_per_launch")
+            tj = json.load(open(tpath))
+            traffic, traffic_round = tj.get("bytes_per_launch"), tj.get("round")
         except Exception:
             traffic = None
     # secondary (honest) bound: fp64 vector issue, from the instruction mix of the steady-state step of the CURRENT build
@@ -525,12 +632,15 @@ def main(argv=None):
         "scaling": scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic" if on_gpu else "synthetic (gloo REHEARSAL, not a measurement)",
         "config": {"workload": ("BASELINE configs[1]: %d tracks/GPU, 2 states, len=30, 2-D, nb_substeps=1, frame_len=6, "
                                 "single log-likelihood eval per step" % a.tracks) if a.config == "c2" else
-                               ("BASELINE configs[3]: %d tracks in total, row-sharded over %d GPU(s) (%d on rank 0), 2 states, len=30, 2-D, "
-                                "nb_substeps=1, frame_len=6, single log-likelihood eval per step" % (total_tracks, world, a.tracks)),
-                   "tracks_per_gpu": a.tracks, "total_tracks": total_tracks, "parallelism": "dp%d" % world, "launch": launch_info},
+                               ("BASELINE configs[%d]: %d tracks in total, row-sharded over %d GPU(s) (%d on rank 0), 2 states, len=30, 2-D, "
+                                "nb_substeps=1, frame_len=6, single log-likelihood eval per step (local kernel + one RCCL all-reduce)"
+                                % (1 if a.config == "c2s" else 3, total_tracks, world, a.tracks)),
+                   "name": a.config, "tracks_per_gpu": a.tracks, "total_tracks": total_tracks, "parallelism": "dp%d" % world, "launch": launch_info},
+        "kernel_ms": head["kernel_ms_max_over_ranks"], "comm_ms": head["comm_ms"],
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic, "traffic_source": "static: rocprofv3 PMC passes of an earlier run of this workload, profiles/hbm_traffic.json "
-                                                           "(not re-measured inside this run)",
+                     "traffic": traffic, "traffic_round": traffic_round,
+                     "traffic_source": "static: rocprofv3 PMC passes of an earlier run of this workload, profiles/hbm_traffic.json "
+                                       "(not re-measured inside this run; `traffic_round` = the round it was collected in)",
                      "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes,
                      "note": "the recursion is FP64-VALU bound, not HBM bound (arithmetic intensity ~300 flop/B, DESIGN.md)",
                      },
@@ -545,6 +655,11 @@ def main(argv=None):
             "valu_issue_floor_ms": wave_steps * mix["issue_cycles_per_wave_step"] / (256 * 4) / 2.4e9 * 1e3,
             "instructions_per_wave_step": {"fp64": mix["fp64_valu_per_wave_step"], "valu32": mix["valu32_per_wave_step"], "lds": mix["lds_per_wave_step"]},
             "source": "profiles/isa_mix.json (tools/isa_mix.py on the current sources): " + mix["kernel"]}
+    if rccl is not None:
+        out["rccl"] = rccl
+    out["scaling_runs"] = dict(scaling_runs, note="every workload of this run: c2 = 1e6 tracks per GPU (weak), c2s = 1e6 tracks in total (strong; the "
+                               "headline at N > 1), c4 = 1e7 tracks in total (strong); comm_ms = ms_per_step - kernel_ms (max over ranks): launch, "
+                               "all-reduce and read-back")
     if th is not None:
         out["threshold_fusion"] = th
     if grad_info is not None:

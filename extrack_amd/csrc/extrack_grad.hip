@@ -215,6 +215,7 @@ static int xt_grad_enqueue(extrack_ctx* ctx, const extrack_model* m, int32_t n_d
             d.ll_const = -(double)(b->L - 1) * D * 0.5 * XT_LOG2PI;
             descs.push_back(d);
         }
+        ctx->desc_shadow.clear();  // this path writes the device table itself: the likelihood launcher's shadow of it no longer holds
         memcpy(ctx->h_desc + doff, descs.data(), descs.size() * sizeof(XtBucketDesc));
         XT_HIP(ctx, hipMemcpyAsync(ctx->d_desc + doff, ctx->h_desc + doff, descs.size() * sizeof(XtBucketDesc), hipMemcpyHostToDevice, ctx->stream));
         XT_HIP(ctx, hipEventRecord(ctx->ev_blob[(ctx->blob_turn - 1u) & 1u], ctx->stream));

@@ -30,6 +30,7 @@ __global__ void __launch_bounds__(MAXT, (MAXT == 256 && !PREDS ? (G_ != 4 ? XT_L
 {
     DevCtx cx;
     xt_track_body<G_, D, K, PREDS>(a, cx);
+    if (!PREDS) xt_fused_total(a);
 }
 
 template <int F, int D, int K>
@@ -37,6 +38,7 @@ __global__ void __launch_bounds__(64 * XT_F2_WAVES) xt_ll_s2_kernel(XtKernelArgs
 {
     DevCtx cx;
     xt_ll_s2_body<F, D, K>(a, cx);
+    xt_fused_total(a);
 }
 
 template <int GP, int D, int K, int MAXT>
@@ -44,6 +46,7 @@ __global__ void __launch_bounds__(MAXT, (MAXT == 256 ? XT_ENTRY_WAVES : 1)) xt_e
 {
     DevCtx cx;
     xt_entry_body<GP, D, K>(a, cx);
+    xt_fused_total(a);
 }
 
 // Posterior / recording mode (PREDS) is launched with 64 or 256 threads per chunk: bounded by 256 threads, PW waves per SIMD asked of the register
@@ -119,7 +122,10 @@ extern "C" int extrack_create(int device_id, extrack_ctx** out)
     c->n_cu = prop.multiProcessorCount;
     if (const char* ev = getenv("EXTRACK_OVERSUB")) {
         int v = atoi(ev);
-        if (v >= 1 && v <= 64) c->oversub = v;
+        if (v >= 1 && v <= 64) {
+            c->oversub = v;
+            c->oversub_forced = true;
+        }
     }
     if (const char* ev = getenv("EXTRACK_LL_PATH")) c->ll_reg2 = strcmp(ev, "reg2") == 0 ? 1 : (strcmp(ev, "lds") == 0 ? 0 : c->ll_reg2);
     if (const char* ev = getenv("EXTRACK_GRAD_PATH")) c->grad_reg2 = strcmp(ev, "lds") == 0 ? 0 : (strcmp(ev, "gradr") == 0 ? 2 : 1);
@@ -174,7 +180,11 @@ extern "C" int extrack_create(int device_id, extrack_ctx** out)
     XT_CREATE(hipEventCreateWithFlags(&c->ev_blob[0], hipEventDisableTiming));
     XT_CREATE(hipEventCreateWithFlags(&c->ev_blob[1], hipEventDisableTiming));
     XT_CREATE(hipMalloc(&c->d_total, sizeof(double)));
-    XT_CREATE(hipHostMalloc(&c->h_total, sizeof(double), hipHostMallocDefault));
+    XT_CREATE(hipHostMalloc(&c->h_total, sizeof(double), hipHostMallocMapped));
+    XT_CREATE(hipHostGetDevicePointer((void**)&c->h_total_dev, c->h_total, 0));
+    XT_CREATE(hipMalloc(&c->d_done, sizeof(unsigned int)));
+    XT_CREATE(hipMemset(c->d_done, 0, sizeof(unsigned int)));
+    if (const char* ev = getenv("EXTRACK_NO_FUSED")) c->no_fused = atoi(ev) != 0;
     XT_CREATE(hipMalloc(&c->d_desc, XT_DESC_CAP * sizeof(XtBucketDesc)));
     XT_CREATE(hipHostMalloc(&c->h_desc, XT_DESC_CAP * sizeof(XtBucketDesc), hipHostMallocDefault));
 #undef XT_CREATE
@@ -254,6 +264,7 @@ extern "C" void extrack_destroy(extrack_ctx* ctx)
     if (ctx->d_gpartials) (void)hipFree(ctx->d_gpartials);
     if (ctx->d_partials) (void)hipFree(ctx->d_partials);
     if (ctx->d_total) (void)hipFree(ctx->d_total);
+    if (ctx->d_done) (void)hipFree(ctx->d_done);
     if (ctx->h_total) (void)hipHostFree(ctx->h_total);
     if (ctx->d_desc) (void)hipFree(ctx->d_desc);
     if (ctx->h_desc) (void)hipHostFree(ctx->h_desc);
@@ -463,6 +474,9 @@ static int xt_prepare(extrack_ctx* ctx, const extrack_model* m)
     XtModelHost mh;
     xt_model_host(m, mh);
     xt_build_blob(mh, ctx->cfg, ctx->blob_host);  // kept on the host: the launcher reads the scaling slots of the header
+    // a small blob rides in the kernel arguments (XtKernelArgs::blob_inline): no staging copy, one dispatch less per evaluation
+    ctx->blob_inline = !ctx->no_fused && ctx->blob_host.size() <= (size_t)XT_INLINE_BLOB;
+    if (ctx->blob_inline) return EXTRACK_OK;
     return xt_upload_blob(ctx, ctx->blob_host);
 }
 
@@ -528,13 +542,19 @@ struct DevLauncher {
         // one-wave-set-per-CU split ends in an under-occupied tail; with several block generations per CU the hardware
         // dispatcher backfills as blocks retire.
         const int nb = (int)descs.size();
-        const double target = (double)occ * ctx->n_cu * ctx->oversub;
+        double target = (double)occ * ctx->n_cu * ctx->oversub;
         std::vector<int64_t> nbatch(nb);
         double wsum = 0.0;
+        int64_t nbsum = 0;
         for (int i = 0; i < nb; ++i) {
             nbatch[i] = (descs[i].N + tracks_per_block - 1) / tracks_per_block;
             wsum += (double)nbatch[i] * (descs[i].L - 1);
+            nbsum += nbatch[i];
         }
+        // small launches: a block should still walk >= 4 batches (its fixed costs - tables, staging set-up, final reduction - are about
+        // one batch's worth), but never fewer blocks than fill the chip once.  125 000 x 30 (the 8-way shard of the headline dataset):
+        // 8 generations 0.399 ms, 4 generations 0.389 ms, 1 generation 0.423 ms (r04, same box)
+        if (!ctx->oversub_forced) target = std::max((double)occ * ctx->n_cu, std::min(target, (double)nbsum / 4.0));
         int64_t acc = 0;
         for (int i = 0; i < nb; ++i) {
             int64_t n = (int64_t)ceil(target * ((double)nbatch[i] * (descs[i].L - 1)) / wsum);
@@ -543,12 +563,26 @@ struct DevLauncher {
             a.blk_end[i] = (int32_t)acc;
         }
         grid = (int)acc;
-        memcpy(ctx->h_desc + desc_off, descs.data(), nb * sizeof(XtBucketDesc));
-        herr = hipMemcpyAsync(ctx->d_desc + desc_off, ctx->h_desc + desc_off, nb * sizeof(XtBucketDesc), hipMemcpyHostToDevice, ctx->stream);
-        if (herr != hipSuccess) return true;
-        // the staging half is reusable once this copy is done too: move the slot's guard event behind it
-        herr = hipEventRecord(ctx->ev_blob[(ctx->blob_turn - 1u) & 1u], ctx->stream);
-        if (herr != hipSuccess) return true;
+        // the descriptors only change when the buckets (or the per-track / posterior outputs) do: keep a host shadow of the device table
+        // and skip the copy when it already holds them (one dispatch less per evaluation in a fit)
+        bool same = !ctx->no_fused && ctx->desc_shadow.size() >= desc_off + (size_t)nb &&
+                    memcmp(ctx->desc_shadow.data() + desc_off, descs.data(), nb * sizeof(XtBucketDesc)) == 0;
+        if (!same) {
+            if (ctx->blob_inline) {  // no blob slot guards this half of the staging area: wait for whatever still reads it
+                herr = hipStreamSynchronize(ctx->stream);
+                if (herr != hipSuccess) return true;
+            }
+            memcpy(ctx->h_desc + desc_off, descs.data(), nb * sizeof(XtBucketDesc));
+            herr = hipMemcpyAsync(ctx->d_desc + desc_off, ctx->h_desc + desc_off, nb * sizeof(XtBucketDesc), hipMemcpyHostToDevice, ctx->stream);
+            if (herr != hipSuccess) return true;
+            if (!ctx->blob_inline) {
+                // the staging half is reusable once this copy is done too: move the slot's guard event behind it
+                herr = hipEventRecord(ctx->ev_blob[(ctx->blob_turn - 1u) & 1u], ctx->stream);
+                if (herr != hipSuccess) return true;
+            }
+            if (ctx->desc_shadow.size() < desc_off + (size_t)nb) ctx->desc_shadow.resize(desc_off + (size_t)nb);
+            memcpy(ctx->desc_shadow.data() + desc_off, descs.data(), nb * sizeof(XtBucketDesc));
+        }
         a.desc = ctx->d_desc + desc_off;
         a.ndesc = nb;
         void* kargs[1] = {(void*)&a};
@@ -571,8 +605,14 @@ int xt_reserve_partials(extrack_ctx* ctx, size_t n)
 }
 
 // Launches ONE kernel for a set of buckets that share (dims, sigma dims): partial sums go to d_partials[poff .. poff+grid).
+struct XtFuseTotal {
+    double* d_total;      // device word that receives the evaluation's total
+    double* h_total_dev;  // + the pinned host word (device view) or nullptr
+};
+
 static int xt_launch_group(extrack_ctx* ctx, const extrack_model* m, const std::vector<XtBucket*>& bks, bool preds, bool per_track,
-                           double* d_preds, size_t poff, size_t desc_off, int* grid_out, double* d_seq = nullptr)
+                           double* d_preds, size_t poff, size_t desc_off, int* grid_out, double* d_seq = nullptr,
+                           const XtFuseTotal* fuse = nullptr)
 {
     const XtConfig& c = ctx->cfg;
     const XtBucket& b0 = *bks[0];
@@ -647,7 +687,17 @@ static int xt_launch_group(extrack_ctx* ctx, const extrack_model* m, const std::
         d.seq_out = d_seq;
         l.descs.push_back(d);
     }
-    l.a.blob = ctx->d_blob;
+    if (ctx->blob_inline) {
+        l.a.blob = nullptr;
+        memcpy(l.a.blob_inline, ctx->blob_host.data(), ctx->blob_host.size() * sizeof(double));
+    } else {
+        l.a.blob = ctx->d_blob;
+    }
+    if (fuse) {
+        l.a.done = ctx->d_done;
+        l.a.total_out = fuse->d_total;
+        l.a.total_host = fuse->h_total_dev;
+    }
     l.a.base_tab = ctx->d_base_tab;
     l.a.off_tab = ctx->d_off_tab;
     l.a.partials = ctx->d_partials + poff;
@@ -673,7 +723,7 @@ static int xt_launch_group(extrack_ctx* ctx, const extrack_model* m, const std::
 // Upper bound of the blocks of one launch (= partial-sum slots to reserve).
 size_t xt_max_grid(const extrack_ctx* ctx) { return (size_t)ctx->n_cu * 8 * ctx->oversub + XT_MAX_BUCKETS; }
 
-static int xt_loglik_enqueue(extrack_ctx* ctx, const extrack_model* m, double* d_total, bool per_track)
+static int xt_loglik_enqueue(extrack_ctx* ctx, const extrack_model* m, double* d_total, bool per_track, bool to_host = false)
 {
     int rc = xt_validate_model(ctx, m);
     if (rc) return rc;
@@ -699,18 +749,25 @@ static int xt_loglik_enqueue(extrack_ctx* ctx, const extrack_model* m, double* d
     if (per_track)
         for (auto& b : ctx->buckets)
             if (!b.d_ll) XT_HIP(ctx, hipMalloc(&b.d_ll, (size_t)b.N * sizeof(double)));
-    size_t poff = 0, doff = xt_desc_base(ctx);
+    size_t poff = 0, doff = ctx->blob_inline ? 0 : xt_desc_base(ctx);
+    // one launch group (the usual case): the likelihood kernel itself leaves the total in d_total (and in the pinned host word for
+    // the synchronous entry point) - ONE dispatch per evaluation instead of five (blob copy, descriptor copy, kernel, reduction, read-back)
+    const bool fused = !ctx->no_fused && groups.size() == 1;
+    XtFuseTotal fz = {d_total, to_host ? ctx->h_total_dev : nullptr};
+    ctx->fused_host = fused && to_host;
     XT_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     for (auto& g : groups) {
         int grid = 0;
-        if ((rc = xt_launch_group(ctx, m, g, false, per_track, nullptr, poff, doff, &grid))) return rc;
+        if ((rc = xt_launch_group(ctx, m, g, false, per_track, nullptr, poff, doff, &grid, nullptr, fused ? &fz : nullptr))) return rc;
         poff += (size_t)grid;
         doff += g.size();
     }
     XT_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     ctx->timed = true;
-    hipLaunchKernelGGL(xt_reduce_partials, dim3(1), dim3(256), 0, ctx->stream, ctx->d_partials, (int)poff, d_total);
-    XT_HIP(ctx, hipGetLastError());
+    if (!fused) {
+        hipLaunchKernelGGL(xt_reduce_partials, dim3(1), dim3(256), 0, ctx->stream, ctx->d_partials, (int)poff, d_total);
+        XT_HIP(ctx, hipGetLastError());
+    }
     return EXTRACK_OK;
 }
 
@@ -723,9 +780,9 @@ extern "C" int extrack_loglik_async(extrack_ctx* ctx, const extrack_model* model
 extern "C" int extrack_loglik(extrack_ctx* ctx, const extrack_model* model, double* total_ll, double* per_track)
 {
     if (!ctx || !total_ll) return xt_fail(ctx, EXTRACK_E_INVALID, "null argument");
-    int rc = xt_loglik_enqueue(ctx, model, ctx->d_total, per_track != nullptr);
+    int rc = xt_loglik_enqueue(ctx, model, ctx->d_total, per_track != nullptr, true);
     if (rc) return rc;
-    XT_HIP(ctx, hipMemcpyAsync(ctx->h_total, ctx->d_total, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (!ctx->fused_host) XT_HIP(ctx, hipMemcpyAsync(ctx->h_total, ctx->d_total, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     if (per_track) {
         size_t o = 0;
         for (auto& b : ctx->buckets) {

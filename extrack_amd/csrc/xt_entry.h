@@ -31,7 +31,7 @@ XT_HD void xt_entry_body(const XtKernelArgs& a, Ctx& cx)
     const int tid = cx.tid();
     double* smem = cx.smem();
     const int ntab = xt_tab_doubles(S, G);
-    for (int i = tid; i < ntab; i += cx.nthreads()) smem[i] = a.blob[i];
+    for (int i = tid; i < ntab; i += cx.nthreads()) smem[i] = xt_blob_ptr(a)[i];
     const double* hdr = smem;
     const double* TAB = smem + XT_BLOB_HDR;
     const double* T64 = TAB + XT_NTAB * S * G;

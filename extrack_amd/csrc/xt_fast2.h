@@ -242,7 +242,7 @@ XT_HD void xt_ll_s2_body(const XtKernelArgs& a, Ctx& cx)
 
     // block-shared model tables + the 2^(j/64) table of the exponential
     const int ntab = xt_tab_doubles(2, 2);
-    for (int i = cx.tid(); i < ntab; i += cx.nthreads()) smem[i] = a.blob[i];
+    for (int i = cx.tid(); i < ntab; i += cx.nthreads()) smem[i] = xt_blob_ptr(a)[i];
     cx.sync();
     const double* hdr = smem;
     const double* TAB = smem + XT_BLOB_HDR;

@@ -80,6 +80,69 @@ static void xt_build_tangent_block(const XtModelHost& m, const extrack_model_tan
         }
 }
 
+// The same for the model tables of the THRESHOLD-FUSION kernels (xt_th_build_blob, xt_tables.h): second table index r in the reference's
+// digit order (digit c of r = c-th newest sub-state), stay term p_stay[r], end term indexed by the newest sub-state.  Layout of the block
+// as above (XT_BLOB_HDR + XT_NTAB * S * G doubles): the frozen-plan gradient kernel (xt_thgrad.h) returns the adjoint in that layout.
+static void xt_th_build_tangent_block(const XtModelHost& m, const extrack_model_tangent& t, int locerr_mode, double* tb)
+{
+    const int S = m.S, NS = m.NS;
+    int G = 1;
+    for (int i = 0; i < NS; ++i) G *= S;
+    const int TBn = xt_grad_tb_doubles(S, G);
+    for (int i = 0; i < TBn; ++i) tb[i] = 0.0;
+    if (locerr_mode == 0)
+        for (int k = 0; k < 3; ++k) {
+            const int kk = k < m.locerr_dims ? k : 0;
+            tb[k] = 2.0 * m.locerr[kk] * t.locerr[kk];
+        }
+    tb[3] = t.slope;
+    tb[4] = t.offset;
+    for (int s = 0; s < S; ++s) tb[8 + s] = m.Fs[s] != 0.0 ? t.Fs[s] / m.Fs[s] : 0.0;
+    const XtDual pBL(m.pBL, t.pBL), one(1.0, 0.0);
+    std::vector<XtDual> T((size_t)S * S), ds2(S), pst(G);
+    for (int i = 0; i < S * S; ++i) T[i] = XtDual(m.TrMat[i], t.TrMat[i]);
+    for (int s = 0; s < S; ++s) ds2[s] = XtDual(m.ds[s] * m.ds[s], t.ds2[s]);
+    for (int r = 0; r < G; ++r) pst[r] = XtDual(m.p_stay[r], t.p_stay[r]);
+    std::vector<XtDual> v(S), w(S);
+    for (int s = 0; s < S; ++s) {
+        const XtDual q1 = one - pst[s];  // raw newest state as index (reference quirk, tracking.py:624)
+        v[s] = pBL + q1 - pBL * q1;
+    }
+    for (int it = 0; it < NS; ++it) {
+        for (int i = 0; i < S; ++i) {
+            XtDual acc;
+            for (int j = 0; j < S; ++j) acc = acc + T[i * S + j] * v[j];
+            w[i] = acc;
+        }
+        v = w;
+    }
+    double* TAB = tb + XT_BLOB_HDR;
+    const size_t SG = (size_t)S * G;
+    for (int prev = 0; prev < S; ++prev)
+        for (int r = 0; r < G; ++r) {
+            int dig[8], rr = r;
+            for (int c = 0; c < NS; ++c) {
+                dig[c] = rr % S;
+                rr /= S;
+            }
+            dig[NS] = prev;
+            XtDual tp = one, d2;
+            for (int c = 0; c < NS; ++c) {
+                tp = tp * T[dig[c + 1] * S + dig[c]];
+                d2 = d2 + (ds2[dig[c]] + ds2[dig[c + 1]]) / 2.0;
+            }
+            d2 = d2 / (double)NS;
+            const XtDual stay = pst[r] * (one - pBL);
+            const XtDual ee = v[dig[0]];
+            const size_t o = (size_t)prev * G + r;
+            TAB[0 * SG + o] = xt_dlog(tp);
+            TAB[1 * SG + o] = xt_dlog(tp * stay);
+            TAB[2 * SG + o] = xt_dlog(tp * ee);
+            TAB[3 * SG + o] = xt_dlog(tp * stay * ee);
+            TAB[4 * SG + o] = d2.d;
+        }
+}
+
 
 // Register-resident 2-state kernels (xt_reg2.h): is this direction "uniform", i.e. does every weight factor of a step change by the SAME
 // relative amount for all sequences (no change of the localisation / diffusion variances, equal d log of the initial fractions, constant

@@ -159,6 +159,59 @@ struct DevCtx {
 
 // MAXT: 256 for the common one-wave-set-per-few-tracks geometry (lets the allocator use up to 256
 // VGPRs at 2 waves/SIMD if it needs them), 1024 when one track's groups need more than 256 threads.
+// Fused total of a likelihood launch (XtKernelArgs::done): called by every likelihood kernel after its body.  The block's partial sum
+// is in a.partials[blockIdx.x] (written by one of its threads); a device-scope counter finds the LAST block of the grid to get here, and
+// that block sums all partials in a fixed order (thread t takes the partials t, t + NT, ... sequentially; lanes by the DPP all-reduce;
+// wavefronts sequentially) - deterministic for a given launch geometry, like the separate xt_reduce_partials launch it replaces.
+// Visibility across the per-XCD L2s (MI355X_MICROARCH.md, "Correctness boundaries"): producer = workgroup barrier, then one thread
+// re-stores the partial with an agent-scope (sc1) store, drains it and increments the counter; consumer = agent-scope acquire fence after
+// the increment that saw the last count, and every partial is read with an agent-scope (sc1) load.
+__device__ __forceinline__ void xt_fused_total(const XtKernelArgs& a)
+{
+    if (!a.done) return;  // kernel argument: uniform over the grid
+    __syncthreads();      // the body is done with the LDS and this block's partial sum has been stored (HIP's barrier drains vmcnt first)
+    int* flag = (int*)(xt_smem + 16);
+    if (threadIdx.x == 0) {
+        // hand-off without an L2 write-back per block (an agent-scope release fence costs one): the block's partial is re-stored with an
+        // agent-scope (sc1, write-through) store and drained (vmcnt(0)) before the counter increment - the guide's "every store of the
+        // handed-off bytes sc1 and drained" form; the consumer reads with sc1 loads
+        const double mine = a.partials[blockIdx.x];
+        __hip_atomic_store(a.partials + blockIdx.x, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the store is acknowledged
+        const unsigned int prev = __hip_atomic_fetch_add(a.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = prev + 1u == gridDim.x;
+        if (last) __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        *flag = last;
+    }
+    __syncthreads();
+    if (!*flag) return;
+    const int n = (int)gridDim.x, nt = (int)blockDim.x;
+    double s = 0.0;
+    // eight loads in flight per thread (a dependent add after every single load would cost one memory round trip per partial)
+    for (int i0 = threadIdx.x; i0 < n; i0 += 8 * nt) {
+        double v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int i = i0 + k * nt;
+            v[k] = i < n ? __hip_atomic_load(a.partials + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += v[k];
+    }
+    DevCtx cx;
+    s = cx.group_sum_f64<64>(s);
+    __syncthreads();  // every thread has read the flag
+    if ((threadIdx.x & 63) == 0) xt_smem[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tot = 0.0;
+        for (int w = 0; w < (nt >> 6); ++w) tot += xt_smem[w];
+        *a.total_out = tot;
+        if (a.total_host) __hip_atomic_store(a.total_host, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(a.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch (stream-ordered)
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
@@ -238,6 +291,13 @@ struct extrack_ctx {
     size_t rf_cap_bytes[RF_SLOTS] = {0};
     double* d_total = nullptr;
     double* h_total = nullptr;  // pinned
+    double* h_total_dev = nullptr;   // the same word as the device sees it (the fused total is written there by the kernel itself)
+    unsigned int* d_done = nullptr;  // block counter of the fused total (zero between launches)
+    bool blob_inline = false;        // the model blob of the current evaluation travels in the kernel arguments (xt_prepare)
+    bool fused_host = false;         // the last xt_loglik_enqueue left the total in h_total (no device-to-host copy needed)
+    bool oversub_forced = false;     // EXTRACK_OVERSUB given: no adaptive block count for small launches
+    bool no_fused = false;           // EXTRACK_NO_FUSED=1: separate reduction launch + copies, as before round 4 (A/B)
+    std::vector<XtBucketDesc> desc_shadow;  // what d_desc[0 .. size) holds: unchanged descriptors are not copied again
     XtBucketDesc* d_desc = nullptr;  // [XT_DESC_CAP] bucket descriptors of the launches of one evaluation
     XtBucketDesc* h_desc = nullptr;  // pinned staging
     hipEvent_t ev0 = nullptr, ev1 = nullptr;

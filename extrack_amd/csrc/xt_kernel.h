@@ -32,6 +32,7 @@
 #define XT_NTAB 5       // tables [v][prev][q]: 0 T, 1 T*stay, 2 T*Eend, 3 T*stay*Eend, 4 d2
 
 #define XT_MAX_BUCKETS 64  // length buckets served by one launch
+#define XT_INLINE_BLOB 176 // doubles: model blobs up to this size are passed inside the kernel arguments (covers <= 4 states, nb_substeps 1)
 
 // One length bucket as seen by a launch that serves several buckets at once: the blocks [blk_end[i-1], blk_end[i]) of the
 // grid work on bucket i (XtKernelArgs::blk_end), striding over its track batches.
@@ -71,7 +72,29 @@ struct XtKernelArgs {
     int32_t prev_div;         // S^(F-NS-1): prev digit of group g = g / prev_div
     int32_t pw[16];           // S^i
     double ll_const;          // -(L-1)*D/2*log(2*pi)
+    // Fused total (round 4): when `done` is set the LAST block to finish (device counter) sums the per-block partials in a fixed order and
+    // writes the evaluation's total to total_out (device) and, when given, total_host (pinned host memory mapped into the device): no
+    // separate reduction launch, no device-to-host copy.  The counter is left at zero for the next launch.
+    unsigned int* done;
+    double* total_out;
+    double* total_host;
+    // Small model blobs travel in the kernel arguments instead of through a host-to-device copy (one dispatch less per evaluation):
+    // blob == nullptr -> the blob is blob_inline (read from the kernarg segment, see xt_blob_ptr).
+    double blob_inline[XT_INLINE_BLOB];
 };
+
+// The model blob of a launch: device memory, or the copy inside the kernel arguments themselves.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ const double* xt_blob_ptr(const XtKernelArgs& a)
+{
+    if (a.blob) return a.blob;
+    // the kernel's (only) argument is the XtKernelArgs struct at offset 0 of the kernarg segment; reading it through the segment pointer
+    // keeps a per-lane indexed load from turning the by-value struct into a scratch copy
+    return (const double*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + __builtin_offsetof(XtKernelArgs, blob_inline));
+}
+#else
+inline const double* xt_blob_ptr(const XtKernelArgs& a) { return a.blob ? a.blob : a.blob_inline; }
+#endif
 
 // LDS footprint in doubles.  Layout: [tables][per-track regions x TPB][pred accumulators x TPB]
 XT_HD int xt_tab_doubles(int S, int G) { return XT_BLOB_HDR + XT_NTAB * S * G + 64; }  // + T64[j] = 2^(j/64)
@@ -131,7 +154,7 @@ XT_HD void xt_track_body(const XtKernelArgs& a, Ctx& cx)
 
     // ---- model tables -> LDS
     const int ntab = xt_tab_doubles(S, G);
-    for (int i = tid; i < ntab; i += cx.nthreads()) smem[i] = a.blob[i];
+    for (int i = tid; i < ntab; i += cx.nthreads()) smem[i] = xt_blob_ptr(a)[i];
     const double* hdr = smem;
     const double* TAB = smem + XT_BLOB_HDR;
     const double* T64 = TAB + XT_NTAB * S * G;

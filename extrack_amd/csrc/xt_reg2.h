@@ -331,7 +331,7 @@ XT_HD void xt_r2_body(const XtKernelArgs& a, const XtGradArgs& ga, Ctx& cx)
     char* lds = (char*)smem;
 
     const int ntab = xt_tab_doubles(2, 2);
-    for (int i = cx.tid(); i < ntab; i += cx.nthreads()) smem[i] = a.blob[i];
+    for (int i = cx.tid(); i < ntab; i += cx.nthreads()) smem[i] = xt_blob_ptr(a)[i];
     if (NP > 0)
         for (int i = cx.tid(); i < NP * XT_R2_TB; i += cx.nthreads()) xt_at<double>(lds, XT_R2_TAN0 + i * 8) = ga.dblob[i];
     // "uniform" directions (ga.NU of them, tangent blocks after the NP full ones): d log of every weight factor of a step is the same for

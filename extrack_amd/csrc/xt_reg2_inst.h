@@ -15,6 +15,7 @@ __global__ void __launch_bounds__(64 * XT_F2_WAVES, XT_R2_LL_WAVES) xt_ll_r2_ker
     ga.dblob = nullptr;
     ga.gpartials = nullptr;
     xt_r2_body<F, D, K, 0>(a, ga, cx);
+    xt_fused_total(a);
 }
 
 // Waves per SIMD asked of the register allocator.  8 directions x 2 sequences x (1 + D + K) doubles of tangents alone are 128 VGPRs; measured

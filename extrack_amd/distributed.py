@@ -67,6 +67,7 @@ class Comm:
         self.backend = dist.get_backend(group)
         self.device = device if device is not None else ("cuda:%d" % torch.cuda.current_device() if self.backend == "nccl" else "cpu")
         self._buf = None
+        self._pin = {}
 
     # ---- scalars ------------------------------------------------------------------------------------------
     def allreduce_scalar(self, x, op="sum"):
@@ -199,13 +200,28 @@ class Comm:
             buf[0:n].zero_()
             buf[n:n + 1].fill_(1.0)
         self.dist.all_reduce(buf, op=self.dist.ReduceOp.SUM, group=self.group)
-        h = buf.cpu().numpy()
+        h = self._read_back(buf, n + 1)
         if h[n] > 0:
             buf[n:n + 1].zero_()
             if err is not None:
                 raise err
             raise RuntimeError("the evaluation failed on %d other rank(s)" % int(round(float(h[n]))))
         return h[:n].copy()
+
+    def _read_back(self, buf, n):
+        """The reduced doubles on the host: an asynchronous copy into a pinned buffer allocated once per size + ONE stream
+        synchronisation (``buf.cpu()`` allocates a tensor and takes the slow pageable path every evaluation: at the strong-scaled
+        shard of 125 000 tracks the kernel is ~0.4 ms and every 10 us of host work per evaluation is 2.5 % of the step)."""
+        torch = self.torch
+        if not buf.is_cuda:
+            return buf.numpy().copy()
+        pin = self._pin.get(n)
+        if pin is None:
+            t = torch.empty(n, dtype=torch.float64, pin_memory=True)
+            pin = self._pin[n] = (t, t.numpy())
+        pin[0].copy_(buf, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        return pin[1]
 
     def allreduce_loglik_grad(self, ts, model, tangents, n_dir):
         """{sum LL, d sum LL / d theta} over the ranks: with RCCL the gradient kernels write their 1 + n_dir sums into the buffer the

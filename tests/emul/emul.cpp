@@ -23,6 +23,7 @@
 #include "../../extrack_amd/csrc/xt_seqmat.h"
 #include "../../extrack_amd/csrc/xt_tables.h"
 #include "../../extrack_amd/csrc/xt_th.h"
+#include "../../extrack_amd/csrc/xt_thgrad.h"
 
 struct EmulLauncher {
     XtKernelArgs a;
@@ -319,6 +320,22 @@ extern "C" void xt_emul_th_set_dt(const double* dt, const double* p_stay_chunks)
     g_th_pstay_chunks = p_stay_chunks;
 }
 
+// Frozen-plan gradient (xt_thgrad.h) for the next xt_emul_th_run call: after the plan + apply bodies the gradient body follows the same plan.
+// tangents: n_dir rows of [locerr(3), slope, offset, pBL, ds2(S), Fs(S), TrMat(S*S), p_stay(G)]; out: [1 + n_dir] = {sum LL, d sum LL / d theta_i};
+// ll_out: per-track LL of the gradient body (or nullptr); waves: wavefronts per emulated workgroup.
+static int g_thg_ndir = -1, g_thg_waves = 1;
+static const double* g_thg_tangents = nullptr;
+static double* g_thg_out = nullptr;
+static double* g_thg_ll = nullptr;
+extern "C" void xt_emul_th_set_grad(int n_dir, const double* tangents, double* out, double* ll_out, int waves)
+{
+    g_thg_ndir = n_dir;
+    g_thg_tangents = tangents;
+    g_thg_out = out;
+    g_thg_ll = ll_out;
+    g_thg_waves = waves > 0 ? waves : 1;
+}
+
 // blobs of all chunks, one after the other (p_stay differs per chunk); returns the stride in doubles
 static int64_t th_chunk_blobs(const XtModelHost& m, int nchunks, int G, std::vector<double>& blobs)
 {
@@ -464,6 +481,56 @@ extern "C" int xt_emul_th_run(const double* tracks, const double* sigma, long lo
     double s = 0.0;
     for (double p : partials) s += p;
     if (total) *total = s;
+    if (g_thg_ndir >= 0) {  // the frozen-plan gradient body on the plan just made
+        const int n_dir = g_thg_ndir;
+        g_thg_ndir = -1;
+        if (a.dt) return -7;
+        const int TB = xt_grad_tb_doubles(S, G), row = 6 + 2 * S + S * S + G, NW = g_thg_waves;
+        std::vector<double> dblob((size_t)(n_dir > 0 ? n_dir : 1) * TB, 0.0);
+        for (int i = 0; i < n_dir; ++i) {
+            const double* r = g_thg_tangents + (size_t)i * row;
+            extrack_model_tangent t;
+            for (int k = 0; k < 3; ++k) t.locerr[k] = r[k];
+            t.slope = r[3];
+            t.offset = r[4];
+            t.pBL = r[5];
+            t.ds2 = r + 6;
+            t.Fs = r + 6 + S;
+            t.TrMat = r + 6 + 2 * S;
+            t.p_stay = r + 6 + 2 * S + S * S;
+            xt_th_build_tangent_block(m, t, locerr_mode, dblob.data() + (size_t)i * TB);
+        }
+        XtThGradArgs ga;
+        memset(&ga, 0, sizeof(ga));
+        ga.TB = TB;
+        ga.capP = maxG > S ? maxG : S;
+        ga.ws_stride = xt_thg_ws_doubles(ga.capP, L, D, K);
+        std::vector<double> gws((size_t)ga.ws_stride * grid * NW, xt_emul_poison() ? NAN : 0.0);
+        std::vector<double> gp((size_t)grid * NW * (1 + TB), 0.0);
+        ga.ws = gws.data();
+        ga.gpartials = gp.data();
+        a.ll_out = g_thg_ll;
+        const size_t glds = (size_t)xt_thg_lds_doubles(S, G, NW);
+#define TH_GRAD(DD, KK) th_emul_blocks(grid, 64 * NW, glds, [&](HostCtx& cx) { xt_thg_body<DD, KK>(a, ga, cx); })
+        if (D == 1 && K == 1) TH_GRAD(1, 1);
+        else if (D == 2 && K == 1) TH_GRAD(2, 1);
+        else if (D == 2 && K == 2) TH_GRAD(2, 2);
+        else if (D == 3 && K == 1) TH_GRAD(3, 1);
+        else if (D == 3 && K == 3) TH_GRAD(3, 3);
+        else return -3;
+#undef TH_GRAD
+        std::vector<double> adj(TB, 0.0);
+        g_thg_out[0] = 0.0;
+        for (int w = 0; w < grid * NW; ++w) {
+            g_thg_out[0] += gp[(size_t)w * (1 + TB)];
+            for (int c = 0; c < TB; ++c) adj[c] += gp[(size_t)w * (1 + TB) + 1 + c];
+        }
+        for (int i = 0; i < n_dir; ++i) {
+            double s2 = 0.0;
+            for (int c = 0; c < TB; ++c) s2 += adj[c] * dblob[(size_t)i * TB + c];
+            g_thg_out[1 + i] = s2;
+        }
+    }
     return 0;
 }
 

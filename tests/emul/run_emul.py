@@ -14,7 +14,7 @@ def lib():
         so = os.path.join(HERE, "libxt_emul.so")
         src = os.path.join(HERE, "emul.cpp")
         hdrs = [os.path.join(HERE, "..", "..", "extrack_amd", "csrc", h) for h in ("xt_kernel.h", "xt_math.h", "xt_tables.h", "xt_dispatch.h", "xt_th.h", "xt_entry.h", "xt_fast2.h", "xt_grad.h",
-                                                                                             "xt_grad_host.h", "xt_hist.h", "xt_hist_host.h", "xt_reg2.h", "xt_gradr.h", "xt_rev.h", "xt_seqmat.h")]
+                                                                                             "xt_grad_host.h", "xt_thgrad.h", "xt_hist.h", "xt_hist_host.h", "xt_reg2.h", "xt_gradr.h", "xt_rev.h", "xt_seqmat.h")]
         if not os.path.exists(so) or any(os.path.getmtime(f) > os.path.getmtime(so) for f in [src, os.path.join(HERE, "emul_r2.cpp"), os.path.join(HERE, "emul_gradr.cpp"), os.path.join(HERE, "emul_rev.cpp"), os.path.join(HERE, "emul_ctx.h")] + hdrs):
             import subprocess
             units = ["emul.cpp", "emul_r2.cpp", "emul_gradr.cpp", "emul_rev.cpp"]  # compiled side by side: emul_r2.cpp unrolls the whole step loop per instance
@@ -141,6 +141,34 @@ def run_th(Cs, LE, ds, Fs, T, pBL, isBL, p_stay, ns, F, min_len, threshold, max_
             steps[t] = [mem[c, t, gst[c, t, g]:gst[c, t, g + 1]].astype(int) for g in range(nG)]
         plan.append(steps)
     return ll, tot.value, plan, hdr, status
+
+
+def pack_tangents(tangents, S, G):
+    """Rows [locerr(3), slope, offset, pBL, ds2(S), Fs(S), TrMat(S*S), p_stay(G)] of a list of tangent dicts."""
+    rows = []
+    for t in tangents:
+        le = np.zeros(3)
+        v = np.atleast_1d(np.asarray(t.get("locerr", 0.0), float)).ravel()
+        le[:len(v)] = v
+        rows.append(np.concatenate([le, [t.get("slope", 0.0), t.get("offset", 0.0), t.get("pBL", 0.0)],
+                                    np.broadcast_to(np.asarray(t.get("ds2", 0.0), float), (S,)),
+                                    np.broadcast_to(np.asarray(t.get("Fs", 0.0), float), (S,)),
+                                    np.broadcast_to(np.asarray(t.get("TrMat", 0.0), float), (S, S)).ravel(),
+                                    np.broadcast_to(np.asarray(t.get("p_stay", 0.0), float), (G,))]))
+    return np.ascontiguousarray(np.array(rows, float)) if rows else np.zeros((1, 1))
+
+
+def run_th_grad(Cs, LE, ds, Fs, T, pBL, isBL, p_stay, ns, F, min_len, threshold, max_nb, tangents, waves=1, **kw):
+    """Threshold-fusion plan + apply bodies, then the frozen-plan gradient body (xt_thgrad.h) on the plan just made.
+    Returns (apply LL per track, gradient-body LL per track, gradient-body total, gradient[n_dir], plan)."""
+    N = len(Cs)
+    S = len(ds)
+    tan = pack_tangents(tangents, S, S ** ns)
+    out = np.zeros(len(tangents) + 1)
+    llg = np.zeros(N)
+    lib().xt_emul_th_set_grad(len(tangents), dp(tan), dp(out), dp(llg), int(waves))
+    ll, tot, plan, hdr, status = run_th(Cs, LE, ds, Fs, T, pBL, isBL, p_stay, ns, F, min_len, threshold, max_nb, **kw)
+    return ll, llg, out[0], out[1:], plan
 
 
 def run_th_predict(Cs, LE, ds, Fs, T, pBL, isBL, p_stay, F, min_len, threshold, max_nb, chunk=1, capE=256, threads=64, nblocks=2,
