@@ -17,7 +17,7 @@ EXPORTS = [
     "extrack_loglik", "extrack_loglik_async", "extrack_predict", "extrack_last_kernel_ms",
     "extrack_last_launch_info", "extrack_p_stay_table", "extrack_loglik_th", "extrack_loglik_th_async", "extrack_th_plan_step",
     "extrack_predict_th", "extrack_loglik_grad", "extrack_loglik_grad_async", "extrack_last_grad_ms", "extrack_segment_len_hist", "extrack_refine_positions",
-    "extrack_sequence_columns", "extrack_sequence_matrix",
+    "extrack_sequence_columns", "extrack_sequence_matrix", "extrack_loglik_th_grad", "extrack_loglik_th_grad_async",
 ]
 
 _dp = C.POINTER(C.c_double)
@@ -39,6 +39,9 @@ class ExtrackModelTangent(C.Structure):
         ("locerr", C.c_double * 3), ("slope", C.c_double), ("offset", C.c_double), ("pBL", C.c_double),
         ("ds2", _dp), ("Fs", _dp), ("TrMat", _dp), ("p_stay", _dp),
     ]
+
+
+E_INVALID, E_HIP, E_NODEVICE, E_UNSUPPORTED = -1, -2, -3, -4  # include/extrack_hip.h
 
 
 class ExtrackError(RuntimeError):
@@ -111,7 +114,9 @@ def load():
     lib.extrack_sequence_columns.argtypes = [i32, i32, i32, i32, i32]
     lib.extrack_sequence_columns.restype = i64
     lib.extrack_sequence_matrix.argtypes = [vp, C.POINTER(ExtrackModel), i32, vp, i64]
-    if lib.extrack_abi_version() != 5:
+    lib.extrack_loglik_th_grad.argtypes = [vp, C.POINTER(ExtrackModel), C.c_double, i32, i32, i32, C.POINTER(ExtrackModelTangent), _dp, vp]
+    lib.extrack_loglik_th_grad_async.argtypes = [vp, C.POINTER(ExtrackModel), C.c_double, i32, i32, i32, C.POINTER(ExtrackModelTangent), vp]
+    if lib.extrack_abi_version() != 6:
         raise ImportError("libextrack_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -286,6 +291,22 @@ class Context:
         {sum LL, gradient} in stream order (the multi-GPU objective all-reduces it there)."""
         n, arr, keep = self._pack_tangents(model, tangents)
         self._check(self._lib.extrack_loglik_grad_async(self._h, C.byref(model.c), n, arr, C.c_void_p(d_out_ptr)))
+        return n
+
+    def loglik_th_grad(self, model, tangents, threshold=0.2, max_nb_states=120, chunk=2000):
+        """(sum LL, d sum LL / d theta_i) of the threshold-fusion objective at the frozen plan of this evaluation (extrack_loglik_th_grad)."""
+        n, arr, keep = self._pack_tangents(model, tangents)
+        tot = C.c_double(0.0)
+        g = np.zeros(max(n, 1))
+        self._check(self._lib.extrack_loglik_th_grad(self._h, C.byref(model.c), C.c_double(threshold), int(max_nb_states), int(chunk), n, arr,
+                                                     C.byref(tot), g.ctypes.data_as(C.c_void_p)))
+        return tot.value, g[:n]
+
+    def loglik_th_grad_async(self, model, tangents, threshold, max_nb_states, chunk, d_out_ptr):
+        """Enqueues the evaluation; the DEVICE buffer ``d_out_ptr`` (1 + n doubles) receives {sum LL, gradient} in stream order."""
+        n, arr, keep = self._pack_tangents(model, tangents)
+        self._check(self._lib.extrack_loglik_th_grad_async(self._h, C.byref(model.c), C.c_double(threshold), int(max_nb_states), int(chunk), n, arr,
+                                                           C.c_void_p(d_out_ptr)))
         return n
 
     def segment_len_hist(self, model, bucket_id, max_nb_states=500):

@@ -55,6 +55,13 @@ static XtGradDst xt_grad_dst_identity(int base)
     return d;
 }
 
+void xt_grad_reduce_launch(hipStream_t st, const double* partials, int nrows, int ncol, double* ll_dst, double* out)
+{
+    XtGradDst d;
+    for (int i = 0; i < 16; ++i) d.idx[i] = i;
+    hipLaunchKernelGGL(xt_grad_reduce, dim3(ncol), dim3(256), 0, st, partials, nrows, ncol, ll_dst, out, d);
+}
+
 struct GradLauncher {
     extrack_ctx* ctx;
     XtKernelArgs a;

@@ -1055,7 +1055,7 @@ static int xt_th_split_streams(extrack_ctx* ctx)
 // of its longest chunk - is in flight.
 static int xt_th_run_group(extrack_ctx* ctx, const extrack_model* m, const std::vector<XtBucket*>& bks, double threshold, int32_t max_nb_states,
                            int32_t chunk, int G, bool per_track, size_t& poff, const std::vector<int64_t>* chunk_base,
-                           const std::function<int()>* between = nullptr)
+                           const std::function<int()>* between = nullptr, const XtThAfterPlan* after_plan = nullptr)
 {
     const int S = m->n_states, NS = m->nb_substeps, F = m->frame_len;
     const XtBucket& b0 = *bks[0];
@@ -1252,6 +1252,7 @@ static int xt_th_run_group(extrack_ctx* ctx, const extrack_model* m, const std::
             return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "more than 8192 live state sequences per step (threshold fusion expands every sequence by n_states^nb_substeps before it merges): raise threshold, lower max_nb_states or nb_substeps - or use the fixed-window kernel (fusion='window' / extrack_loglik), which serves this model");
         ctx->th_capE = ncap;
     }
+    if (after_plan) return (*after_plan)(a, D, K, maxG, Lmax);  // the plan is all the caller wanted (frozen-plan gradient, extrack_thgrad.hip)
     // apply geometry: a workgroup serves tiles of TT tracks of one chunk and keeps that chunk's plan in LDS when it is small
     // enough (always, for the usual 2-3 state models); TT = as many tracks as keep the tile within ~48 KiB of LDS
     a.capG = maxG;
@@ -1451,6 +1452,47 @@ static int xt_loglik_th_enqueue(extrack_ctx* ctx, const extrack_model* m, double
     ctx->timed = true;
     hipLaunchKernelGGL(xt_reduce_partials, dim3(1), dim3(256), 0, ctx->stream, ctx->d_partials, (int)poff, d_total);
     XT_HIP(ctx, hipGetLastError());
+    return EXTRACK_OK;
+}
+
+// The plan stage alone, for every launch group (buckets sharing dims / sigma dims) of the uploaded dataset: validates like
+// xt_loglik_th_enqueue, uploads the threshold-fusion blob (ctx->d_blob), runs the plan kernel (capacity growth included) and hands the
+// group's arguments to `cb` (extrack_thgrad.hip launches the frozen-plan gradient kernel there).  One stream, no concurrent groups.
+int xt_th_plan_groups(extrack_ctx* ctx, const extrack_model* m, double threshold, int32_t max_nb_states, int32_t chunk, const XtThAfterPlan& cb)
+{
+    int rc = xt_validate_model(ctx, m);
+    if (rc) return rc;
+    if (ctx->buckets.empty()) return xt_fail(ctx, EXTRACK_E_INVALID, "no bucket uploaded");
+    if (chunk < 1) return xt_fail(ctx, EXTRACK_E_INVALID, "chunk must be >= 1");
+    if (!(threshold >= 0.0)) return xt_fail(ctx, EXTRACK_E_INVALID, "threshold must be >= 0");
+    if (m->frame_len <= m->nb_substeps || m->frame_len > 15) return xt_fail(ctx, EXTRACK_E_INVALID, "frame_len must be in (nb_substeps, 15]");
+    for (auto& b : ctx->buckets)
+        if (b.d_dt) return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "per-track time steps are not served by the frozen-plan gradient");
+    if (m->n_p_stay > 1) return xt_fail(ctx, EXTRACK_E_INVALID, "several p_stay tables but no per-track time steps");
+    XT_HIP(ctx, hipSetDevice(ctx->device));
+    XtModelHost mh;
+    xt_model_host(m, mh);
+    std::vector<double> blob;
+    int G = 0;
+    std::string err = xt_th_build_blob(mh, blob, G);
+    if (!err.empty()) return xt_fail(ctx, EXTRACK_E_INVALID, err);
+    if ((rc = xt_upload_blob(ctx, blob))) return rc;
+    if (m->n_states * G > XT_TH_MAXCAP) return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "n_states^(nb_substeps+1) exceeds the plan capacity");
+    std::vector<XtBucket*> order;
+    for (auto& b : ctx->buckets) order.push_back(&b);
+    std::stable_sort(order.begin(), order.end(), [](const XtBucket* x, const XtBucket* y) {
+        if (x->D != y->D) return x->D < y->D;
+        if (x->KS != y->KS) return x->KS < y->KS;
+        return x->L > y->L;
+    });
+    size_t poff = 0;
+    for (size_t i = 0; i < order.size();) {
+        size_t jn = i;
+        std::vector<XtBucket*> grp;
+        while (jn < order.size() && order[jn]->D == order[i]->D && order[jn]->KS == order[i]->KS) grp.push_back(order[jn++]);
+        if ((rc = xt_th_run_group(ctx, m, grp, threshold, max_nb_states, chunk, G, false, poff, nullptr, nullptr, &cb))) return rc;
+        i = jn;
+    }
     return EXTRACK_OK;
 }
 

@@ -1,0 +1,175 @@
+// libextrack_hip.so, translation unit: log-likelihood + exact gradient of the THRESHOLD-FUSION objective at the frozen plan of the
+// evaluation (xt_thgrad.h) behind extrack_loglik_th_grad.  Replaces the finite-difference loop that lmfit's BFGS runs around
+// cum_Proba_Cs -> P_Cs_inter_bound_stats_th (extrack/tracking.py:1371 -> :991 -> :427-743).
+#include "xt_host.h"
+
+#include "xt_grad_host.h"
+#include "xt_thgrad.h"
+
+// one lane per track; state in a per-wavefront region of global memory, table adjoints in LDS rows: the kernel is bound by memory
+// latency, not registers - let the allocator use what it wants, occupancy is set by the LDS rows
+template <int D, int K>
+__global__ void __launch_bounds__(256) xt_thg_kernel(XtThArgs a, XtThGradArgs ga)
+{
+    DevCtx cx;
+    xt_thg_body<D, K>(a, ga, cx);
+}
+
+static int xt_thg_reserve(extrack_ctx* ctx, double** buf, size_t* cap, size_t n)
+{
+    if (n <= *cap) return EXTRACK_OK;
+    XT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (*buf) (void)hipFree(*buf);
+    *buf = nullptr;
+    *cap = 0;
+    XT_HIP(ctx, hipMalloc(buf, n * sizeof(double)));
+    *cap = n;
+    return EXTRACK_OK;
+}
+
+// Enqueues plan + gradient kernels of one evaluation; d_out (device, 1 + n_dir doubles) receives {sum LL, d sum LL / d theta_i}.  The plan
+// stage reads the chunks' sequence counts back (as extrack_loglik_th does); everything after it is stream-ordered.
+static int xt_th_grad_enqueue(extrack_ctx* ctx, const extrack_model* m, double threshold, int32_t max_nb_states, int32_t chunk, int32_t n_dir,
+                              const extrack_model_tangent* tangents, double* d_out)
+{
+    int rc = xt_validate_model(ctx, m);
+    if (rc) return rc;
+    for (int i = 0; i < n_dir; ++i)
+        if (!tangents[i].ds2 || !tangents[i].Fs || !tangents[i].TrMat || !tangents[i].p_stay) return xt_fail(ctx, EXTRACK_E_INVALID, "null tangent field");
+    const int S = m->n_states, NS = m->nb_substeps;
+    if (S < 2 || S > XT_MAX_STATES || NS < 1 || NS > 4) return xt_fail(ctx, EXTRACK_E_INVALID, "n_states must be in [2, 8], nb_substeps in [1, 4]");
+    int G = 1;
+    for (int i = 0; i < NS; ++i) G *= S;
+    const int TB = xt_grad_tb_doubles(S, G);
+    // one wavefront's accumulator rows must leave room for at least two workgroups per CU
+    if ((size_t)xt_thg_lds_doubles(S, G, 1) * sizeof(double) > 80 * 1024)
+        return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "frozen-plan gradient: n_states^(nb_substeps+1) table adjoints do not fit the LDS (use finite differences)");
+    XT_HIP(ctx, hipSetDevice(ctx->device));
+    // tangent blocks of the directions (threshold-fusion table layout) -> device
+    XtModelHost mh;
+    xt_model_host(m, mh);
+    const size_t ndbl = (size_t)std::max(n_dir, 1) * TB;
+    if (ctx->dblob_busy) {
+        XT_HIP(ctx, hipEventSynchronize(ctx->ev_dblob));
+        ctx->dblob_busy = false;
+    }
+    if (ndbl > ctx->h_dblob_cap) {
+        if (ctx->h_dblob) (void)hipHostFree(ctx->h_dblob);
+        ctx->h_dblob = nullptr;
+        ctx->h_dblob_cap = 0;
+        XT_HIP(ctx, hipHostMalloc((void**)&ctx->h_dblob, ndbl * sizeof(double)));
+        ctx->h_dblob_cap = ndbl;
+    }
+    if (!ctx->ev_dblob) XT_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_dblob, hipEventDisableTiming));
+    for (int i = 0; i < n_dir; ++i) xt_th_build_tangent_block(mh, tangents[i], m->locerr_mode, ctx->h_dblob + (size_t)i * TB);
+    if ((rc = xt_thg_reserve(ctx, &ctx->d_dblob, &ctx->dblob_cap, ndbl))) return rc;
+    XT_HIP(ctx, hipMemcpyAsync(ctx->d_dblob, ctx->h_dblob, ndbl * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    XT_HIP(ctx, hipEventRecord(ctx->ev_dblob, ctx->stream));
+    ctx->dblob_busy = true;
+    if ((rc = xt_thg_reserve(ctx, &ctx->d_revadj, &ctx->revadj_cap, (size_t)TB))) return rc;
+    if (!ctx->evg0) XT_HIP(ctx, hipEventCreate(&ctx->evg0));
+    if (!ctx->evg1) XT_HIP(ctx, hipEventCreate(&ctx->evg1));
+    XT_HIP(ctx, hipEventRecord(ctx->evg0, ctx->stream));
+
+    // per-wavefront output rows of all launch groups, one after the other
+    size_t rows = 0;
+    const XtThAfterPlan cb = [&](XtThArgs& a, int D, int K, int maxG, int Lmax) -> int {
+        XtThGradArgs ga;
+        memset(&ga, 0, sizeof(ga));
+        ga.TB = TB;
+        ga.capP = std::max(maxG, S);
+        ga.ws_stride = xt_thg_ws_doubles(ga.capP, Lmax, D, K);
+        // wavefronts per workgroup: the accumulator rows of a wavefront decide how many wavefronts a CU holds
+        const size_t row_bytes = (size_t)xt_thg_rows(S, G) * 64 * sizeof(double);
+        const int NW = row_bytes <= 8 * 1024 ? 4 : (row_bytes <= 16 * 1024 ? 2 : 1);
+        const size_t lds = (size_t)xt_thg_lds_doubles(S, G, NW) * sizeof(double);
+        const int threads = 64 * NW;
+        int blocks_per_cu = (int)std::min<size_t>(16, (160 * 1024) / lds);
+        blocks_per_cu = std::max(1, std::min(blocks_per_cu, 32 / NW));  // at most 8 wavefronts per SIMD
+        const int64_t tpc = ((int64_t)a.chunk + 63) / 64;                 // tiles per chunk
+        // scratch budget: every wavefront of the launch owns a region (EXTRACK_THG_WS_MB, default 48 GiB of the 288)
+        size_t budget_mb = 48 * 1024;
+        if (const char* ev = getenv("EXTRACK_THG_WS_MB")) budget_mb = (size_t)std::max(64, atoi(ev));
+        const int64_t max_waves = std::max<int64_t>(1, (int64_t)((budget_mb << 20) / ((size_t)ga.ws_stride * sizeof(double))));
+        int64_t target = (int64_t)ctx->n_cu * blocks_per_cu * 2;
+        target = std::min(target, std::max<int64_t>(1, max_waves / NW));
+        int64_t bpc = std::max<int64_t>(1, std::min<int64_t>((target + a.nchunks - 1) / a.nchunks, (tpc + NW - 1) / NW));
+        if ((int64_t)a.nchunks * bpc * NW > max_waves && a.nchunks > max_waves / NW)
+            return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "frozen-plan gradient: the state log of one wavefront per chunk exceeds the scratch budget (EXTRACK_THG_WS_MB)");
+        a.bpc = (int32_t)bpc;
+        const int grid = (int)(a.nchunks * bpc);
+        const size_t nw_total = (size_t)grid * NW;
+        int rc2;
+        if ((rc2 = xt_thg_reserve(ctx, &ctx->d_revlog, &ctx->revlog_cap, nw_total * (size_t)ga.ws_stride))) return rc2;
+        // d_gpartials may still hold the rows of an earlier group of this evaluation: grow by copy
+        const size_t need = (rows + nw_total) * (size_t)(1 + TB);
+        if (need > ctx->gpartials_cap) {
+            double* nw = nullptr;
+            XT_HIP(ctx, hipMalloc(&nw, need * 2 * sizeof(double)));
+            if (ctx->d_gpartials) {
+                if (rows) XT_HIP(ctx, hipMemcpyAsync(nw, ctx->d_gpartials, rows * (size_t)(1 + TB) * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+                XT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                (void)hipFree(ctx->d_gpartials);
+            }
+            ctx->d_gpartials = nw;
+            ctx->gpartials_cap = need * 2;
+        }
+        ga.ws = ctx->d_revlog;
+        ga.gpartials = ctx->d_gpartials + rows * (size_t)(1 + TB);
+        const void* kp = nullptr;
+        if (D == 1 && K == 1) kp = (const void*)xt_thg_kernel<1, 1>;
+        else if (D == 2 && K == 1) kp = (const void*)xt_thg_kernel<2, 1>;
+        else if (D == 2 && K == 2) kp = (const void*)xt_thg_kernel<2, 2>;
+        else if (D == 3 && K == 1) kp = (const void*)xt_thg_kernel<3, 1>;
+        else if (D == 3 && K == 3) kp = (const void*)xt_thg_kernel<3, 3>;
+        else return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "frozen-plan gradient: track / error dimensionality not built");
+        if (lds > 64 * 1024) XT_HIP(ctx, hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        void* kargs[2] = {(void*)&a, (void*)&ga};
+        XT_HIP(ctx, hipLaunchKernel(kp, dim3(grid), dim3(threads), kargs, lds, ctx->stream));
+        XT_HIP(ctx, hipGetLastError());
+        rows += nw_total;
+        ctx->launch_info[0] = grid;
+        ctx->launch_info[1] = threads;
+        ctx->launch_info[2] = (int32_t)lds;
+        ctx->launch_info[3] = 64;
+        ctx->launch_info[4] = blocks_per_cu;
+        ctx->launch_info[5] = ctx->n_cu;
+        if (getenv("EXTRACK_TH_DEBUG"))
+            fprintf(stderr, "[thgrad] chunks %d maxG %d Lmax %d | NW %d lds %zu bpc %d grid %d ws/wave %.2f MB total %.1f MB\n", a.nchunks, maxG, Lmax, NW, lds,
+                    a.bpc, grid, ga.ws_stride * 8.0 / 1048576.0, nw_total * ga.ws_stride * 8.0 / 1048576.0);
+        return EXTRACK_OK;
+    };
+    if ((rc = xt_th_plan_groups(ctx, m, threshold, max_nb_states, chunk, cb))) return rc;
+    // fixed-order sums over the wavefronts: column 0 = sum LL, columns 1 .. TB = adjoint of the model blob; then < adjoint, tangent block >
+    xt_grad_reduce_launch(ctx->stream, ctx->d_gpartials, (int)rows, TB + 1, d_out, ctx->d_revadj);
+    XT_HIP(ctx, hipGetLastError());
+    if (n_dir > 0) {
+        xt_rev_project(ctx->stream, ctx->d_revadj, ctx->d_dblob, TB, n_dir, d_out + 1);
+        XT_HIP(ctx, hipGetLastError());
+    }
+    XT_HIP(ctx, hipEventRecord(ctx->evg1, ctx->stream));
+    ctx->grad_timed = true;
+    return EXTRACK_OK;
+}
+
+extern "C" int extrack_loglik_th_grad_async(extrack_ctx* ctx, const extrack_model* m, double threshold, int32_t max_nb_states, int32_t chunk,
+                                            int32_t n_dir, const extrack_model_tangent* tangents, double* d_out)
+{
+    if (!ctx || !d_out || n_dir < 0 || (n_dir > 0 && !tangents)) return xt_fail(ctx, EXTRACK_E_INVALID, "null argument");
+    return xt_th_grad_enqueue(ctx, m, threshold, max_nb_states, chunk, n_dir, tangents, d_out);
+}
+
+extern "C" int extrack_loglik_th_grad(extrack_ctx* ctx, const extrack_model* m, double threshold, int32_t max_nb_states, int32_t chunk,
+                                      int32_t n_dir, const extrack_model_tangent* tangents, double* total_ll, double* grad)
+{
+    if (!ctx || !total_ll || n_dir < 0 || (n_dir > 0 && (!tangents || !grad))) return xt_fail(ctx, EXTRACK_E_INVALID, "null argument");
+    int rc = xt_thg_reserve(ctx, &ctx->d_gout, &ctx->gout_cap, (size_t)n_dir + 1);
+    if (rc) return rc;
+    if ((rc = xt_th_grad_enqueue(ctx, m, threshold, max_nb_states, chunk, n_dir, tangents, ctx->d_gout))) return rc;
+    std::vector<double> host((size_t)n_dir + 1);
+    XT_HIP(ctx, hipMemcpyAsync(host.data(), ctx->d_gout, host.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    XT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *total_ll = host[0];
+    for (int i = 0; i < n_dir; ++i) grad[i] = host[1 + i];
+    return EXTRACK_OK;
+}

@@ -375,5 +375,11 @@ size_t xt_max_grid(const extrack_ctx* ctx);
 __global__ void xt_reduce_partials(const double* __restrict__ partials, int n, double* __restrict__ out);
 const void* xt_r2_kernel(int F, int D, int K, int NP);  // extrack_reg2.hip: register-resident 2-state kernels, nullptr = not built
 const void* xt_rev_kernel_ptr(int G, int D, int K, int nbuf);  // extrack_rev.hip: reverse-mode gradient kernels (xt_rev.h), 1 | 2 exchange buffers
+// threshold-fusion plan stage for other translation units (extrack_hip.hip): `cb` gets, per launch group, the kernel arguments with the plan
+// made (a.buckets / a.chunk_end on the device), the track / error dimensionality, the largest group count of its chunks and the longest length
+typedef std::function<int(XtThArgs& a, int D, int K, int maxG, int Lmax)> XtThAfterPlan;
+int xt_th_plan_groups(extrack_ctx* ctx, const extrack_model* m, double threshold, int32_t max_nb_states, int32_t chunk, const XtThAfterPlan& cb);
+// column sums of per-block partials [nrows][ncol] (extrack_grad.hip): column 0 -> *ll_dst, column 1 + i -> out[i]
+void xt_grad_reduce_launch(hipStream_t st, const double* partials, int nrows, int ncol, double* ll_dst, double* out);
 void xt_rev_project(hipStream_t st, const double* adj, const double* dblob, int TB, int n_dir, double* out);  // out[i] = <adj, dblob[i]>
 const void* xt_gradr_kernel_ptr(int G, int D, int K, int NPC);  // extrack_gradr.hip: register-resident gradient kernels (xt_gradr.h), NPC = 3 | 4

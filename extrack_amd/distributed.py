@@ -236,6 +236,22 @@ class Comm:
             return np.concatenate([[ll], g])
         return self.allreduce_checked(local, 1 + n_dir)
 
+    def allreduce_loglik_th_grad(self, ts, model, tangents, n_dir, threshold, max_nb_states, chunk):
+        """{sum LL, d sum LL / d theta} of the threshold-fusion objective at the frozen plan of the evaluation, over chunk-aligned shards
+        (every rank plans and differentiates exactly the chunks a single GPU would): one all-reduce of 1 + n_dir doubles."""
+        if getattr(ts, "shard_chunk", None) != chunk:
+            raise ValueError("fusion='threshold' needs shards aligned to the %d-track chunks (Comm.shard_trackset(..., chunk=%d))"
+                             % (chunk, chunk))
+        if self.backend == "nccl":
+            return self._reduce_on_stream(ts, lambda ptr: ts.ctx.loglik_th_grad_async(model, tangents, threshold, max_nb_states, chunk, ptr), 1 + n_dir)
+
+        def local():
+            if not ts.n_tracks:
+                return np.zeros(1 + n_dir)
+            ll, g = ts.ctx.loglik_th_grad(model, tangents, threshold, max_nb_states, chunk)
+            return np.concatenate([[ll], g])
+        return self.allreduce_checked(local, 1 + n_dir)
+
     def _device_buffer(self, ts, n=2):
         """fp64 device buffer of ``n`` doubles on this rank's GPU (the last one is the failure flag) + the context bound to torch's
         current stream (kernels and the collective are ordered on one stream)."""

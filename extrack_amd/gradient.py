@@ -43,21 +43,18 @@ def values_along(params, name, h=_H):
     complex arithmetic.  Raises TypeError / NameError when an expression is not complex-differentiable."""
     vals = {k: complex(p.value) for k, p in params.items()}
     vals[name] += 1j * h
-    pending = [p for p in params.values() if getattr(p, "_code", None) is not None]
-    for _ in range(len(pending) + 1):
-        if not pending:
+    exprs = [p for p in params.values() if getattr(p, "_code", None) is not None]
+    env = dict(_CSAFE)
+    env.update(vals)
+    # expressions may depend on each other in any order (c = 'b*3', b = '2*a'): sweep until nothing changes (a chain of depth d settles in d sweeps)
+    for _ in range(len(exprs) + 1):
+        changed = False
+        for p in exprs:
+            new = complex(eval(p._code, {"__builtins__": {}}, env))
+            changed = changed or new != vals[p.name]
+            vals[p.name] = env[p.name] = new
+        if not changed:
             break
-        env = dict(_CSAFE)
-        env.update(vals)
-        nxt = []
-        for p in pending:
-            try:
-                vals[p.name] = complex(eval(p._code, {"__builtins__": {}}, env))
-            except NameError:
-                nxt.append(p)
-        if len(nxt) == len(pending):
-            raise NameError("unresolved names in parameter expressions")
-        pending = nxt
     return vals
 
 
@@ -87,23 +84,24 @@ def _values_batched(params, names, h=_H):
         vals[k] = np.full(n, complex(p.value))
     for i, nm in enumerate(names):
         vals[nm][i] += 1j * h
-    pending = [(k, _expr_code(p)) for k, p in params.items() if getattr(p, "expr", None)]
-    for _ in range(len(pending) + 1):
-        if not pending:
-            break
-        env = dict(_NSAFE)
-        env.update(vals)
-        nxt = []
-        for k, code in pending:
+    exprs = [(k, _expr_code(p)) for k, p in params.items() if getattr(p, "expr", None)]
+    env = dict(_NSAFE)
+    env.update(vals)
+    # expressions may depend on each other in any order (c = 'b*3', b = '2*a'): every sweep re-evaluates all of them against the values
+    # AND tangents refreshed so far, until nothing changes (a chain of depth d settles in d sweeps)
+    for _ in range(len(exprs) + 1):
+        changed = False
+        for k, code in exprs:
             try:
-                vals[k] = np.asarray(eval(code, {"__builtins__": {}}, env), complex) * np.ones(n)
+                new = np.asarray(eval(code, {"__builtins__": {}}, env), complex) * np.ones(n)
             except NameError as e:
                 if any(nm in str(e) for nm in ("abs", "min", "max", "fabs", "floor", "ceil")):
                     raise TypeError("parameter expression is not analytic: %s" % e)
-                nxt.append((k, code))
-        if len(nxt) == len(pending):
-            raise NameError("unresolved names in parameter expressions")
-        pending = nxt
+                raise
+            changed = changed or not np.array_equal(new, vals[k])
+            vals[k] = env[k] = new
+        if not changed:
+            break
     return vals
 
 
@@ -175,17 +173,37 @@ def analytic_support(params, names):
     return None
 
 
-def objective_and_gradient(params, ts, dt, cell_dims, nb_states, nb_substeps, frame_len, Matrix_type=1, comm=None, names=None):
+def objective_and_gradient(params, ts, dt, cell_dims, nb_states, nb_substeps, frame_len, Matrix_type=1, comm=None, names=None,
+                           threshold_fusion=None):
     """(-sum LL, d(-sum LL)/d(free parameter VALUES)) at ``params`` on the TrackSet ``ts``; (+inf, zeros) for invalid parameters.
-    ``comm``: extrack_amd.distributed.Comm - the (1 + nvar) vector is all-reduced over the ranks."""
+    ``comm``: extrack_amd.distributed.Comm - the (1 + nvar) vector is all-reduced over the ranks.
+    ``threshold_fusion``: None = the fixed-window objective; (threshold, max_nb_states, chunk) = the threshold-fusion objective of
+    extrack/tracking.py:427-743 and its gradient at the frozen plan of this evaluation (extrack_loglik_th_grad)."""
     from .tracking import _objective_model
     names = free_names(params) if names is None else list(names)
+    if ts.has_dt and threshold_fusion is not None:
+        raise NotImplementedError("the frozen-plan gradient does not serve per-track time steps: use gradient='fd'")
     model = _objective_model(params, ts, dt, cell_dims, None, nb_states, nb_substeps, frame_len, Matrix_type)
     if model is None:
         return np.inf, np.zeros(len(names))
+    if not names:  # nothing to differentiate: the plain objective
+        if threshold_fusion is not None:
+            ll = comm.allreduce_loglik_th(ts, model, *threshold_fusion) if comm is not None else ts.loglik_th(model, *threshold_fusion)
+        else:
+            ll = comm.allreduce_loglik(ts, model) if comm is not None else ts.loglik(model)
+        return -float(ll), np.zeros(0)
     tang = model_tangents(params, dt, nb_substeps, Matrix_type, cell_dims, names, has_sigma=ts.has_sigma)
 
-    if comm is not None:
+    if threshold_fusion is not None:
+        thr, mnb, chunk = threshold_fusion
+        if comm is not None:
+            v = comm.allreduce_loglik_th_grad(ts, model, tang, len(names), thr, mnb, chunk)
+        elif ts.n_tracks:
+            ll, g = ts.ctx.loglik_th_grad(model, tang, thr, mnb, chunk)
+            v = np.concatenate([[ll], g])
+        else:
+            v = np.zeros(1 + len(names))
+    elif comm is not None:
         v = comm.allreduce_loglik_grad(ts, model, tang, len(names))
     elif ts.n_tracks:
         ll, g = ts.ctx.loglik_grad(model, tang)

@@ -263,6 +263,18 @@ def _own_minimize(fcn, params, method="leastsq", args=None, kws=None, iter_cb=No
         return val, gi
 
     x0 = np.array([_to_internal(work[k]) for k in names], float)
+    if fcn_grad is not None and m in _GRADIENT_METHODS:
+        # A free parameter that starts exactly ON a bound (generate_params' default D0 = 0) sits where the derivative of the bounds transform
+        # is zero: its exact internal gradient vanishes and a gradient method would never move it - finite differences leave the bound only
+        # through their second-order term.  Start 1e-6 of the range (1e-6 for one-sided bounds) inside: d value / d internal = 1e-3 x range.
+        for i, k in enumerate(names):
+            pk = work[k]
+            lo_side = np.isfinite(pk.min) and pk._val <= pk.min
+            hi_side = np.isfinite(pk.max) and pk._val >= pk.max
+            if lo_side or hi_side:
+                rng_ = (pk.max - pk.min) if (np.isfinite(pk.min) and np.isfinite(pk.max)) else 1.0
+                pk._val = (pk.min + 1e-6 * rng_) if lo_side else (pk.max - 1e-6 * rng_)
+                x0[i] = _to_internal(pk)
     opts = dict(fit_kws.pop("options", {}))
     if max_nfev is not None:
         opts.setdefault("maxfev" if _SCALAR_METHODS[m] in ("Powell", "Nelder-Mead") else "maxiter", int(max_nfev))

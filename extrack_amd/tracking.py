@@ -28,7 +28,7 @@ import os
 import numpy as np
 from scipy import linalg
 
-from . import engine
+from . import _lib, engine
 from .engine import TrackSet
 from .lmfit_compat import Parameters, is_parameters, minimize
 
@@ -383,17 +383,20 @@ def cum_Proba_Cs(params, all_tracks, dt, cell_dims, input_LocErr, nb_states, nb_
 def cum_Proba_Cs_grad(params, names, all_tracks, dt, cell_dims, input_LocErr, nb_states, nb_substeps, frame_len, verbose=1, workers=1,
                       Matrix_type=1, threshold=0.2, max_nb_states=120, max_number_of_tracks_per_matrix=2000, comm=None, fusion=None,
                       device=None):
-    """(objective, gradient): ``cum_Proba_Cs`` (fixed-window kernel) and its exact derivative with respect to the VALUES of the free
-    parameters ``names``, from ONE pass of the gradient kernel (extrack_loglik_grad) instead of the nvar + 1 evaluations the
-    reference's optimiser spends on finite differences (extrack/tracking.py:1371).  Same argument list as ``cum_Proba_Cs`` after
-    ``names``; same prints; (+inf, zeros) for invalid parameters or NaN."""
+    """(objective, gradient): ``cum_Proba_Cs`` and its exact derivative with respect to the VALUES of the free parameters ``names``,
+    from ONE pass of the gradient kernels instead of the nvar + 1 evaluations the reference's optimiser spends on finite differences
+    (extrack/tracking.py:1371).  ``fusion="window"``: extrack_loglik_grad; ``fusion="threshold"`` (what extrack.tracking.param_fitting
+    minimises in v1.6.3): extrack_loglik_th_grad - the value is that of ``cum_Proba_Cs(..., fusion="threshold")`` and the gradient its
+    derivative with the merge groups of THIS evaluation held fixed (the plan is re-decided at every call, exactly as the objective does).
+    Same argument list as ``cum_Proba_Cs`` after ``names``; same prints; (+inf, zeros) for invalid parameters or NaN."""
     from . import gradient
-    if _check_fusion(fusion):
-        raise ValueError("the analytic gradient exists for the fixed-window kernel only (the threshold-fusion objective is only "
-                         "piecewise smooth in the parameters)")
+    th = _check_fusion(fusion)
+    if th and comm is not None and not isinstance(all_tracks, TrackSet):
+        raise ValueError("fusion='threshold' with comm needs chunk-aligned shards: pass the TrackSet of comm.shard_trackset(..., chunk=...)")
     ts, owned = _as_trackset(all_tracks, input_LocErr, device, comm)
     try:
-        out, g = gradient.objective_and_gradient(params, ts, dt, cell_dims, nb_states, nb_substeps, frame_len, Matrix_type, comm, names)
+        out, g = gradient.objective_and_gradient(params, ts, dt, cell_dims, nb_states, nb_substeps, frame_len, Matrix_type, comm, names,
+                                                 threshold_fusion=(threshold, max_nb_states, max_number_of_tracks_per_matrix) if th else None)
     finally:
         if owned:
             ts.close()
@@ -413,37 +416,57 @@ def cum_Proba_Cs_grad(params, names, all_tracks, dt, cell_dims, input_LocErr, nb
     return out, g
 
 
-def _pick_gradient(params, fargs, explicit, comm=None):
-    """Should ``param_fitting`` hand the optimiser the analytic gradient (one ``extrack_loglik_grad`` pass per iteration) rather than
-    let it difference the objective (nvar + 1 evaluations per iteration, what the reference does, extrack/tracking.py:1371)?
+def _pick_gradient(params, fargs, explicit, comm=None, info=None):
+    """Should ``param_fitting`` hand the optimiser the analytic gradient (one gradient-kernel pass per iteration) rather than let it
+    difference the objective (nvar + 1 evaluations per iteration, what the reference does, extrack/tracking.py:1371)?
     Yes when (a) every constraint expression is complex-differentiable and (b) - unless the caller asked for it explicitly - a timing
     probe on this dataset says a gradient call costs less than the nvar + 1 objective calls it replaces: on large datasets the gradient
-    kernels beat finite differences (two states: tangents in registers, xt_reg2.h; 3 / 4 states: reverse mode, xt_rev.h - about the cost
-    of four objective calls whatever nvar is), on datasets of a few thousand tracks the comparison is decided by host overheads, and models
-    only the LDS-resident forward-mode kernel serves (xt_grad.h) are slower than differences.  With ``comm`` the decision is taken on the slowest rank's timings."""
+    kernels beat finite differences (two states: tangents in registers, xt_reg2.h; 3 / 4 states: reverse mode, xt_rev.h; threshold
+    fusion: reverse mode at the frozen plan, xt_thgrad.h - a few objective calls' worth whatever nvar is), on datasets of a few thousand
+    tracks the comparison is decided by host overheads.  With ``comm`` the decision is taken on the slowest rank's timings.
+    ``info`` (dict) receives ``gradient_path`` ("analytic" | "fd") and ``gradient_why``: the decision is part of the fit's record.  Only a
+    model the gradient kernels do not serve (ExtrackError E_UNSUPPORTED / NotImplementedError) falls back silently; any other failure of
+    the probe is an error of the gradient path and is raised."""
     import time
     from . import gradient
+    info = {} if info is None else info
+
+    def decide(use, why):
+        info["gradient_path"], info["gradient_why"] = ("analytic" if use else "fd"), why
+        return use
     names = gradient.free_names(params)
     why = gradient.analytic_support(params, names)
     if why is not None:
         if explicit:
             raise ValueError("gradient='analytic': a parameter expression is not differentiable (%s)" % why)
-        return False
+        return decide(False, "a parameter expression is not complex-differentiable (%s)" % why)
     if explicit:
-        return True
+        return decide(True, "requested (gradient='analytic')")
     import contextlib, io
     a = list(fargs)
     a[7] = 0  # verbose
     sink = io.StringIO()
+    unsupported = None
+    t_ll = t_g = 0.0
     with contextlib.redirect_stdout(sink):
+        cum_Proba_Cs(params, *a)  # warm-up: tables, workspaces, clocks
+        t0 = time.perf_counter()
+        cum_Proba_Cs(params, *a)
+        t_ll = time.perf_counter() - t0
         try:
-            cum_Proba_Cs(params, *a)  # warm-up: tables, workspaces, clocks
-            t0 = time.perf_counter()
-            cum_Proba_Cs(params, *a)
-            t_ll = time.perf_counter() - t0
             t0 = time.perf_counter()
             cum_Proba_Cs_grad(params, names, *a)  # first call: includes one-time allocations
             t_g = time.perf_counter() - t0
+        except NotImplementedError as e:
+            unsupported = str(e)
+        except _lib.ExtrackError as e:
+            if e.code != _lib.E_UNSUPPORTED:
+                raise
+            unsupported = str(e)
+        if comm is not None:  # every rank must take the same branch below
+            if comm.allreduce_scalar(1.0 if unsupported else 0.0, "max") > 0.5:
+                unsupported = unsupported or "not served on another rank"
+        if unsupported is None:
             clear = t_g > 1.5 * (len(names) + 1) * t_ll  # already far on the wrong side: spare the second (warm) gradient call
             if comm is not None:
                 clear = comm.allreduce_scalar(1.0 if clear else 0.0, "min") > 0.5
@@ -451,12 +474,13 @@ def _pick_gradient(params, fargs, explicit, comm=None):
                 t0 = time.perf_counter()
                 cum_Proba_Cs_grad(params, names, *a)
                 t_g = time.perf_counter() - t0
-        except Exception:  # e.g. a model the gradient kernels do not serve: the objective itself decides later
-            return False
+    if unsupported is not None:
+        return decide(False, "the gradient kernels do not serve this model (%s)" % unsupported)
     if comm is not None:
         v = comm.allreduce_vector(np.array([t_ll, t_g]), op="max")
         t_ll, t_g = float(v[0]), float(v[1])
-    return t_g < (len(names) + 1) * t_ll
+    use = t_g < (len(names) + 1) * t_ll
+    return decide(use, "timing probe: one gradient call %.3g ms vs %d objective calls of %.3g ms" % (t_g * 1e3, len(names) + 1, t_ll * 1e3))
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -496,17 +520,18 @@ def param_fitting(all_tracks, dt, params=None, nb_states=2, nb_substeps=1, frame
     else:
         ts = TrackSet(tracks, sigmas, device=device, dts=dts)
     from . import lmfit_compat
-    can_grad = fusion == "window" and str(method).lower() in lmfit_compat._GRADIENT_METHODS
+    can_grad = str(method).lower() in lmfit_compat._GRADIENT_METHODS and not (fusion == "threshold" and dts is not None)
     if gradient not in (None, "analytic", "fd"):
         raise ValueError("gradient must be None, 'analytic' or 'fd'")
     if gradient == "analytic" and not can_grad:
-        raise ValueError("gradient='analytic' needs fusion='window' and a gradient-based method")
+        raise ValueError("gradient='analytic' needs a gradient-based method (and, with fusion='threshold', a scalar dt)")
     fargs = (ts, dt, cell_dims, sigmas, nb_states, nb_substeps, frame_len, verbose, workers, Matrix_type, threshold, max_nb_states, 2000,
              comm, fusion)
+    ginfo = {"gradient_path": "fd", "gradient_why": "requested (gradient='fd')" if gradient == "fd" else "method %r takes no gradient" % method}
     try:
         use_grad = can_grad and gradient != "fd"
         if use_grad:
-            use_grad = _pick_gradient(params, fargs, explicit=(gradient == "analytic"), comm=comm)
+            use_grad = _pick_gradient(params, fargs, explicit=(gradient == "analytic"), comm=comm, info=ginfo)
         if use_grad:
             # the built-in BFGS driver takes the analytic gradient (chain rule through the bounds transform applied there); with real
             # lmfit installed its Parameters are converted for the fit and the fitted values written back into a copy of them
@@ -516,6 +541,8 @@ def param_fitting(all_tracks, dt, params=None, nb_states=2, nb_substeps=1, frame
             fit = minimize(cum_Proba_Cs, params, args=fargs, method=method, nan_policy="propagate")
     finally:
         ts.close()
+    # which way the optimiser got its gradient, and why (the fit's record; `ngev` > 0 says the same for the built-in driver)
+    fit.gradient_path, fit.gradient_why = ginfo["gradient_path"], ginfo["gradient_why"]
     if verbose == 0:
         print("")
     return fit

@@ -35,6 +35,11 @@
  *       extrack_loglik AND its exact gradient in one pass.  It replaces the finite-difference loop that the reference's
  *       optimiser runs around cum_Proba_Cs (lmfit.minimize at extrack/tracking.py:1371: BFGS evaluates the objective
  *       nvar + 1 times per iteration to difference it numerically).
+ *   extrack_loglik_th_grad
+ *       extrack_loglik_th AND the exact gradient of that value at the evaluation's own merge plan - the objective v1.6.3's
+ *       param_fitting hands to lmfit.minimize (extrack/tracking.py:1371 -> cum_Proba_Cs :991 -> P_Cs_inter_bound_stats_th :427-650);
+ *       the reference differences it numerically although the grouping decisions of fuse_tracks_th (:676-701) make it only
+ *       piecewise smooth.
  *
  * Conventions: plain C, no exceptions cross the boundary.  Every function returns 0 on success or a
  * negative EXTRACK_E_* code; extrack_last_error() gives the message.  The caller owns every host
@@ -50,7 +55,7 @@
 extern "C" {
 #endif
 
-#define EXTRACK_ABI_VERSION 5
+#define EXTRACK_ABI_VERSION 6
 
 #define EXTRACK_OK 0
 #define EXTRACK_E_INVALID (-1)     /* bad argument / unsupported configuration */
@@ -160,7 +165,21 @@ int extrack_loglik_grad(extrack_ctx* ctx, const extrack_model* model, int32_t n_
  * stream (RCCL), like extrack_loglik_async does for the scalar.  The tangent arrays are consumed before the call returns. */
 int extrack_loglik_grad_async(extrack_ctx* ctx, const extrack_model* model, int32_t n_dir, const extrack_model_tangent* tangents,
                               double* d_out);
-/* Device time (ms) of the gradient kernels of the last extrack_loglik_grad / extrack_loglik_grad_async call (waits for them). */
+/* Threshold-fusion log-likelihood (as extrack_loglik_th: same threshold / max_nb_states / chunk semantics, same value up to rounding)
+ * together with its derivative along n_dir model directions AT THE FROZEN PLAN of this evaluation: the plan kernel decides the merge
+ * groups of every chunk from its pilot tracks at `model`, then one forward and one backward sweep over every track (reverse mode, csrc/
+ * xt_thgrad.h) return sum LL and the adjoint of every model table, contracted with the directions' tangents - the cost does not
+ * depend on n_dir.  With the groups held fixed the value is a smooth function of the model and grad is its exact derivative; where a
+ * parameter change flips a grouping decision the objective itself jumps (by ~1e-9 relative) and no derivative exists - finite
+ * differences of the reference's optimiser sample those jumps, this gradient does not.  n_dir may be 0.  Not built: per-track time
+ * steps (extrack_set_bucket_dt) and models whose n_states^(nb_substeps + 1) table adjoints exceed the LDS (EXTRACK_E_UNSUPPORTED). */
+int extrack_loglik_th_grad(extrack_ctx* ctx, const extrack_model* model, double threshold, int32_t max_nb_states, int32_t chunk,
+                           int32_t n_dir, const extrack_model_tangent* tangents, double* total_ll, double* grad);
+/* The same, enqueued on the context's stream: d_out (DEVICE, 1 + n_dir doubles) receives {sum LL, gradient} in stream order (the plan
+ * kernel's sequence counts are still read back once inside the call, as in extrack_loglik_th_async). */
+int extrack_loglik_th_grad_async(extrack_ctx* ctx, const extrack_model* model, double threshold, int32_t max_nb_states, int32_t chunk,
+                                 int32_t n_dir, const extrack_model_tangent* tangents, double* d_out);
+/* Device time (ms) of the gradient kernels of the last extrack_loglik_grad / extrack_loglik_th_grad (or _async) call (waits for them). */
 int extrack_last_grad_ms(extrack_ctx* ctx, float* ms);
 
 /* State-duration histogram of one bucket (extrack/histograms.py:26-286 P_segment_len, third return value, summed over the bucket's

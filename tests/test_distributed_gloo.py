@@ -94,6 +94,34 @@ class OracleContext:
             g.append((at(+1) - at(-1)) / (2 * h))
         return total(ds, Fs, T, pBL, le), np.array(g)
 
+    def loglik_th_grad(self, model, tangents, threshold=0.2, max_nb_states=120, chunk=2000):
+        """Threshold-fusion sum LL and its derivative AT THE FROZEN PLAN of the evaluation along every model tangent: central differences of
+        the oracle with every chunk's grouping held fixed (test stand-in for extrack_loglik_th_grad; the kernel's own derivative is checked
+        in tests/test_emul_thgrad.py and on the GPU)."""
+        from oracle import oracle_th as OT
+        le, ds, Fs, T, pBL, ns, F, lo, hi = self._model(model)
+        chunks = [(b[a0:a0 + chunk], 0 if b.shape[1] == hi else 1) for b in self.data for a0 in range(0, len(b), chunk)]
+        plans, base = [], 0.0
+        for Cc, isBL in chunks:
+            tr = []
+            base += OT.proba_cs_th(Cc, le, ds, Fs, T, pBL, isBL, CELL, ns, F, lo, threshold, max_nb_states, trace=tr).sum()
+            plans.append(tr)
+
+        def total(ds_, Fs_, T_, pBL_, le_):
+            return sum(OT.proba_cs_th(Cc, le_, ds_, Fs_, T_, pBL_, isBL, CELL, ns, F, lo, threshold, max_nb_states, plan=pl).sum()
+                       for (Cc, isBL), pl in zip(chunks, plans))
+        h = 1e-6
+        if isinstance(tangents, dict):
+            from extrack_amd import gradient
+            tangents = gradient.tangent_rows(tangents)
+        g = []
+        for t in tangents:
+            def at(sg):
+                return total(np.sqrt(ds ** 2 + sg * h * np.asarray(t["ds2"])), Fs + sg * h * np.asarray(t["Fs"]), T + sg * h * np.asarray(t["TrMat"]),
+                             pBL + sg * h * t["pBL"], le + sg * h * np.asarray(t.get("locerr", 0.0)))
+            g.append((at(+1) - at(-1)) / (2 * h))
+        return base, np.array(g)
+
     def segment_len_hist(self, model, bucket_id, max_nb_states=500):
         from oracle import oracle_hist as OH
         le, ds, Fs, T, pBL, ns, F, lo, hi = self._model(model)
@@ -191,6 +219,18 @@ def _worker(rank, world, port, q, scenario):
             gv1, gg1 = gradient.objective_and_gradient(pg, full, 0.02, CELL, 2, 1, 4)
             full.close()
             out.update(gv=gv, gg=gg.tolist(), gv1=gv1, gg1=gg1.tolist())
+            # the same for the threshold-fusion objective (gradient at the frozen plan): chunk-aligned shards, one all-reduce of 1 + nvar doubles
+            ts = comm.shard_trackset(lst, chunk=16)
+            with contextlib.redirect_stdout(io.StringIO()):
+                tv, tg = T.cum_Proba_Cs_grad(pg, gradient.free_names(pg), ts, 0.02, CELL, None, 2, 1, 4, verbose=0, threshold=0.2, max_nb_states=120,
+                                             max_number_of_tracks_per_matrix=16, comm=comm, fusion="threshold")
+                tv0 = T.cum_Proba_Cs(pg, ts, 0.02, CELL, None, 2, 1, 4, verbose=0, threshold=0.2, max_nb_states=120,
+                                     max_number_of_tracks_per_matrix=16, comm=comm, fusion="threshold")
+            ts.close()
+            full = T.TrackSet(lst, device=0)
+            tv1, tg1 = gradient.objective_and_gradient(pg, full, 0.02, CELL, 2, 1, 4, threshold_fusion=(0.2, 120, 16))
+            full.close()
+            out.update(tv=tv, tv0=tv0, tg=tg.tolist(), tv1=tv1, tg1=tg1.tolist())
             with contextlib.redirect_stdout(io.StringIO()):
                 hh = len_hist(tracks, p, 0.02, cell_dims=CELL, nb_states=2, max_nb_states=30, comm=comm)
             out.update(hist_err=float(np.abs(hh - OH.len_hist(vals, tracks, 0.02, CELL, 30)).max()), hist_sum=float(hh.sum()))
@@ -296,6 +336,8 @@ def test_two_rank_product_path_matches_unsharded():
         assert abs(r["th"] - r["th_ref"]) < 1e-12 * abs(r["th_ref"]), r
         assert abs(r["th_dt"] - r["th_dt_ref"]) < 1e-12 * abs(r["th_dt_ref"]), r
         assert abs(r["gv"] - r["gv1"]) < 1e-10 * abs(r["gv1"]) and np.allclose(r["gg"], r["gg1"], rtol=1e-6, atol=1e-4), (r["gg"], r["gg1"])
+        assert abs(r["tv"] - r["tv1"]) < 1e-10 * abs(r["tv1"]) and abs(r["tv"] - r["tv0"]) < 1e-12 * abs(r["tv0"]), r
+        assert np.allclose(r["tg"], r["tg1"], rtol=1e-6, atol=1e-4) and np.abs(r["tg"]).max() > 1.0, (r["tg"], r["tg1"])
         assert r["hist_err"] < 1e-10 and r["hist_sum"] > 1.0, r
         assert r["ranges"] == [(0, 21), (21, 41)] and r["ranges_chunk"] == [(0, 32), (32, 41)]
     assert res[0]["got"] == res[1]["got"] and res[0]["th"] == res[1]["th"]  # every rank sees the same reduced scalar
