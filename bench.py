@@ -221,6 +221,14 @@ def other_configs(device, no_cpu_baseline=False):
     wall, kms, v = timed(lambda: ts.loglik_th(model, 0.2, 120, 2000), 5, warm=2)
     out["c3_loglik_threshold"] = {"what": "configs[2] through the threshold-fusion kernels (v1.6.3 defaults, frame_len 6)", "ms_per_eval": wall * 1e3,
                                   "kernel_ms": kms, "algorithmic_bytes": nbytes, "hbm_gbs": nbytes / (kms * 1e-3) / 1e9, "neg_loglik": -v}
+    # ... and its exact gradient at the frozen plan (extrack_loglik_th_grad, round 4): what an optimiser iteration of the v1.6.3 objective costs
+    for _ in range(2):
+        gv, gg = gradient.objective_and_gradient(pg, ts, DT, CELL, 3, 1, 6, names=names, threshold_fusion=(0.2, 120, 2000))
+    out["c3_loglik_th_grad"] = {"what": "configs[2] through the threshold-fusion kernels: -sum(LL) AND its exact gradient (13 free parameters) at the frozen plan of the "
+                                        "evaluation (plan kernel + xt_thg_kernel: one forward + one backward sweep, one lane per track)",
+                                "kernel_ms": ts.ctx.last_grad_ms(), "n_directions": len(names),
+                                "fd_equivalent_ms": (len(names) + 1) * out["c3_loglik_threshold"]["kernel_ms"], "grad_inf_norm": float(np.abs(gg).max()),
+                                "launch": ts.ctx.last_launch_info()}
     ts.close()
     # configs[2] as BASELINE states it: the FULL fit of the 1e6-track dataset (3 states, 13 free parameters, frame_len 6), default settings -
     # param_fitting decides by a timing probe whether the optimiser gets the one-pass gradient (ngev > 0) or differences the objective
@@ -243,6 +251,23 @@ def other_configs(device, no_cpu_baseline=False):
                              "seconds": fits3["default"]["seconds"], "objective_calls": fits3["default"]["objective_calls"],
                              "gradient_calls": fits3["default"]["gradient_calls"], "neg_loglik": fits3["default"]["neg_loglik"], "fit": fits3,
                              "simulated": {"D1": 0.04, "D2": 0.25, "LocErr": LOCERR, "F0": 0.3, "F1": 0.3}}
+    # the same fit of the objective extrack.tracking.param_fitting minimises in v1.6.3 (threshold fusion): default = the frozen-plan driver
+    # (plan, minimise at that plan with the exact gradient, re-plan), fd = the reference's finite-difference BFGS
+    fits3t = {}
+    for grad in (None, "fd"):
+        with contextlib.redirect_stdout(io.StringIO()):
+            t0 = time.perf_counter()
+            r = tracking.param_fitting(tracks, DT, params=p0, nb_states=3, frame_len=6, cell_dims=CELL, verbose=0, device=device, gradient=grad, fusion="threshold")
+            t_fit = time.perf_counter() - t0
+        fits3t["default" if grad is None else grad] = {"seconds": t_fit, "objective_calls": int(r.nfev), "gradient_calls": int(getattr(r, "ngev", 0)),
+                                                        "neg_loglik": float(r.residual[0]), "gradient_path": getattr(r, "gradient_path", None),
+                                                        "gradient_why": getattr(r, "gradient_why", None), "plan_rounds": int(getattr(r, "plan_rounds", 0)),
+                                                        "fitted": {k: float(r.params[k].value) for k in ("D1", "D2", "LocErr", "F0", "F1")}}
+    out["c3_full_fit_threshold"] = {"what": "configs[2] with fusion='threshold' (v1.6.3's objective): param_fitting on 1e6 tracks, 3 states, 46 buckets, frame_len 6 from the "
+                                            "same generic start; 'default' = gradient=None (probe -> frozen-plan gradient, plan / minimise / re-plan rounds), 'fd' = finite "
+                                            "differences of the re-planning objective like the reference",
+                                    "seconds": fits3t["default"]["seconds"], "objective_calls": fits3t["default"]["objective_calls"],
+                                    "gradient_calls": fits3t["default"]["gradient_calls"], "neg_loglik": fits3t["default"]["neg_loglik"], "fit": fits3t}
     del tracks
     # the same for the headline dataset (configs[1]: 1e6 x 30, 2 states, 7 free parameters): analytic gradient vs finite differences
     c2 = {str(LEN): synth.brownian_tracks(N_TRACKS, LEN, DS_COEF, TRMAT, FS, LOCERR, DT, DIMS, seed=0)}
@@ -322,10 +347,17 @@ def other_configs(device, no_cpu_baseline=False):
             r = tracking.param_fitting(small, DT, nb_states=2, frame_len=6, cell_dims=CELL, verbose=0, gradient=grad, device=device)
             fits["default" if grad is None else grad] = {"seconds": time.perf_counter() - t0, "objective_calls": int(r.nfev),
                                                           "gradient_calls": int(getattr(r, "ngev", 0)), "neg_loglik": float(r.residual[0])}
+    fits_th = {}
+    for grad in ("analytic", "fd"):
+        with contextlib.redirect_stdout(io.StringIO()):
+            t0 = time.perf_counter()
+            r = tracking.param_fitting(small, DT, nb_states=2, frame_len=6, cell_dims=CELL, verbose=0, gradient=grad, device=device, fusion="threshold")
+            fits_th[grad] = {"seconds": time.perf_counter() - t0, "objective_calls": int(r.nfev), "gradient_calls": int(getattr(r, "ngev", 0)),
+                             "neg_loglik": float(r.residual[0])}
     out["c1_like_small_dataset"] = {"what": "6 730 tracks in 16 length buckets (5-20 positions), 2 states, frame_len 6: one evaluation, and param_fitting from the "
                                             "default start with the exact gradient / with finite differences",
                                     "window_ms_per_eval": w_win * 1e3, "window_kernel_ms": k_win, "threshold_ms_per_eval": w_th * 1e3,
-                                    "threshold_kernels_ms": k_th, "fit": fits}
+                                    "threshold_kernels_ms": k_th, "fit": fits, "fit_threshold_fusion": fits_th}
     # ---- state-duration histograms and position refinement on 1e5 tracks x 30
     from extrack_amd.histograms import len_hist
     from extrack_amd.refined_localization import position_refinement

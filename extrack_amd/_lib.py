@@ -17,7 +17,7 @@ EXPORTS = [
     "extrack_loglik", "extrack_loglik_async", "extrack_predict", "extrack_last_kernel_ms",
     "extrack_last_launch_info", "extrack_p_stay_table", "extrack_loglik_th", "extrack_loglik_th_async", "extrack_th_plan_step",
     "extrack_predict_th", "extrack_loglik_grad", "extrack_loglik_grad_async", "extrack_last_grad_ms", "extrack_segment_len_hist", "extrack_refine_positions",
-    "extrack_sequence_columns", "extrack_sequence_matrix", "extrack_loglik_th_grad", "extrack_loglik_th_grad_async",
+    "extrack_sequence_columns", "extrack_sequence_matrix", "extrack_loglik_th_grad", "extrack_loglik_th_grad_async", "extrack_th_freeze_plan",
 ]
 
 _dp = C.POINTER(C.c_double)
@@ -116,6 +116,7 @@ def load():
     lib.extrack_sequence_matrix.argtypes = [vp, C.POINTER(ExtrackModel), i32, vp, i64]
     lib.extrack_loglik_th_grad.argtypes = [vp, C.POINTER(ExtrackModel), C.c_double, i32, i32, i32, C.POINTER(ExtrackModelTangent), _dp, vp]
     lib.extrack_loglik_th_grad_async.argtypes = [vp, C.POINTER(ExtrackModel), C.c_double, i32, i32, i32, C.POINTER(ExtrackModelTangent), vp]
+    lib.extrack_th_freeze_plan.argtypes = [vp, i32]
     if lib.extrack_abi_version() != 6:
         raise ImportError("libextrack_hip.so ABI version mismatch")
     _lib = lib
@@ -292,6 +293,10 @@ class Context:
         n, arr, keep = self._pack_tangents(model, tangents)
         self._check(self._lib.extrack_loglik_grad_async(self._h, C.byref(model.c), n, arr, C.c_void_p(d_out_ptr)))
         return n
+
+    def th_freeze_plan(self, on):
+        """Threshold-fusion evaluations follow the plan of the last planning evaluation (on) / decide their own again (off)."""
+        self._check(self._lib.extrack_th_freeze_plan(self._h, 1 if on else 0))
 
     def loglik_th_grad(self, model, tangents, threshold=0.2, max_nb_states=120, chunk=2000):
         """(sum LL, d sum LL / d theta_i) of the threshold-fusion objective at the frozen plan of this evaluation (extrack_loglik_th_grad)."""

@@ -402,7 +402,8 @@ static int xt_grad_enqueue(extrack_ctx* ctx, const extrack_model* m, int32_t n_d
         }
         // ---- 2 - 4 members per group, <= 256 groups per track: state and tangents in registers, LDS as the exchange medium (xt_gradr.h)
         // Measured against the LDS-resident kernel below (r03): C3 (3 states, 13 directions) frame_len 6 601 ms vs 1 960 ms, frame_len 4 63 vs 79 ms;
-        // C2-type data through the general kernels (2 states, per-peak errors take this path) frame_len 6 43.8 vs 52.9 ms, frame_len 4 16.1 vs 16.4 ms.
+        // C2-type data through the general kernels (2 states with per-peak errors; in the launcher's order reg2 -> rev -> gradr -> lds the reverse-mode
+        // kernels above now take those models first) frame_len 6 43.8 vs 52.9 ms, frame_len 4 16.1 vs 16.4 ms.
         if (ctx->grad_reg2 && n_dir > 0 && c.G >= 2 && c.G <= 4 && c.NG <= 256 && xt_gradr_kernel_ptr(c.G, D, K, 4) != nullptr) {
             const int tpb = std::max(1, 256 / c.NG), threads = (tpb * c.NG + 63) / 64 * 64;
             // 4 directions per pass: with 6 the register allocator spills inside the step loop (3 states: 917 GB of scratch traffic per C3

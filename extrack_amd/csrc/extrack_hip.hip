@@ -954,6 +954,7 @@ static int xt_th_reserve_plan(extrack_ctx* ctx, XtBucket& b, int chunk, int capE
     b.th_capE = capE;
     b.th_chunk = chunk;
     b.th_nchunks = nchunks;
+    b.th_maxG = -1;
     return EXTRACK_OK;
 }
 
@@ -1126,7 +1127,47 @@ static int xt_th_run_group(extrack_ctx* ctx, const extrack_model* m, const std::
     hipError_t e = hipSuccess;
     int rc, maxG = 0, sumE = 0;
     bool force_global = false;
-    for (;;) {  // plan, growing the capacity on overflow
+    if (ctx->th_frozen) {
+        // frozen plan: no plan kernel, no read-back - the buckets still hold the plan of the last planning evaluation
+        bool ok = !chunk_base;
+        for (int i = 0; ok && i < nbk; ++i)
+            ok = bks[i]->th_members && bks[i]->th_maxG >= 0 && bks[i]->th_capE == bks[0]->th_capE && bks[i]->th_chunk == chunk;
+        if (!ok) return xt_fail(ctx, EXTRACK_E_INVALID, "frozen plan: no plan of a previous evaluation with this chunk size for these buckets (evaluate once unfrozen first; per-track time steps are not served)");
+        a.capE = bks[0]->th_capE;
+        for (int i = 0; i < nbk; ++i) {
+            maxG = std::max(maxG, bks[i]->th_maxG);
+            sumE = std::max(sumE, bks[i]->th_sumE);
+        }
+        for (int i = 0; i < nbk; ++i) {
+            XtBucket& b = *bks[i];
+            XtThBucket& k = desc[i];
+            k.tracks = b.d_tracks;
+            k.sigma = m->locerr_mode ? b.d_sigma : nullptr;
+            k.dt = nullptr;
+            k.ll_out = per_track ? b.d_ll : nullptr;
+            k.preds_out = nullptr;
+            k.N = b.N;
+            k.L = b.L;
+            k.isBL = (b.L != m->max_len) ? 1 : 0;
+            k.ll_const = -(double)(b.L - 1) * D * 0.5 * XT_LOG2PI;
+            k.members = b.th_members;
+            k.mpack = b.th_mpack;
+            k.gstart = b.th_gstart;
+            k.gnew = b.th_gnew;
+            k.hdr = b.th_hdr;
+            k.status = ctx->d_th_status + (size_t)(i ? chunk_end[i - 1] : 0) * 4;
+        }
+        if ((rc = xt_th_upload_small(ctx, (void**)&ctx->d_th_desc, &ctx->th_desc_cap, desc.data(), desc.size() * sizeof(XtThBucket)))) return rc;
+        if ((rc = xt_th_upload_small(ctx, (void**)&ctx->d_th_cend, &ctx->th_cend_cap, chunk_end.data(), chunk_end.size() * sizeof(int32_t)))) return rc;
+        a.buckets = ctx->d_th_desc;
+        a.chunk_end = ctx->d_th_cend;
+        if (between) {
+            const std::function<int()>* f = between;
+            between = nullptr;
+            if ((rc = (*f)())) return rc;
+        }
+    }
+    for (; !ctx->th_frozen;) {  // plan, growing the capacity on overflow
         int capE = ctx->th_capE;
         while (capE < S * G) capE *= 2;
         ctx->th_capE = capE;
@@ -1232,6 +1273,15 @@ static int xt_th_run_group(extrack_ctx* ctx, const extrack_model* m, const std::
             maxE = std::max(maxE, ctx->h_th_status[(size_t)c * 4 + 1]);
             maxG = std::max(maxG, ctx->h_th_status[(size_t)c * 4 + 2]);
             sumE = std::max(sumE, ctx->h_th_status[(size_t)c * 4 + 3]);
+        }
+        for (int i = 0; i < nbk; ++i) {  // per bucket: what a later evaluation with this plan frozen needs to size its launches
+            XtBucket& b = *bks[i];
+            b.th_maxG = over ? -1 : 0;
+            b.th_sumE = 0;
+            for (int c = (i ? chunk_end[i - 1] : 0); !over && c < chunk_end[i]; ++c) {
+                b.th_maxG = std::max(b.th_maxG, ctx->h_th_status[(size_t)c * 4 + 2]);
+                b.th_sumE = std::max(b.th_sumE, ctx->h_th_status[(size_t)c * 4 + 3]);
+            }
         }
         if (!over) {
             const int lp = maxG + maxG / 4 + 2, le = maxE + maxE / 4 + 2;
@@ -1409,7 +1459,7 @@ static int xt_loglik_th_enqueue(extrack_ctx* ctx, const extrack_model* m, double
             }
             if (k0 < grp.size()) seg.emplace_back(grp.begin() + k0, grp.end());
         }
-        const bool split = !ctx->th_no_split && !dt_mode && grp.size() >= 4 && seg.size() >= 2 && gchunks >= ctx->n_cu && ctx->th_learnE > 0;
+        const bool split = !ctx->th_frozen && !ctx->th_no_split && !dt_mode && grp.size() >= 4 && seg.size() >= 2 && gchunks >= ctx->n_cu && ctx->th_learnE > 0;
         if (!split) {
             if ((rc = xt_th_run_group(ctx, m, grp, threshold, max_nb_states, chunk, G, per_track, poff, dt_mode ? &chunk_base : nullptr))) return rc;
         } else {
@@ -1493,6 +1543,13 @@ int xt_th_plan_groups(extrack_ctx* ctx, const extrack_model* m, double threshold
         if ((rc = xt_th_run_group(ctx, m, grp, threshold, max_nb_states, chunk, G, false, poff, nullptr, nullptr, &cb))) return rc;
         i = jn;
     }
+    return EXTRACK_OK;
+}
+
+extern "C" int extrack_th_freeze_plan(extrack_ctx* ctx, int32_t on)
+{
+    if (!ctx) return EXTRACK_E_INVALID;
+    ctx->th_frozen = on != 0;
     return EXTRACK_OK;
 }
 

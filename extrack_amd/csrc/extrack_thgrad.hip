@@ -6,14 +6,19 @@
 #include "xt_grad_host.h"
 #include "xt_thgrad.h"
 
-// one lane per track; state in a per-wavefront region of global memory, table adjoints in LDS rows: the kernel is bound by memory
-// latency, not registers - let the allocator use what it wants, occupancy is set by the LDS rows
-template <int D, int K>
-__global__ void __launch_bounds__(256) xt_thg_kernel(XtThArgs a, XtThGradArgs ga)
+// one lane per track; state in a per-wavefront region of global memory (coalesced rows, served by L2 / Infinity Cache): the kernel is bound
+// by memory latency - what counts is the number of wavefronts a CU holds (registers: XT_THG_WAVES per SIMD; LDS: the accumulator rows)
+#ifndef XT_THG_WAVES
+#define XT_THG_WAVES 3
+#endif
+template <int D, int K, bool RG>
+__global__ void __launch_bounds__(256, RG ? XT_THG_WAVES : 1) xt_thg_kernel(XtThArgs a, XtThGradArgs ga)  // LDS rows: the LDS bounds the wavefronts, the allocator is left alone (2 states: 23.9 ms unbounded, 27.9 ms at 3 waves)
 {
     DevCtx cx;
-    xt_thg_body<D, K>(a, ga, cx);
+    xt_thg_body<D, K, RG>(a, ga, cx);
 }
+template <int D, int K>
+static const void* xt_thg_kernel_ptr(bool rg) { return rg ? (const void*)xt_thg_kernel<D, K, true> : (const void*)xt_thg_kernel<D, K, false>; }
 
 static int xt_thg_reserve(extrack_ctx* ctx, double** buf, size_t* cap, size_t n)
 {
@@ -42,7 +47,7 @@ static int xt_th_grad_enqueue(extrack_ctx* ctx, const extrack_model* m, double t
     for (int i = 0; i < NS; ++i) G *= S;
     const int TB = xt_grad_tb_doubles(S, G);
     // one wavefront's accumulator rows must leave room for at least two workgroups per CU
-    if ((size_t)xt_thg_lds_doubles(S, G, 1) * sizeof(double) > 80 * 1024)
+    if ((size_t)xt_thg_lds_doubles(S, G, 1, XT_TH_MAXCAP) * sizeof(double) > 96 * 1024)
         return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "frozen-plan gradient: n_states^(nb_substeps+1) table adjoints do not fit the LDS (use finite differences)");
     XT_HIP(ctx, hipSetDevice(ctx->device));
     // tangent blocks of the directions (threshold-fusion table layout) -> device
@@ -78,11 +83,17 @@ static int xt_th_grad_enqueue(extrack_ctx* ctx, const extrack_model* m, double t
         memset(&ga, 0, sizeof(ga));
         ga.TB = TB;
         ga.capP = std::max(maxG, S);
-        ga.ws_stride = xt_thg_ws_doubles(ga.capP, Lmax, D, K);
         // wavefronts per workgroup: the accumulator rows of a wavefront decide how many wavefronts a CU holds
         const size_t row_bytes = (size_t)xt_thg_rows(S, G) * 64 * sizeof(double);
-        const int NW = row_bytes <= 8 * 1024 ? 4 : (row_bytes <= 16 * 1024 ? 2 : 1);
-        const size_t lds = (size_t)xt_thg_lds_doubles(S, G, NW) * sizeof(double);
+        int rows_global = row_bytes > 16 * 1024 ? 1 : 0;
+        if (const char* ev = getenv("EXTRACK_THG_ROWS_GLOBAL")) rows_global = atoi(ev) != 0;
+        ga.rows_global = rows_global;
+        ga.ws_stride = xt_thg_ws_doubles(ga.capP, Lmax, D, K, rows_global ? xt_thg_rows(S, G) : 0);
+        // measured (MI355X, r04): rows in scratch for 3 states 56 -> 48 ms per 1e6 mixed-length tracks (5 -> 12 wavefronts per CU); for 2 states the
+        // LDS rows (14 KB per wavefront, 10 wavefronts per CU) are faster (23.9 vs 29 ms per 1e6 x 30)
+        int NW = rows_global ? 2 : (row_bytes <= 8 * 1024 ? 4 : (row_bytes <= 16 * 1024 ? 2 : 1));
+        if (const char* ev = getenv("EXTRACK_THG_NW")) NW = std::max(1, std::min(4, atoi(ev)));
+        const size_t lds = (size_t)xt_thg_lds_doubles(S, G, NW, a.capE, rows_global != 0) * sizeof(double);
         const int threads = 64 * NW;
         int blocks_per_cu = (int)std::min<size_t>(16, (160 * 1024) / lds);
         blocks_per_cu = std::max(1, std::min(blocks_per_cu, 32 / NW));  // at most 8 wavefronts per SIMD
@@ -117,11 +128,11 @@ static int xt_th_grad_enqueue(extrack_ctx* ctx, const extrack_model* m, double t
         ga.ws = ctx->d_revlog;
         ga.gpartials = ctx->d_gpartials + rows * (size_t)(1 + TB);
         const void* kp = nullptr;
-        if (D == 1 && K == 1) kp = (const void*)xt_thg_kernel<1, 1>;
-        else if (D == 2 && K == 1) kp = (const void*)xt_thg_kernel<2, 1>;
-        else if (D == 2 && K == 2) kp = (const void*)xt_thg_kernel<2, 2>;
-        else if (D == 3 && K == 1) kp = (const void*)xt_thg_kernel<3, 1>;
-        else if (D == 3 && K == 3) kp = (const void*)xt_thg_kernel<3, 3>;
+        if (D == 1 && K == 1) kp = xt_thg_kernel_ptr<1, 1>(rows_global != 0);
+        else if (D == 2 && K == 1) kp = xt_thg_kernel_ptr<2, 1>(rows_global != 0);
+        else if (D == 2 && K == 2) kp = xt_thg_kernel_ptr<2, 2>(rows_global != 0);
+        else if (D == 3 && K == 1) kp = xt_thg_kernel_ptr<3, 1>(rows_global != 0);
+        else if (D == 3 && K == 3) kp = xt_thg_kernel_ptr<3, 3>(rows_global != 0);
         else return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "frozen-plan gradient: track / error dimensionality not built");
         if (lds > 64 * 1024) XT_HIP(ctx, hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         void* kargs[2] = {(void*)&a, (void*)&ga};

@@ -233,6 +233,7 @@ struct XtBucket {
     int32_t* th_status = nullptr;
     int th_capE = 0, th_chunk = 0;
     int64_t th_nchunks = 0;
+    int th_maxG = -1, th_sumE = 0;  // of that plan: largest group count of a step / largest sum of expanded sequences over the steps, over the bucket's chunks (-1: no valid plan)
 };
 
 struct extrack_ctx {
@@ -344,6 +345,9 @@ struct extrack_ctx {
     int th_stage_in_lds_mode = 0;  // EXTRACK_TH_STAGE_LDS: LDS-typed copy of the pilot means/stds also when the state is in LDS (measured: no gain)
     int th_no_gen_single = 0;  // EXTRACK_TH_NO_GEN_SINGLE: never use the one-buffer general apply variant
     int th_plan_bs = 0;         // plan kernel, > 64 sequences: pivot rows per batch = wavefronts x max(n, 1); < 0: one batch (EXTRACK_TH_PLAN_BS)
+    // Frozen plan (extrack_th_freeze_plan): threshold-fusion evaluations skip the plan kernel and follow the plan the last planning
+    // evaluation left in the buckets; per launch group (keyed by its first bucket and size) the sequence counts that size the apply / gradient launch
+    bool th_frozen = false;  // the per-bucket sequence counts that size the apply / gradient launch: XtBucket::th_maxG, th_sumE
     std::vector<double> blob_host;  // model tables of the current fixed-window evaluation (xt_prepare)
     bool th_plan_threads_forced = false;
     int th_plan_threads = 512;  // workgroup size of the plan kernel (EXTRACK_TH_PLAN_THREADS)

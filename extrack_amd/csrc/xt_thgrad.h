@@ -29,6 +29,7 @@ struct XtThGradArgs {
     double* gpartials;   // [wavefronts of the launch][1 + TB]: {sum LL, adjoint of blob[0 .. TB)}
     int32_t TB;          // XT_BLOB_HDR + XT_NTAB * S * G
     int32_t capP;        // sequences per step the scratch is laid out for: max(S, largest group count of the launch's chunks)
+    int32_t rows_global; // 1: the table-adjoint rows live at the end of the wavefront's scratch region instead of in LDS (more wavefronts per CU)
 };
 
 // LDS rows of one wavefront: the blob entries that can receive an adjoint, compacted (l2[0..2], slope, offset | log Fs[S] | tables) + sum LL
@@ -40,11 +41,15 @@ XT_HD int xt_thg_row_of_blob(int i, int S)  // -1: the slot has no adjoint
     if (i >= XT_BLOB_HDR) return 5 + S + (i - XT_BLOB_HDR);
     return -1;
 }
-XT_HD int64_t xt_thg_lds_doubles(int S, int G, int waves) { return ((xt_tab_doubles(S, G) + 1) & ~1) + (int64_t)waves * xt_thg_rows(S, G) * 64; }
-// scratch of one wavefront: the log (Lmax - 1 steps) + the re-integrated parents + two adjoint buffers
-XT_HD int64_t xt_thg_ws_doubles(int capP, int Lmax, int D, int K)
+XT_HD int64_t xt_thg_lds_doubles(int S, int G, int waves, int capE, bool rows_global = false)
 {
-    return (int64_t)Lmax * xt_th_buf_doubles(capP * 64, D, K) + 2 * (int64_t)capP * 64 * (1 + D + K);
+    // tables | accumulator rows per wavefront | per wavefront: group index of every expanded sequence of the step being walked back (u16)
+    return ((xt_tab_doubles(S, G) + 1) & ~1) + (rows_global ? 0 : (int64_t)waves * xt_thg_rows(S, G) * 64) + (int64_t)waves * (((capE + 3) & ~3) / 4);
+}
+// scratch of one wavefront: the log (Lmax - 1 steps) + the re-integrated parents + two adjoint buffers
+XT_HD int64_t xt_thg_ws_doubles(int capP, int Lmax, int D, int K, int rows = 0)
+{
+    return (int64_t)Lmax * xt_th_buf_doubles(capP * 64, D, K) + 2 * (int64_t)capP * 64 * (1 + D + K) + (int64_t)rows * 64;
 }
 
 // adjoint record of one sequence of one track: [a = d LL / d log z | mb[D] | ub[K]] as rows of 64 lanes
@@ -56,7 +61,9 @@ struct XtThgAdj {
     XT_HD double& ub(int k, int g, int x) const { return base[((int64_t)g * (1 + D + K) + 1 + D + k) * 64 + x]; }
 };
 
-template <int D, int K, class Ctx>
+// RG: the table-adjoint rows live in the wavefront's scratch region (global memory) instead of LDS - a compile-time choice so that the
+// LDS variant keeps LDS-typed accesses (a run-time select makes them flat: measured +20 %)
+template <int D, int K, bool RG, class Ctx>
 XT_HD void xt_thg_body(const XtThArgs& a, const XtThGradArgs& ga, Ctx& cx)
 {
     typedef XtThView<D, K, false> View;
@@ -75,7 +82,11 @@ XT_HD void xt_thg_body(const XtThArgs& a, const XtThGradArgs& ga, Ctx& cx)
     const double* TABl = smem + XT_BLOB_HDR;
     const double* T64 = TABl + XT_NTAB * SG;
     const int NR = xt_thg_rows(S, G);
-    double* rows = smem + ((ntab + 1) & ~1) + (int64_t)wv * NR * 64;  // this wavefront's accumulators [NR][64]
+    const int capP = ga.capP;
+    const int64_t bufd = xt_th_buf_doubles(capP * 64, D, K);
+    double* wsw = ga.ws + ((int64_t)cx.block() * NW + wv) * ga.ws_stride;
+    // this wavefront's accumulators [NR][64]: LDS, or the tail of its scratch region
+    double* rows = RG ? wsw + (int64_t)Lmax * bufd + 2 * (int64_t)capP * 64 * (1 + D + K) : smem + ((ntab + 1) & ~1) + (int64_t)wv * NR * 64;
     for (int r = 0; r < NR; ++r) rows[r * 64 + x] = 0.0;
     const int rFs = 5, rT = 5 + S, rD2 = 5 + S + 4 * SG, rLL = NR - 1;
     // wave-uniform reads: the plan and the expansion tables through the constant address space (scalar loads on the device)
@@ -88,9 +99,6 @@ XT_HD void xt_thg_body(const XtThArgs& a, const XtThGradArgs& ga, Ctx& cx)
     const typename CD::type TD2 = TAB + 4 * SG;
     cx.sync();
 
-    const int capP = ga.capP;
-    const int64_t bufd = xt_th_buf_doubles(capP * 64, D, K);
-    double* wsw = ga.ws + ((int64_t)cx.block() * NW + wv) * ga.ws_stride;
     auto logv = [&](int t) XT_INL {
         View v;
         v.base = wsw + (int64_t)t * bufd;
@@ -242,153 +250,206 @@ XT_HD void xt_thg_body(const XtThArgs& a, const XtThGradArgs& ga, Ctx& cx)
         }
 
         // ================= backward sweep =================
-        // seed: d LL / d (every term of the last position's sum) = term / Z
-        const double rZ = keep * xt_rcp(tot.m);
-        for (int g = 0; g < nPar; ++g) {
-            const int idx = g * 64 + x;
-            const double zq = fin.zm(idx);
-            const int eq = fin.ze(idx);
-            const int o = (L >= 3 ? (int)gnew_g[(int64_t)(L - 2) * capE + g] : g) * G;
-            double dq[D], uq[K], dsq = 0.0, dsqk[K];
-            for (int k = 0; k < K; ++k) dsqk[k] = 0.0;
+        // Gaussian integration of position `pos` into one sequence, in registers (xt_th_integrate_store without the store)
+        auto integrate_regs = [&](double& z, int& e, double* m, double* u, const double* c, const double* l2) XT_INL {
+            double dm[D], dsq = 0.0;
             for (int d = 0; d < D; ++d) {
-                dq[d] = cl[d] - fin.m(d, idx);
-                dsq = xt_fma(dq[d], dq[d], dsq);
-                dsqk[K == 1 ? 0 : d] += dq[d] * dq[d];
+                dm[d] = c[d] - m[d];
+                dsq = xt_fma(dm[d], dm[d], dsq);
             }
-            for (int k = 0; k < K; ++k) uq[k] = fin.u(k, idx);
-            double ag = 0.0, mbg[D], ubg[K];
-            for (int d = 0; d < D; ++d) mbg[d] = 0.0;
-            for (int k = 0; k < K; ++k) ubg[k] = 0.0;
-            for (int r = 0; r < G; ++r) {
-                double quad, gf, rr[K];
-                if (K == 1) {
-                    rr[0] = xt_rcp(TD2[o + r] + uq[0] + l2l[0]);
-                    quad = 0.5 * dsq * rr[0];
-                    gf = xt_pow_half<D>(rr[0]);
+            double quad, gf, tt[K];
+            if (K == 1) {
+                const double r = xt_rcp(l2[0] + u[0]);
+                tt[0] = u[0] * r;
+                quad = 0.5 * dsq * r;
+                gf = xt_pow_half<D>(r);
+            } else {
+                quad = 0.0;
+                gf = 1.0;
+                for (int d = 0; d < D; ++d) {
+                    const double r = xt_rcp(l2[d] + u[d]);
+                    tt[d] = u[d] * r;
+                    quad = xt_fma(0.5 * dm[d] * dm[d], r, quad);
+                    gf *= r;
+                }
+                gf = sqrt(gf);
+            }
+            double p;
+            int jj, n2;
+            xt_exp_tab(-quad, p, jj, n2);
+            const double z0 = z;
+            z = z0 * (gf * T64[jj]) * p;
+            const int en = e + n2;
+            e = (z0 != 0.0 && en > XT_EMIN) ? en : XT_EMIN;
+            for (int d = 0; d < D; ++d) m[d] = xt_fma(dm[d], tt[K == 1 ? 0 : d], m[d]);
+            for (int k = 0; k < K; ++k) u[k] = l2[k] * tt[k];
+        };
+        // the same integration backwards: adjoint (ay, mby, uby) of the integrated sequence -> adjoint of the sequence before it (m, u: its
+        // mean / variance), stored as entry g of `dst`; the localisation variance of the position gets its share
+        auto integrate_back = [&](int pos, const double* m, const double* u, const double* c, const double* l2, double ay, const double* mby,
+                                  const double* uby, const XtThgAdj<D, K>& dst, int g) XT_INL {
+            double dm[D], r[K], mdm[K], dsqk[K];
+            for (int k = 0; k < K; ++k) {
+                r[k] = xt_rcp(l2[k] + u[k]);
+                mdm[k] = 0.0;
+                dsqk[k] = 0.0;
+            }
+            for (int d = 0; d < D; ++d) {
+                const int kd = K == 1 ? 0 : d;
+                dm[d] = c[d] - m[d];
+                mdm[kd] = xt_fma(mby[d], dm[d], mdm[kd]);
+                dsqk[kd] = xt_fma(dm[d], dm[d], dsqk[kd]);
+                // m' = m + dm tt, log z' has -dm^2 r / 2:  d/dm = a dm r + mb' (1 - tt)
+                dst.mb(d, g, x) = xt_fma(ay * dm[d], r[kd], mby[d] * (1.0 - u[kd] * r[kd]));
+            }
+            dst.a(g, x) = ay;
+            for (int k = 0; k < K; ++k) {
+                const double r2 = r[k] * r[k];
+                const double gk = ay * r[k] * xt_fma(0.5 * dsqk[k], r[k], K == 1 ? -0.5 * D : -0.5);  // d log z' / d (l2 + u)
+                dst.ub(k, g, x) = gk + mdm[k] * l2[k] * r2 + uby[k] * l2[k] * l2[k] * r2;
+                l2_back(pos, k, gk - mdm[k] * u[k] * r2 + uby[k] * u[k] * u[k] * r2);
+            }
+        };
+        // ---- seed: d LL / d (every term of the last position's sum) = term / Z -> adjoint of Y_{L-2}, taken straight through the integration of
+        // position L - 2 to the adjoint of X_{L-2} (L >= 3); for two-position tracks it is the adjoint of X_0
+        const double rZ = keep * xt_rcp(tot.m);
+        {
+            const View Xl = logv(L >= 3 ? L - 2 : 0);
+            double c2[D], l22[K];
+            if (L >= 3) {
+                load_pos(L - 2, c2);
+                load_l2(L - 2, l22);
+            }
+            for (int g = 0; g < nPar; ++g) {
+                const int idx = g * 64 + x;
+                const double zq = fin.zm(idx);
+                const int eq = fin.ze(idx);
+                const int o = (L >= 3 ? (int)gnew_g[(int64_t)(L - 2) * capE + g] : g) * G;
+                double dq[D], uq[K], dsq = 0.0, dsqk[K];
+                for (int k = 0; k < K; ++k) dsqk[k] = 0.0;
+                for (int d = 0; d < D; ++d) {
+                    dq[d] = cl[d] - fin.m(d, idx);
+                    dsq = xt_fma(dq[d], dq[d], dsq);
+                    dsqk[K == 1 ? 0 : d] += dq[d] * dq[d];
+                }
+                for (int k = 0; k < K; ++k) uq[k] = fin.u(k, idx);
+                double ag = 0.0, mbg[D], ubg[K];
+                for (int d = 0; d < D; ++d) mbg[d] = 0.0;
+                for (int k = 0; k < K; ++k) ubg[k] = 0.0;
+                for (int r = 0; r < G; ++r) {
+                    double quad, gf, rr[K];
+                    if (K == 1) {
+                        rr[0] = xt_rcp(TD2[o + r] + uq[0] + l2l[0]);
+                        quad = 0.5 * dsq * rr[0];
+                        gf = xt_pow_half<D>(rr[0]);
+                    } else {
+                        quad = 0.0;
+                        gf = 1.0;
+                        for (int d = 0; d < D; ++d) {
+                            rr[d] = xt_rcp(TD2[o + r] + uq[d] + l2l[d]);
+                            quad = xt_fma(0.5 * dq[d] * dq[d], rr[d], quad);
+                            gf *= rr[d];
+                        }
+                        gf = sqrt(gf);
+                    }
+                    double p;
+                    int jj, n2;
+                    xt_exp_tab(-quad, p, jj, n2);
+                    const double term = zq * TF[o + r] * (gf * T64[jj]) * p;
+                    const double f = (term == 0.0) ? 0.0 : xt_ldexp(term * rZ, eq + n2 - tot.e);
+                    ag += f;
+                    rows[(rT + vF * SG + o + r) * 64 + x] += f;
+                    double hs = 0.0;
+                    for (int k = 0; k < K; ++k) {
+                        // d log term / d v_k,  v_k = u_k + d2 + l2_k:  -(D or 1) / (2 v) + dsq_k / (2 v^2)
+                        const double h = f * rr[k] * xt_fma(0.5 * dsqk[k], rr[k], K == 1 ? -0.5 * D : -0.5);
+                        ubg[k] += h;
+                        hs += h;
+                        l2_back(tl, k, h);
+                    }
+                    rows[(rD2 + o + r) * 64 + x] += hs;
+                    for (int d = 0; d < D; ++d) mbg[d] = xt_fma(f * dq[d], rr[K == 1 ? 0 : d], mbg[d]);
+                }
+                if (L >= 3) {
+                    double mx[D], ux[K];
+                    for (int d = 0; d < D; ++d) mx[d] = Xl.m(d, idx);
+                    for (int k = 0; k < K; ++k) ux[k] = Xl.u(k, idx);
+                    integrate_back(L - 2, mx, ux, c2, l22, ag, mbg, ubg, adjB, g);
                 } else {
-                    quad = 0.0;
-                    gf = 1.0;
-                    for (int d = 0; d < D; ++d) {
-                        rr[d] = xt_rcp(TD2[o + r] + uq[d] + l2l[d]);
-                        quad = xt_fma(0.5 * dq[d] * dq[d], rr[d], quad);
-                        gf *= rr[d];
-                    }
-                    gf = sqrt(gf);
+                    rows[(rFs + g) * 64 + x] += ag;
+                    for (int k = 0; k < K; ++k) l2_back(0, k, ubg[k]);
                 }
-                double p;
-                int j, n2;
-                xt_exp_tab(-quad, p, j, n2);
-                const double term = zq * TF[o + r] * (gf * T64[j]) * p;
-                const double f = (term == 0.0) ? 0.0 : xt_ldexp(term * rZ, eq + n2 - tot.e);
-                ag += f;
-                rows[(rT + vF * SG + o + r) * 64 + x] += f;
-                double hs = 0.0;
-                for (int k = 0; k < K; ++k) {
-                    // d log term / d v_k,  v_k = u_k + d2 + l2_k:  -(D or 1) / (2 v) + dsq_k / (2 v^2)
-                    const double h = f * rr[k] * xt_fma(0.5 * dsqk[k], rr[k], K == 1 ? -0.5 * D : -0.5);
-                    ubg[k] += h;
-                    hs += h;
-                    l2_back(tl, k, h);
-                }
-                rows[(rD2 + o + r) * 64 + x] += hs;
-                for (int d = 0; d < D; ++d) mbg[d] = xt_fma(f * dq[d], rr[K == 1 ? 0 : d], mbg[d]);
             }
-            adjA.a(g, x) = ag;
-            for (int d = 0; d < D; ++d) adjA.mb(d, g, x) = mbg[d];
-            for (int k = 0; k < K; ++k) adjA.ub(k, g, x) = ubg[k];
         }
-        // adjA = adjoint of Y_{L-2} (of X_0 when L == 2)
-        for (int t = L - 2; t >= 1; --t) {
-            const int nG = n_groups(t), nPp = n_groups(t - 1);
-            // ---- integration of position t, backwards: adjoint of X_t from the adjoint of Y_t
-            {
-                const View X = logv(t);
-                double c[D], l2[K];
-                load_pos(t, c);
-                load_l2(t, l2);
-                for (int g = 0; g < nG; ++g) {
-                    const int idx = g * 64 + x;
-                    const double ay = adjA.a(g, x);
-                    double dm[D], r[K], u[K], mdm[K], dsqk[K];
-                    for (int k = 0; k < K; ++k) {
-                        u[k] = X.u(k, idx);
-                        r[k] = xt_rcp(l2[k] + u[k]);
-                        mdm[k] = 0.0;
-                        dsqk[k] = 0.0;
-                    }
-                    double mby[D];
-                    for (int d = 0; d < D; ++d) {
-                        const int kd = K == 1 ? 0 : d;
-                        dm[d] = c[d] - X.m(d, idx);
-                        mby[d] = adjA.mb(d, g, x);
-                        mdm[kd] = xt_fma(mby[d], dm[d], mdm[kd]);
-                        dsqk[kd] = xt_fma(dm[d], dm[d], dsqk[kd]);
-                        // m' = m + dm tt, log z' has -dm^2 r / 2:  d/dm = a dm r + mb' (1 - tt)
-                        adjB.mb(d, g, x) = xt_fma(ay * dm[d], r[kd], mby[d] * (1.0 - u[kd] * r[kd]));
-                    }
-                    adjB.a(g, x) = ay;
-                    for (int k = 0; k < K; ++k) {
-                        const double r2 = r[k] * r[k];
-                        const double gk = ay * r[k] * xt_fma(0.5 * dsqk[k], r[k], K == 1 ? -0.5 * D : -0.5);  // d log z' / d (l2 + u)
-                        const double uby = adjA.ub(k, g, x);
-                        adjB.ub(k, g, x) = gk + mdm[k] * l2[k] * r2 + uby * l2[k] * l2[k] * r2;
-                        l2_back(t, k, gk - mdm[k] * u[k] * r2 + uby * u[k] * u[k] * r2);
-                    }
+        // ---- s = L-2 ... 1: adjB = adjoint of X_s (its groups).  Every parent p of step s (a sequence of X_{s-1}) is re-integrated in
+        // registers, gathers its adjoint from the G groups that took its expansions (the inverse of the plan's member lists, built per step
+        // in LDS), and is taken straight back through its own integration: one pass per step, the adjoint of Y_{s-1} is never stored
+        uint16_t* gidx = (uint16_t*)(smem + ((ntab + 1) & ~1) + (RG ? 0 : (int64_t)NW * NR * 64)) + (int64_t)wv * ((capE + 3) & ~3);
+        XtThgAdj<D, K> aCur = adjB, aNxt = adjA;
+        for (int s2 = L - 2; s2 >= 1; --s2) {
+            const int nG = n_groups(s2), nPp = n_groups(s2 - 1);
+            const typename CU32::type mem = mpk_g + (int64_t)s2 * capE;
+            const typename CU16::type gst = gst_g + (int64_t)s2 * (capE + 1);
+            cx.wave_sync();  // the previous step's reads of the map are done
+            for (int g2 = x; g2 < nG; g2 += 64)
+                for (int kk = gst[g2]; kk < (int)gst[g2 + 1]; ++kk) {
+                    const uint32_t pk = mem[kk];
+                    gidx[(int)(pk >> 16) * G + (int)((pk & 0xffffu) % (uint32_t)G)] = (uint16_t)g2;
                 }
-            }
-            // ---- merge step t, backwards: adjoint of Y_{t-1} (its parents) from the adjoint of X_t (the groups)
-            if (t >= 2) integrate_all(t - 1, nPp);
-            const View src = t >= 2 ? Y : logv(0);
-            const View Xt = logv(t);
-            for (int p = 0; p < nPp; ++p) {
-                adjA.a(p, x) = 0.0;
-                for (int d = 0; d < D; ++d) adjA.mb(d, p, x) = 0.0;
-                for (int k = 0; k < K; ++k) adjA.ub(k, p, x) = 0.0;
-            }
-            const typename CU32::type mem = mpk_g + (int64_t)t * capE;
-            const typename CU16::type gst = gst_g + (int64_t)t * (capE + 1);
-            const bool stay = t >= 2 && t >= a.min_len;
+            cx.wave_sync();
+            const bool stay = s2 >= 2 && s2 >= a.min_len;
             const int vT = stay ? 1 : 0;
             const typename CD::type TTl = TAB + vT * SG;
-            for (int g2 = 0; g2 < nG; ++g2) {
-                const int gi = g2 * 64 + x;
-                const double Wm = Xt.zm(gi);
-                if (Wm == 0.0) continue;  // a dead group has no share in the likelihood (its adjoint is zero, its members' weights too)
-                const int We = Xt.ze(gi);
-                const double rW = xt_rcp(Wm);
-                const double A = adjB.a(g2, x);
-                double M[D], U[K], Mb[D], Ub[K], ubs = 0.0;
-                for (int d = 0; d < D; ++d) {
-                    M[d] = Xt.m(d, gi);
-                    Mb[d] = adjB.mb(d, g2, x);
-                }
-                for (int k = 0; k < K; ++k) {
-                    U[k] = Xt.u(k, gi);
-                    Ub[k] = adjB.ub(k, g2, x);
-                    ubs += Ub[k];
-                }
-                const int k0 = gst[g2], k1 = gst[g2 + 1];
-                for (int kk = k0; kk < k1; ++kk) {
-                    const uint32_t pk = mem[kk];
-                    const int o = (int)(pk & 0xffffu), p = (int)(pk >> 16), pi = p * 64 + x;
-                    const double al = xt_ldexp(src.zm(pi) * TTl[o] * rW, src.ze(pi) - We);  // this member's share of the group's weight
-                    double cj = A;
-                    for (int d = 0; d < D; ++d) cj = xt_fma(Mb[d], src.m(d, pi) - M[d], cj);
-                    for (int k = 0; k < K; ++k) cj = xt_fma(Ub[k], src.u(k, pi) + TD2[o] - U[k], cj);
+            const View Xs = logv(s2), Xp = logv(s2 - 1);
+            double c[D], l2[K];
+            if (s2 >= 2) {
+                load_pos(s2 - 1, c);
+                load_l2(s2 - 1, l2);
+            }
+            for (int p = 0; p < nPp; ++p) {
+                const int pi = p * 64 + x;
+                double mx[D], ux[K], my[D], uy[K];
+                double zy = Xp.zm(pi);
+                int ey = Xp.ze(pi);
+                for (int d = 0; d < D; ++d) my[d] = mx[d] = Xp.m(d, pi);
+                for (int k = 0; k < K; ++k) uy[k] = ux[k] = Xp.u(k, pi);
+                if (s2 >= 2) integrate_regs(zy, ey, my, uy, c, l2);
+                const int o0 = (s2 >= 2 ? (int)gnew_g[(int64_t)(s2 - 1) * capE + p] : p) * G;
+                double ap = 0.0, mbp[D], ubp[K];
+                for (int d = 0; d < D; ++d) mbp[d] = 0.0;
+                for (int k = 0; k < K; ++k) ubp[k] = 0.0;
+                for (int r = 0; r < G; ++r) {
+                    const int g2 = gidx[p * G + r], gi = g2 * 64 + x, o = o0 + r;
+                    const double Wm = Xs.zm(gi);
+                    if (Wm == 0.0) continue;  // a dead group has no share in the likelihood
+                    const double al = xt_ldexp(zy * TTl[o] * xt_rcp(Wm), ey - Xs.ze(gi));  // this member's share of its group's weight
+                    double cj = aCur.a(g2, x), ubs = 0.0;
+                    for (int d = 0; d < D; ++d) {
+                        const double Mb = aCur.mb(d, g2, x);
+                        cj = xt_fma(Mb, my[d] - Xs.m(d, gi), cj);
+                        mbp[d] = xt_fma(al, Mb, mbp[d]);
+                    }
+                    for (int k = 0; k < K; ++k) {
+                        const double Ub = aCur.ub(k, g2, x);
+                        cj = xt_fma(Ub, uy[k] + TD2[o] - Xs.u(k, gi), cj);
+                        ubp[k] = xt_fma(al, Ub, ubp[k]);
+                        ubs += Ub;
+                    }
                     const double ac = al * cj;
-                    adjA.a(p, x) += ac;
+                    ap += ac;
                     rows[(rT + vT * SG + o) * 64 + x] += ac;
                     rows[(rD2 + o) * 64 + x] += al * ubs;
-                    for (int d = 0; d < D; ++d) adjA.mb(d, p, x) = xt_fma(al, Mb[d], adjA.mb(d, p, x));
-                    for (int k = 0; k < K; ++k) adjA.ub(k, p, x) = xt_fma(al, Ub[k], adjA.ub(k, p, x));
+                }
+                if (s2 >= 2) {
+                    integrate_back(s2 - 1, mx, ux, c, l2, ap, mbp, ubp, aNxt, p);
+                } else {  // X_0: weight = Fs, mean = first position, variance = l2 of the first position
+                    rows[(rFs + p) * 64 + x] += ap;
+                    for (int k = 0; k < K; ++k) l2_back(0, k, ubp[k]);
                 }
             }
-        }
-        // adjA = adjoint of X_0: weight = Fs, mean = first position, variance = l2 of the first position
-        for (int g = 0; g < S; ++g) {
-            rows[(rFs + g) * 64 + x] += adjA.a(g, x);
-            for (int k = 0; k < K; ++k) l2_back(0, k, adjA.ub(k, g, x));
+            const XtThgAdj<D, K> tmp = aCur;
+            aCur = aNxt;
+            aNxt = tmp;
         }
     }
 

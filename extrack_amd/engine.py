@@ -197,6 +197,12 @@ class TrackSet:
             return (0.0, np.empty(0)) if per_track else 0.0
         return self.ctx.loglik_th(model, threshold, max_nb_states, chunk, per_track=per_track)
 
+    def th_freeze_plan(self, on):
+        """Threshold-fusion evaluations follow the plan of the last planning evaluation (True) or decide their own again (False);
+        see extrack_th_freeze_plan in include/extrack_hip.h.  A shard without tracks has nothing to freeze."""
+        if self.shapes:
+            self.ctx.th_freeze_plan(on)
+
     def predict_th(self, model, threshold=0.1, max_nb_states=200, nb_max=1):
         return [self.ctx.predict_th(model, i, threshold, max_nb_states, nb_max) for i in range(len(self.shapes))]
 

@@ -455,7 +455,7 @@ def _pick_gradient(params, fargs, explicit, comm=None, info=None):
         t_ll = time.perf_counter() - t0
         try:
             t0 = time.perf_counter()
-            cum_Proba_Cs_grad(params, names, *a)  # first call: includes one-time allocations
+            cum_Proba_Cs_grad(params, names, *a)  # first call: includes one-time allocations (the state log of the reverse-mode kernels: GBs)
             t_g = time.perf_counter() - t0
         except NotImplementedError as e:
             unsupported = str(e)
@@ -467,7 +467,7 @@ def _pick_gradient(params, fargs, explicit, comm=None, info=None):
             if comm.allreduce_scalar(1.0 if unsupported else 0.0, "max") > 0.5:
                 unsupported = unsupported or "not served on another rank"
         if unsupported is None:
-            clear = t_g > 1.5 * (len(names) + 1) * t_ll  # already far on the wrong side: spare the second (warm) gradient call
+            clear = t_g > 20.0 * (len(names) + 1) * t_ll  # hopelessly on the wrong side even with its allocations: spare the warm call
             if comm is not None:
                 clear = comm.allreduce_scalar(1.0 if clear else 0.0, "min") > 0.5
             if not clear:
@@ -481,6 +481,61 @@ def _pick_gradient(params, fargs, explicit, comm=None, info=None):
         t_ll, t_g = float(v[0]), float(v[1])
     use = t_g < (len(names) + 1) * t_ll
     return decide(use, "timing probe: one gradient call %.3g ms vs %d objective calls of %.3g ms" % (t_g * 1e3, len(names) + 1, t_ll * 1e3))
+
+
+def _fit_threshold_frozen_plan(params, fargs, method, ts, max_rounds=6):
+    """Threshold-fusion fit with the exact gradient.  The objective of extrack/tracking.py:991 re-decides its merge groups at every
+    evaluation (fuse_tracks_th, :676-701), which makes it piecewise smooth: a quasi-Newton method fed with exact gradients of the pieces
+    sees jumps its model cannot explain, needs several times the iterations of the fixed-window fit and ends on "precision loss".  So:
+      1. evaluate once (the plan kernel decides the groups at the current parameters),
+      2. FREEZE that plan and minimise the now smooth objective with its exact gradient (gradient kernel only, no plan kernel),
+      3. re-plan at the minimiser; stop when the re-planned objective equals the frozen one (the plan did not change) or no longer improves.
+    The result's ``residual`` is the reference's objective (own plan) at the returned parameters; ``nfev`` / ``ngev`` count every evaluation of
+    every round; ``plan_rounds`` says how many plans were used."""
+    from . import lmfit_compat
+    nfev = ngev = 0
+    cur, fit, f_prev, rounds = params, None, None, 0
+    a = list(fargs)
+    a[7] = 0  # the planning evaluations between the rounds are silent
+    import contextlib
+    import io
+    try:
+        for rounds in range(1, max_rounds + 1):
+            ts.th_freeze_plan(False)
+            with contextlib.redirect_stdout(io.StringIO()):
+                f_plan = cum_Proba_Cs(cur, *a)  # decides the plan at `cur`
+            nfev += 1
+            if not np.isfinite(f_plan):
+                raise ValueError("the starting parameters are invalid for the model (objective = inf)")
+            ts.th_freeze_plan(True)
+            fit = lmfit_compat.minimize_with_gradient(cum_Proba_Cs, cur, args=fargs, method=method, nan_policy="propagate", fcn_grad=cum_Proba_Cs_grad)
+            nfev += int(fit.nfev)
+            ngev += int(getattr(fit, "ngev", 0))
+            ts.th_freeze_plan(False)
+            cur = getattr(fit, "own_params", fit.params)
+            with contextlib.redirect_stdout(io.StringIO()):
+                f_new = cum_Proba_Cs(cur, *a)  # the reference's objective (own plan) at the minimiser
+            nfev += 1
+            f_frozen = float(fit.residual[0])
+            same_plan = abs(f_new - f_frozen) <= 1e-11 * abs(f_new)
+            no_gain = f_prev is not None and f_new >= f_prev - 1e-10 * abs(f_prev)
+            f_prev = f_new if f_prev is None else min(f_prev, f_new)
+            if same_plan or no_gain:
+                break
+    finally:
+        ts.th_freeze_plan(False)
+    fit.residual = np.atleast_1d(np.float64(f_new))
+    fit.nfev, fit.ngev, fit.plan_rounds = nfev, ngev, rounds
+    if type(fit.params) is not type(params):  # the caller's Parameters type (real lmfit) carries the fitted values
+        import copy
+        out = copy.deepcopy(params)
+        for k, p in cur.items():
+            if not getattr(out[k], "expr", None):
+                out[k].value = p.value
+        if hasattr(out, "update_constraints"):
+            out.update_constraints()
+        fit.own_params, fit.params = cur, out
+    return fit
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -532,7 +587,9 @@ def param_fitting(all_tracks, dt, params=None, nb_states=2, nb_substeps=1, frame
         use_grad = can_grad and gradient != "fd"
         if use_grad:
             use_grad = _pick_gradient(params, fargs, explicit=(gradient == "analytic"), comm=comm, info=ginfo)
-        if use_grad:
+        if use_grad and fusion == "threshold":
+            fit = _fit_threshold_frozen_plan(params, fargs, method, ts)
+        elif use_grad:
             # the built-in BFGS driver takes the analytic gradient (chain rule through the bounds transform applied there); with real
             # lmfit installed its Parameters are converted for the fit and the fitted values written back into a copy of them
             fit = lmfit_compat.minimize_with_gradient(cum_Proba_Cs, params, args=fargs, method=method, nan_policy="propagate",

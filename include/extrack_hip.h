@@ -157,7 +157,10 @@ typedef struct extrack_model_tangent {
  * directions, by forward-mode differentiation inside the recursion (window fusion included: it is the exact gradient of the
  * value extrack_loglik returns, not an approximation).  total_ll: sum of per-track log-likelihoods; grad[i] = d total_ll /
  * d theta_i (host, n_dir entries).  n_dir may be 0 (then it is extrack_loglik).  Two-state models with one substep run with the
- * sequence state and its tangents in registers (csrc/xt_reg2.h), <= 8 directions per pass; other models with the tangents in LDS. */
+ * sequence state and its tangents in registers (csrc/xt_reg2.h), <= 8 directions per pass; 3 / 4 states by reverse mode (csrc/xt_rev.h);
+ * other models with the tangents in registers + LDS exchange (csrc/xt_gradr.h) or in LDS (csrc/xt_grad.h).  Restriction: all uploaded
+ * buckets must share the track dimensionality and the per-peak error layout (ONE launch group; a real dataset does) - otherwise
+ * EXTRACK_E_UNSUPPORTED (extrack_loglik itself serves such mixed sets, group by group). */
 int extrack_loglik_grad(extrack_ctx* ctx, const extrack_model* model, int32_t n_dir, const extrack_model_tangent* tangents,
                         double* total_ll, double* grad);
 /* The same evaluation enqueued on the context's stream (extrack_set_stream) without waiting for it: d_out (DEVICE, 1 + n_dir
@@ -179,6 +182,13 @@ int extrack_loglik_th_grad(extrack_ctx* ctx, const extrack_model* model, double 
  * kernel's sequence counts are still read back once inside the call, as in extrack_loglik_th_async). */
 int extrack_loglik_th_grad_async(extrack_ctx* ctx, const extrack_model* model, double threshold, int32_t max_nb_states, int32_t chunk,
                                  int32_t n_dir, const extrack_model_tangent* tangents, double* d_out);
+/* Frozen plan: with on = 1 the threshold-fusion evaluations of this context (extrack_loglik_th[_async], extrack_loglik_th_grad[_async])
+ * skip the plan kernel and follow the merge plan the LAST planning evaluation left with the buckets (same chunk size required;
+ * EXTRACK_E_INVALID if there is none).  The value is then a smooth function of the model (the objective fuse_tracks_th would give if its
+ * grouping decisions, /root/reference/extrack/tracking.py:676-701, did not react to the parameters) - what an optimiser should be
+ * handed between two re-plannings (extrack_amd.tracking.param_fitting does: plan, minimise at that plan with the exact gradient,
+ * re-plan, until the plan no longer changes).  on = 0: every evaluation decides its own plan again (the reference's semantics). */
+int extrack_th_freeze_plan(extrack_ctx* ctx, int32_t on);
 /* Device time (ms) of the gradient kernels of the last extrack_loglik_grad / extrack_loglik_th_grad (or _async) call (waits for them). */
 int extrack_last_grad_ms(extrack_ctx* ctx, float* ms);
 

@@ -504,14 +504,15 @@ extern "C" int xt_emul_th_run(const double* tracks, const double* sigma, long lo
         memset(&ga, 0, sizeof(ga));
         ga.TB = TB;
         ga.capP = maxG > S ? maxG : S;
-        ga.ws_stride = xt_thg_ws_doubles(ga.capP, L, D, K);
+        ga.rows_global = getenv("XT_EMUL_THG_ROWS_GLOBAL") ? 1 : 0;
+        ga.ws_stride = xt_thg_ws_doubles(ga.capP, L, D, K, ga.rows_global ? xt_thg_rows(S, G) : 0);
         std::vector<double> gws((size_t)ga.ws_stride * grid * NW, xt_emul_poison() ? NAN : 0.0);
         std::vector<double> gp((size_t)grid * NW * (1 + TB), 0.0);
         ga.ws = gws.data();
         ga.gpartials = gp.data();
         a.ll_out = g_thg_ll;
-        const size_t glds = (size_t)xt_thg_lds_doubles(S, G, NW);
-#define TH_GRAD(DD, KK) th_emul_blocks(grid, 64 * NW, glds, [&](HostCtx& cx) { xt_thg_body<DD, KK>(a, ga, cx); })
+        const size_t glds = (size_t)xt_thg_lds_doubles(S, G, NW, capE, ga.rows_global != 0);
+#define TH_GRAD(DD, KK) th_emul_blocks(grid, 64 * NW, glds, [&](HostCtx& cx) { if (ga.rows_global) xt_thg_body<DD, KK, true>(a, ga, cx); else xt_thg_body<DD, KK, false>(a, ga, cx); })
         if (D == 1 && K == 1) TH_GRAD(1, 1);
         else if (D == 2 && K == 1) TH_GRAD(2, 1);
         else if (D == 2 && K == 2) TH_GRAD(2, 2);

@@ -61,8 +61,10 @@ def test_emulated_frozen_plan_gradient_vs_oracle_differences(S, ns, F, L, N, D, 
     assert rel.max() < 1e-6, [(d[0], a, b) for d, a, b, r in zip(dirs, g, fd, rel) if r > 1e-6]
 
 
-def test_emulated_frozen_plan_gradient_affine_per_peak_errors():
-    """Per-peak localisation errors with the affine correction (slope / offset, tracking.py:928-930): the two parameters' derivatives."""
+def test_emulated_frozen_plan_gradient_affine_per_peak_errors(monkeypatch):
+    """Per-peak localisation errors with the affine correction (slope / offset, tracking.py:928-930): the two parameters' derivatives; the
+    variant with the accumulator rows in the scratch region (what the launcher takes for 3 states and more)."""
+    monkeypatch.setenv("XT_EMUL_THG_ROWS_GLOBAL", "1")
     import run_emul as E
     from extrack_amd import synth
     from oracle import oracle_np as O

@@ -156,7 +156,7 @@ def test_c3_three_state_fit_recovers_simulated_parameters(capsys):
     tracks = _c3_tracks(6e4, seed0=500)
     p0 = T.generate_params(nb_states=3, LocErr_type=1, LocErr_bounds=[0.005, 0.1], D_max=3, estimated_Ds=[0.0001, 0.02, 0.4],
                            estimated_Fs=[0.3, 0.3], estimated_transition_rates=0.1)
-    # frame_len 6: the reference's default (extrack/tracking.py:1304); gradient=None: the timing probe decides (finite differences for 3 states today)
+    # frame_len 6: the reference's default (extrack/tracking.py:1304); gradient=None: the timing probe decides (the reverse-mode gradient on any dataset of this size; fit.gradient_path says which)
     fit = T.param_fitting(tracks, 0.02, params=p0, nb_states=3, nb_substeps=1, frame_len=6, verbose=0, method="bfgs", cell_dims=[1])
     capsys.readouterr()
     v = {k: fit.params[k].value for k in fit.params}
@@ -169,6 +169,26 @@ def test_c3_three_state_fit_recovers_simulated_parameters(capsys):
     rate = lambda pr: -np.log(1 - pr)  # Matrix_type 1: p = 1 - exp(-rate)
     assert abs(v["p01"] - rate(0.1)) < 0.03 and abs(v["p10"] - rate(0.05)) < 0.02 and abs(v["p21"] - rate(0.06)) < 0.02
     assert 10 < fit.nfev < 20000
+    assert fit.gradient_path in ("analytic", "fd") and fit.gradient_why
+
+
+def test_c3_full_size_fit_as_configs_2_states_it(capsys):
+    """BASELINE configs[2] as written: the FULL param_fitting of 1e6 tracks (3 states, 46 buckets of lengths 5 - 50, 13 free parameters,
+    frame_len 6) with default settings (gradient=None -> the probe picks the reverse-mode gradient): the optimum of the reference-style
+    finite-difference fit to 1e-9 relative, within 120 objective + gradient calls - a regression of either turns this red."""
+    from extrack_amd import tracking as T
+    tracks = _c3_tracks(1e6, seed0=1000)
+    p0 = T.generate_params(nb_states=3, LocErr_type=1, LocErr_bounds=[0.005, 0.1], D_max=3, estimated_Ds=[0.0001, 0.02, 0.4],
+                           estimated_Fs=[0.3, 0.3], estimated_transition_rates=0.1)
+    fa = T.param_fitting(tracks, 0.02, params=p0, nb_states=3, frame_len=6, verbose=0, method="bfgs", cell_dims=[1])
+    ff = T.param_fitting(tracks, 0.02, params=p0, nb_states=3, frame_len=6, verbose=0, method="bfgs", cell_dims=[1], gradient="fd")
+    capsys.readouterr()
+    print("full C3 fit: default path %s: %d + %d calls -> %.6f ; fd: %d calls -> %.6f" % (fa.gradient_path, fa.nfev, fa.ngev, fa.residual[0], ff.nfev, ff.residual[0]))
+    assert fa.gradient_path == "analytic", fa.gradient_why
+    assert fa.residual[0] <= ff.residual[0] + 1e-9 * abs(ff.residual[0]), (fa.residual[0], ff.residual[0])
+    assert fa.nfev + fa.ngev <= 120, (fa.nfev, fa.ngev)
+    v = {k: fa.params[k].value for k in fa.params}
+    assert abs(v["D1"] - 0.04) < 0.003 and abs(v["D2"] - 0.25) < 0.01 and abs(v["LocErr"] - 0.02) < 0.0005
 
 
 # ------------------------------------------------------------------------------------------------------------------
