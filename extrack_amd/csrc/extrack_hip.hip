@@ -7,6 +7,7 @@
 #include "xt_entry.h"
 #include "xt_fast2.h"
 #include "xt_reg2.h"
+#include "xt_big.h"
 
 // Waves per SIMD the register allocator is asked to allow (workgroups of 256 threads).  Likelihood kernels: 4, except 4 members per group
 // (4 states: 66 ms unbounded against 74 ms at 3 on the 5e5 x 60 set, frame_len 5).  Posterior kernels (226 VGPRs unbounded = 2 waves):
@@ -47,6 +48,26 @@ __global__ void __launch_bounds__(MAXT, (MAXT == 256 ? XT_ENTRY_WAVES : 1)) xt_e
     DevCtx cx;
     xt_entry_body<GP, D, K>(a, cx);
     xt_fused_total(a);
+}
+
+// Models whose sequence state does not fit a workgroup: one lane per track, state in global memory (xt_big.h)
+template <int D, int K, bool PREDS>
+__global__ void __launch_bounds__(256) xt_big_kernel(XtKernelArgs a, XtBigArgs ba)
+{
+    DevCtx cx;
+    xt_big_body<D, K, PREDS>(a, ba, cx);
+    if (!PREDS) xt_fused_total(a);
+}
+template <int D, int K>
+static const void* xt_big_kernel_ptr(bool preds) { return preds ? (const void*)xt_big_kernel<D, K, true> : (const void*)xt_big_kernel<D, K, false>; }
+static const void* xt_big_kernel_dk(int D, int K, bool preds)
+{
+    if (D == 1 && K == 1) return xt_big_kernel_ptr<1, 1>(preds);
+    if (D == 2 && K == 1) return xt_big_kernel_ptr<2, 1>(preds);
+    if (D == 2 && K == 2) return xt_big_kernel_ptr<2, 2>(preds);
+    if (D == 3 && K == 1) return xt_big_kernel_ptr<3, 1>(preds);
+    if (D == 3 && K == 3) return xt_big_kernel_ptr<3, 3>(preds);
+    return nullptr;
 }
 
 // Posterior / recording mode (PREDS) is launched with 64 or 256 threads per chunk: bounded by 256 threads, PW waves per SIMD asked of the register
@@ -264,6 +285,7 @@ extern "C" void extrack_destroy(extrack_ctx* ctx)
     if (ctx->d_gpartials) (void)hipFree(ctx->d_gpartials);
     if (ctx->d_partials) (void)hipFree(ctx->d_partials);
     if (ctx->d_total) (void)hipFree(ctx->d_total);
+    if (ctx->d_big_ws) (void)hipFree(ctx->d_big_ws);
     if (ctx->d_done) (void)hipFree(ctx->d_done);
     if (ctx->h_total) (void)hipHostFree(ctx->h_total);
     if (ctx->d_desc) (void)hipFree(ctx->d_desc);
@@ -491,6 +513,8 @@ struct DevLauncher {
     size_t desc_off = 0;
     int grid = 0, occ = 0;
     hipError_t herr = hipSuccess;
+    void* extra_arg = nullptr;  // second kernel argument (xt_big_kernel: its scratch description) or nullptr
+    double max_blocks = 0.0;    // > 0: upper bound of the grid (scratch budget of the launch)
 
     template <int G_, int D, int K, bool PREDS>
     bool run()
@@ -555,6 +579,7 @@ struct DevLauncher {
         // one batch's worth), but never fewer blocks than fill the chip once.  125 000 x 30 (the 8-way shard of the headline dataset):
         // 8 generations 0.399 ms, 4 generations 0.389 ms, 1 generation 0.423 ms (r04, same box)
         if (!ctx->oversub_forced) target = std::max((double)occ * ctx->n_cu, std::min(target, (double)nbsum / 4.0));
+        if (max_blocks > 0.0) target = std::max((double)nb, std::min(target, max_blocks));
         int64_t acc = 0;
         for (int i = 0; i < nb; ++i) {
             int64_t n = (int64_t)ceil(target * ((double)nbatch[i] * (descs[i].L - 1)) / wsum);
@@ -585,7 +610,7 @@ struct DevLauncher {
         }
         a.desc = ctx->d_desc + desc_off;
         a.ndesc = nb;
-        void* kargs[1] = {(void*)&a};
+        void* kargs[2] = {(void*)&a, extra_arg};
         herr = hipLaunchKernel(kp, dim3(grid), dim3(threads), kargs, lds, ctx->stream);
         if (herr == hipSuccess) herr = hipGetLastError();
         return true;
@@ -643,8 +668,38 @@ static int xt_launch_group(extrack_ctx* ctx, const extrack_model* m, const std::
                              : (size_t)xt_f2_block_bytes(D, K, m->locerr_mode ? b0.KS : 0, tpw);
     } else {
         xt_geometry(c, D, K, tpb, threads);
-        if (threads > 1024) return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "n_states^(frame_len-nb_substeps) > 1024 groups per track is not built");
         l.lds = xt_lds_bytes(c, D, K, tpb);
+    }
+    // the sequence state of a track does not fit a workgroup (more than 1024 groups, more than the CU's LDS, posteriors beyond the built group
+    // sizes): one lane per track with the state in global memory (xt_big.h)
+    bool big = l.lds > 160 * 1024 || (!fast2 && !entry && (threads > 1024 || (preds && c.G > 6)));
+    if (const char* ev = getenv("EXTRACK_FORCE_BIG")) big = big || (atoi(ev) != 0 && !d_seq);
+    XtBigArgs bargs;
+    if (big) {
+        if (d_seq) return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "sequence matrix: n_states^frame_len sequences per track do not fit a workgroup");
+        if (preds && c.F > 15) return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "posteriors: frame_len > 15");
+        const int NW = 4;
+        threads = 64 * NW;
+        tpb = threads;
+        l.lds = (size_t)(((xt_tab_doubles(c.S, c.G) + 1) & ~1) + threads) * sizeof(double);
+        bargs.ws_stride = xt_big_ws_doubles(c.E, D, K);
+        size_t budget_mb = 32 * 1024;
+        if (const char* ev = getenv("EXTRACK_BIG_WS_MB")) budget_mb = (size_t)std::max(16, atoi(ev));
+        const size_t per_block = (size_t)bargs.ws_stride * sizeof(double) * NW;
+        const size_t maxb = std::max<size_t>(1, (budget_mb << 20) / per_block);
+        if (maxb < bks.size()) return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "n_states^frame_len sequences per track: the state of one workgroup per bucket exceeds the scratch budget (EXTRACK_BIG_WS_MB)");
+        l.max_blocks = (double)std::min<size_t>(maxb, (size_t)ctx->n_cu * 8);
+        const size_t need = (size_t)l.max_blocks * NW * (size_t)bargs.ws_stride + 64;
+        if (need > ctx->big_ws_cap) {
+            XT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (ctx->d_big_ws) (void)hipFree(ctx->d_big_ws);
+            ctx->d_big_ws = nullptr;
+            ctx->big_ws_cap = 0;
+            XT_HIP(ctx, hipMalloc(&ctx->d_big_ws, need * sizeof(double)));
+            ctx->big_ws_cap = need;
+        }
+        bargs.ws = ctx->d_big_ws;
+        l.extra_arg = (void*)&bargs;
     }
     l.threads = threads;
     l.tracks_per_block = tpb;
@@ -672,7 +727,6 @@ static int xt_launch_group(extrack_ctx* ctx, const extrack_model* m, const std::
         }
         l.a.well_scaled = (ctx->blob_host.size() > 8 && xt_model_well_scaled(ctx->blob_host, lo, hi)) ? 1 : 0;
     }
-    if (l.lds > 160 * 1024) return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "sequence state does not fit the 160 KiB LDS of a CU");
     l.desc_off = desc_off;
     for (XtBucket* b : bks) {
         XtBucketDesc d;
@@ -705,8 +759,13 @@ static int xt_launch_group(extrack_ctx* ctx, const extrack_model* m, const std::
     l.a.min_len = m->min_len;
     l.a.locerr_mode = m->locerr_mode;
     l.a.KS = b0.KS ? b0.KS : 1;
-    const bool ok = fast2 ? xt_dispatch_f2(c.F, D, K, l)
-                          : (entry ? xt_dispatch_entry(xt_entry_gp(c.G), D, K, l) : xt_dispatch(c.G, D, K, preds, l));
+    bool ok;
+    if (big) {
+        const void* kp = xt_big_kernel_dk(D, K, preds);
+        ok = kp != nullptr && l.launch_ptr(kp);
+    } else {
+        ok = fast2 ? xt_dispatch_f2(c.F, D, K, l) : (entry ? xt_dispatch_entry(xt_entry_gp(c.G), D, K, l) : xt_dispatch(c.G, D, K, preds, l));
+    }
     if (!ok)
         return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, preds ? "posteriors are built for n_states <= 6" : "kernel variant not built");
     if (l.herr != hipSuccess) return xt_fail(ctx, EXTRACK_E_HIP, std::string("kernel launch: ") + hipGetErrorString(l.herr));

@@ -347,6 +347,8 @@ struct extrack_ctx {
     int th_plan_bs = 0;         // plan kernel, > 64 sequences: pivot rows per batch = wavefronts x max(n, 1); < 0: one batch (EXTRACK_TH_PLAN_BS)
     // Frozen plan (extrack_th_freeze_plan): threshold-fusion evaluations skip the plan kernel and follow the plan the last planning
     // evaluation left in the buckets; per launch group (keyed by its first bucket and size) the sequence counts that size the apply / gradient launch
+    double* d_big_ws = nullptr;  // per-wavefront sequence state of the global-memory kernel for big models (xt_big.h)
+    size_t big_ws_cap = 0;       // doubles
     bool th_frozen = false;  // the per-bucket sequence counts that size the apply / gradient launch: XtBucket::th_maxG, th_sumE
     std::vector<double> blob_host;  // model tables of the current fixed-window evaluation (xt_prepare)
     bool th_plan_threads_forced = false;

@@ -33,7 +33,9 @@ static inline std::string xt_build_config(int S, int NS, int F, XtConfig& c)
     if (F <= NS) return "frame_len must be at least nb_substeps + 1";
     if (F > 15) return "frame_len too large";
     double e = pow((double)S, F);
-    if (e > 8192.0) return "n_states^frame_len exceeds the LDS-resident limit (8192 sequences): lower frame_len (the window), or use the threshold-fusion kernel (fusion='threshold'), whose live-sequence count adapts to the data";
+    // up to 8192 sequences the state of a track lives in LDS / registers; beyond that (5 states at frame_len 6, 2 states at frame_len 14, ...)
+    // in a per-wavefront region of global memory (xt_big.h), up to 2^20 sequences per track
+    if (e > 1048576.0) return "n_states^frame_len exceeds 2^20 sequences per track: lower frame_len (the window), or use the threshold-fusion kernel (fusion='threshold'), whose live-sequence count adapts to the data";
     c.S = S;
     c.NS = NS;
     c.F = F;

@@ -70,7 +70,11 @@ typedef struct extrack_ctx extrack_ctx;
 typedef struct extrack_model {
     int32_t n_states;    /* S, 2..8 */
     int32_t nb_substeps; /* ns, 1..4 */
-    int32_t frame_len;   /* F > ns, window of exactly enumerated states */
+    int32_t frame_len;   /* F > ns, window of exactly enumerated states; S^F <= 2^20 sequences per track.  Up to 1024 groups
+                            (S^(F-ns)) and 160 KB per track the state lives in LDS / registers; beyond that - 5 states at the reference's default
+                            frame_len 6, 6 states at frame_len 5 - 6, 2 states at frame_len 11 - 15, posteriors with 7 / 8 states - in global
+                            memory, one lane per track (csrc/xt_big.h: likelihood and posteriors; the gradient entry points answer
+                            EXTRACK_E_UNSUPPORTED there and the caller differences the objective) */
     int32_t min_len;     /* smallest track length of the WHOLE dataset (all shards); the stay-in-FOV term starts at step max(min_len, 2) */
     int32_t max_len;     /* largest track length of the WHOLE dataset: buckets of this length get isBL = 0 */
     int32_t locerr_mode; /* 0: global locerr[]; 1: per-peak sigma uploaded with the bucket;

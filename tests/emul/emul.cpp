@@ -24,6 +24,7 @@
 #include "../../extrack_amd/csrc/xt_tables.h"
 #include "../../extrack_amd/csrc/xt_th.h"
 #include "../../extrack_amd/csrc/xt_thgrad.h"
+#include "../../extrack_amd/csrc/xt_big.h"
 
 struct EmulLauncher {
     XtKernelArgs a;
@@ -146,7 +147,7 @@ extern "C" int xt_emul_run(const double* tracks, const double* sigma, long long 
     xt_fill_args_from_config(cfg, l.a);
     int tpb, threads;
     xt_geometry(cfg, D, K, tpb, threads);
-    if (threads > 1024) return -2;
+    const bool big = threads > 1024 || getenv("XT_EMUL_BIG") != nullptr;  // one lane per track, state in (emulated) global memory: xt_big.h
     std::vector<double> partials(nblocks, 0.0);
     l.a.tracks = tracks;
     l.a.sigma = locerr_mode ? sigma : nullptr;
@@ -196,7 +197,33 @@ extern "C" int xt_emul_run(const double* tracks, const double* sigma, long long 
     double* const seq_raw = g_seq_raw;
     g_seq_raw = nullptr;
     l.a.seq_out = seq_raw;
-    if (seq_raw) {
+    if (big && !seq_raw) {
+        const int NW = 2;
+        XtBigArgs ba;
+        ba.ws_stride = xt_big_ws_doubles(cfg.E, D, K);
+        std::vector<double> ws((size_t)ba.ws_stride * nblocks * NW, xt_emul_poison() ? NAN : 0.0);
+        ba.ws = ws.data();
+        const size_t ldsd = (size_t)((xt_tab_doubles(S, cfg.G) + 1) & ~1) + 64 * NW;
+        if (info) {
+            info[0] = 64 * NW;
+            info[1] = 64 * NW;
+            info[2] = (int)(ldsd * 8);
+        }
+#define XT_BIG_RUN(DD, KK)                                                                                                \
+    th_emul_blocks(nblocks, 64 * NW, ldsd, [&](HostCtx& cx) {                                                              \
+        if (preds) xt_big_body<DD, KK, true>(l.a, ba, cx);                                                                 \
+        else xt_big_body<DD, KK, false>(l.a, ba, cx);                                                                      \
+    })
+        if (D == 1 && K == 1) XT_BIG_RUN(1, 1);
+        else if (D == 2 && K == 1) XT_BIG_RUN(2, 1);
+        else if (D == 2 && K == 2) XT_BIG_RUN(2, 2);
+        else if (D == 3 && K == 1) XT_BIG_RUN(3, 1);
+        else if (D == 3 && K == 3) XT_BIG_RUN(3, 3);
+        else return -3;
+#undef XT_BIG_RUN
+    } else if (big) {
+        return -2;
+    } else if (seq_raw) {
         if (!xt_dispatch(cfg.G, D, K, preds != 0, l)) return -3;
     } else if (xt_use_reg2(S, NS, F) && !preds && getenv("XT_EMUL_REG2")) {
         XtGradArgs ga;

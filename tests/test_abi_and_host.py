@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert sorted(_lib.EXPORTS) == declared
-    assert lib.extrack_abi_version() == 5
+    assert lib.extrack_abi_version() == 6
 
 
 def test_no_silent_cpu_fallback():

@@ -235,3 +235,35 @@ def test_sequence_matrix_on_golden_cases(kernel_cases):
         if n >= 25:  # the GPU test (tests/test_hip_parity.py) runs all 670 reference matrices
             break
     assert n >= 25 and worst < 1e-9, (n, worst)
+
+
+@pytest.mark.parametrize("S,ns,F,L,N,D,K,isBL,preds", [(2, 1, 4, 9, 70, 2, 1, 1, False), (3, 1, 3, 8, 66, 2, 2, 0, True), (2, 2, 4, 7, 10, 1, 1, 1, False),
+                                                        (4, 1, 3, 6, 9, 3, 3, 1, True), (2, 1, 5, 2, 5, 2, 1, 1, True), (3, 1, 4, 3, 5, 2, 1, 0, True),
+                                                        (2, 1, 11, 14, 3, 2, 1, 1, False), (5, 1, 5, 7, 2, 2, 1, 1, True)])
+def test_emulated_global_state_body_for_big_models(S, ns, F, L, N, D, K, isBL, preds, monkeypatch):
+    """csrc/xt_big.h (one lane per track, sequence state in global memory: the models whose state does not fit a workgroup - here also forced
+    on small ones, XT_EMUL_BIG) on CPU threads against the pinned oracle: per-track LL 1e-10, posteriors 1e-9.  (2, 1, 11): 2048 groups per
+    track, (5, 1, 5): 3125 sequences - both refused by the LDS kernels."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "emul"))
+    import run_emul as E
+    from extrack_amd import synth
+    from oracle import oracle_np as O
+    monkeypatch.setenv("XT_EMUL_BIG", "1")
+    rng = np.random.default_rng(S * 100 + F)
+    Ds = np.sort(rng.uniform(0.01, 0.3, S))
+    Ds[0] = 0.001
+    T = np.full((S, S), 0.05) + rng.uniform(0, 0.03, (S, S))
+    T[np.arange(S), np.arange(S)] = 0
+    T[np.arange(S), np.arange(S)] = 1 - T.sum(1)
+    Fs = rng.dirichlet(np.ones(S) * 3)
+    Cs = synth.brownian_tracks(N, L, Ds, T, Fs, seed=S + F + L, dims=D)
+    ds, cell, pBL, min_len = np.sqrt(2 * Ds * 0.02), [1.0], 0.1, 3
+    le = np.array([0.02, 0.025, 0.03][:K])[None, None]
+    ll, pr, tot, info = E.run(Cs, le, ds, Fs, T, pBL, isBL, O.p_stay_table(ds, S, ns, cell), ns, F, min_len, preds=preds, nblocks=2)
+    ref = O.proba_cs(Cs, le, ds, Fs, T, pBL, isBL, cell, ns, F, min_len)
+    assert np.abs(ll - ref).max() < 1e-10 and abs(tot - ref.sum()) < 1e-12 * abs(tot)
+    if preds:
+        refp = O.p_cs_inter_bound_stats(Cs, le, ds, Fs, T, pBL, isBL, cell, ns, F, 1, min_len)[1]
+        assert np.abs(pr - refp).max() < 1e-9

@@ -23,7 +23,7 @@ def _params(vals):
 def test_library_loaded_and_device():
     from extrack_amd import _lib
     ctx = _lib.Context(0)
-    assert ctx._lib.extrack_abi_version() == 5
+    assert ctx._lib.extrack_abi_version() == 6
     ctx.close()
 
 
@@ -179,10 +179,14 @@ def test_c1_param_fitting_recovers_simulated_parameters(capsys):
 
 
 @pytest.mark.parametrize("S,ns,F,L,N", [(2, 1, 6, 30, 5000), (3, 1, 6, 17, 600), (4, 1, 5, 20, 200), (4, 3, 4, 12, 24), (2, 2, 6, 40, 500),
-                                         (3, 1, 4, 50, 700), (2, 1, 9, 25, 300), (4, 1, 6, 14, 40)])
+                                         (3, 1, 4, 50, 700), (2, 1, 9, 25, 300), (4, 1, 6, 14, 40),
+                                         (5, 1, 6, 8, 8), (6, 1, 5, 7, 6), (2, 1, 12, 16, 70), (7, 1, 3, 8, 12), (8, 1, 3, 6, 9), (3, 2, 7, 9, 5)])
 def test_seeded_vs_oracle(S, ns, F, L, N):
     """Seeded synthetic batches at sizes the numpy oracle finishes in seconds (incl. multi-wave tracks:
-    S=3,F=6 -> 243 groups; S=4,F=6 -> 1024 groups; S=2,F=9 -> 256 groups)."""
+    S=3,F=6 -> 243 groups; S=4,F=6 -> 1024 groups; S=2,F=9 -> 256 groups).  Round 4: the models the LDS kernels refuse - 5 states at the
+    reference's default frame_len 6 (15 625 sequences per track), 6 states at frame_len 5, 2 states at frame_len 12 (2048 groups), posteriors
+    with 7 / 8 states, 3 states with 2 substeps at frame_len 7 - run through the global-state kernel (csrc/xt_big.h), likelihood and
+    posteriors (reference: extrack/tracking.py:109-318, which has no size limit)."""
     from extrack_amd import synth, tracking as T
     from oracle import oracle_np as O
     rng = np.random.default_rng(S * 100 + F)
@@ -202,6 +206,26 @@ def test_seeded_vs_oracle(S, ns, F, L, N):
         _, _, preds = T.P_Cs_inter_bound_stats(Cs[:100], LE, ds, Fs, TT, 0.1, 0, [1.0], 1, F, 1, 3)
         _, pref = O.p_cs_inter_bound_stats(Cs[:100], LE, ds, Fs, TT, 0.1, 0, [1.0], 1, F, 1, 3)
         assert np.abs(preds - pref).max() < TOL_PRED
+
+
+def test_global_state_kernel_forced_on_ordinary_models(monkeypatch):
+    """csrc/xt_big.h forced (EXTRACK_FORCE_BIG=1) on models the LDS kernels serve: same per-track LL (1e-10) and posteriors (1e-9) as those
+    kernels' oracle, several wavefronts and a ragged last batch, two length buckets in one launch."""
+    from extrack_amd import synth, tracking as T
+    from oracle import oracle_np as O
+    monkeypatch.setenv("EXTRACK_FORCE_BIG", "1")
+    vals = dict(D0=1e-3, D1=0.05, D2=0.3, LocErr=0.02, F0=0.3, F1=0.3, F2=0.4, p01=0.08, p02=0.04, p10=0.06, p12=0.05, p20=0.03, p21=0.07, pBL=0.1)
+    Tm = np.array([[0.9, 0.07, 0.03], [0.05, 0.9, 0.05], [0.03, 0.07, 0.9]])
+    tracks = {"9": synth.brownian_tracks(333, 9, [0.0, 0.05, 0.3], Tm, [0.3, 0.3, 0.4], seed=1),
+              "14": synth.brownian_tracks(150, 14, [0.0, 0.05, 0.3], Tm, [0.3, 0.3, 0.4], seed=2)}
+    p = _params(vals)
+    _, lst, _ = T.engine.sort_buckets(tracks)
+    got = T.cum_Proba_Cs(p, lst, 0.02, [1], None, 3, 1, 4, verbose=0)
+    ref = O.cum_proba_cs(vals, tracks, 0.02, [1], None, 1, 4)
+    assert abs(got - ref) < 1e-12 * abs(ref), (got, ref)
+    pr = T.predict_Bs(tracks, 0.02, p, cell_dims=[1], nb_states=3, frame_len=4)
+    pro = O.predict_bs(vals, tracks, 0.02, [1], 4)
+    assert max(np.abs(pr[k] - pro[k]).max() for k in tracks) < 1e-9
 
 
 def test_full_size_properties():
