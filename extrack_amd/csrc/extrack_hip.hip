@@ -1858,7 +1858,8 @@ struct XtRefineArgs {
     double* sig_out;       // [N][L]
     int64_t N;             // rows of this launch (the records are [L - 1][cap][2 + D][N]: a wavefront reads 64 neighbouring tracks' values of a field)
     int32_t L, S, cap_f, cap_p;  // sequences recorded per (entry, track) by the two passes
-    double l2;             // squared localisation error
+    double l2;             // squared localisation error (global), or
+    const double* sigma;   // per-peak localisation errors [N][L] of these rows (nullptr: the global one)
     double logF[XT_MAX_STATES];
 };
 
@@ -1876,6 +1877,11 @@ __global__ void __launch_bounds__(256) xt_refine_combine(XtRefineArgs a)
     const int L = a.L, R = 2 + D;
     double c[D];
     for (int d = 0; d < D; ++d) c[d] = a.tracks[(x * L + k) * D + d];
+    // this position's own localisation variance (get_pos_PDF, refined_localization.py:222, 271, 289).  Per-peak errors: the in-place update
+    // of the last record inside get_LC_Km_Ks (:186-193) takes the error of index len - 1 of the array it was given - for position 0 (pass
+    // over the unreversed array) that is the LAST position's error, reproduced as it is; for position len - 1 it is its own
+    const double l2k = a.sigma ? a.sigma[x * L + k] * a.sigma[x * L + k] : a.l2;
+    const double l2q = a.sigma ? a.sigma[x * L + (L - 1)] * a.sigma[x * L + (L - 1)] : a.l2;
     double wmax = -INFINITY, sw = 0.0, smu[D], ssg = 0.0;
     for (int d = 0; d < D; ++d) smu[d] = 0.0;
     auto add = [&](double w, const double* mu, double var) {
@@ -1902,15 +1908,16 @@ __global__ void __launch_bounds__(256) xt_refine_combine(XtRefineArgs a)
         const int n = (k == 0 ? a.fut_cnt : a.past_cnt)[L - 2];
         for (int q = 0; q < n; ++q) {
             const double* r = rec + (int64_t)q * R * a.N;
-            const double lp = r[0], sd = r[(int64_t)(1 + D) * a.N], v = sd * sd + a.l2;
+            const double lp = r[0], sd = r[(int64_t)(1 + D) * a.N], v = sd * sd + l2k, vq = sd * sd + l2q;
             double dsq = 0.0, mu[D];
             for (int d = 0; d < D; ++d) {
                 const double m = r[(int64_t)(1 + d) * a.N];
                 dsq += (c[d] - m) * (c[d] - m);
-                mu[d] = (m * a.l2 + c[d] * sd * sd) / v;
+                mu[d] = (m * l2k + c[d] * sd * sd) / v;
             }
-            const double lk = -0.5 * D * log(2.0 * M_PI * v) - dsq / (2.0 * v);
-            add(lp + 2.0 * lk + (k == 0 ? a.logF[nw[q]] : 0.0), mu, a.l2 * sd * sd / v);
+            const double lk = -0.5 * D * log(2.0 * M_PI * v) - dsq / (2.0 * v);       // get_pos_PDF's overlap term
+            const double lkq = -0.5 * D * log(2.0 * M_PI * vq) - dsq / (2.0 * vq);    // the in-place update of the last record
+            add(lp + lk + lkq + (k == 0 ? a.logF[nw[q]] : 0.0), mu, l2k * sd * sd / v);
         }
     } else {
         const double* rf = a.fut + ((int64_t)(L - 2 - k) * a.cap_f * R) * a.N + x;
@@ -1921,11 +1928,11 @@ __global__ void __launch_bounds__(256) xt_refine_combine(XtRefineArgs a)
         for (int q1 = 0; q1 < n1; ++q1) {
             const double* r1 = rf + (int64_t)q1 * R * a.N;
             const double lp1 = r1[0], s1 = r1[(int64_t)(1 + D) * a.N];
-            const double v12 = s1 * s1 + a.l2, vA = s1 * s1 * a.l2 / v12;
+            const double v12 = s1 * s1 + l2k, vA = s1 * s1 * l2k / v12;
             double muA[D], d1 = 0.0;
             for (int d = 0; d < D; ++d) {
                 const double m1 = r1[(int64_t)(1 + d) * a.N];
-                muA[d] = (m1 * a.l2 + c[d] * s1 * s1) / v12;
+                muA[d] = (m1 * l2k + c[d] * s1 * s1) / v12;
                 d1 += (m1 - c[d]) * (m1 - c[d]);
             }
             const double lk1 = -0.5 * D * log(2.0 * M_PI * v12) - d1 / (2.0 * v12);
@@ -1975,7 +1982,7 @@ enum { XT_RF_REV = 0, XT_RF_REC0, XT_RF_REC1, XT_RF_NEW0, XT_RF_NEW1, XT_RF_CNT0
 
 // One launch of the recording kernel over bucket `d_tracks` ([N][L][D] on the device).  rows == 0: capacity probe on the pilot tracks
 // (nothing recorded; *cap_out = sequences to record per entry); else: the tracks [row0, row0 + rows) are recorded into a.rf_out.
-static int xt_refine_launch(extrack_ctx* ctx, const extrack_model* m, const double* d_tracks, int64_t N, int L, int D, double threshold,
+static int xt_refine_launch(extrack_ctx* ctx, const extrack_model* m, const double* d_tracks, const double* d_sigma, int64_t N, int L, int D, double threshold,
                             int32_t max_nb_states, int64_t row0, int64_t rows, int rf_cap, double* d_rec, uint8_t* d_new, int32_t* d_cnt, int* cap_out)
 {
     const int S = m->n_states, F = m->frame_len, G = S;
@@ -1990,7 +1997,8 @@ static int xt_refine_launch(extrack_ctx* ctx, const extrack_model* m, const doub
     a.F = F;
     a.isBL = 0;
     a.min_len = L + 2;  // no field-of-view / bleaching factors in the recorded weights
-    a.locerr_mode = 0;
+    a.sigma = d_sigma;  // per-peak errors [N][L][1], read at the SAME index as the position of d_tracks (see extrack_refine_positions)
+    a.locerr_mode = d_sigma ? 1 : 0;
     a.KS = 1;
     a.max_nb = max_nb_states;
     a.threshold = threshold;
@@ -2066,13 +2074,20 @@ extern "C" int extrack_refine_positions(extrack_ctx* ctx, const extrack_model* m
     if (rc) return rc;
     if (bucket_id < 0 || bucket_id >= (int)ctx->buckets.size()) return xt_fail(ctx, EXTRACK_E_INVALID, "bucket id out of range");
     if (m->nb_substeps != 1) return xt_fail(ctx, EXTRACK_E_INVALID, "position refinement is defined for nb_substeps == 1");
-    if (m->locerr_mode != 0 || m->locerr_dims != 1)
-        return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "position refinement is built for one global localisation error (as the reference's reshapes assume)");
+    if (m->locerr_mode == 2 || (m->locerr_mode == 0 && m->locerr_dims != 1))
+        return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "position refinement takes one global localisation error or per-peak errors [n][len][1] (what the reference's reshapes carry through)");
     if (!(threshold >= 0.0)) return xt_fail(ctx, EXTRACK_E_INVALID, "threshold must be >= 0");
     if (m->frame_len <= 1 || m->frame_len > 15) return xt_fail(ctx, EXTRACK_E_INVALID, "frame_len must be in (1, 15]");
     XtBucket& b = ctx->buckets[bucket_id];
     const int S = m->n_states, L = b.L, D = b.D, R = 2 + D;
     if (L < 2) return xt_fail(ctx, EXTRACK_E_INVALID, "position refinement needs tracks of at least 2 positions");
+    if (m->locerr_mode == 1 && (!b.d_sigma || b.KS != 1))
+        return xt_fail(ctx, EXTRACK_E_INVALID, "position refinement with per-peak errors needs the bucket's sigma [n][len][1]");
+    // Per-peak errors (refined_localization.py:59-70): get_LC_Km_Ks reverses the error array but walks an UNREVERSED track from its end, so the
+    // k-th position it injects meets the error of index k counted from the START of the array it was given - the same array in both passes
+    // (:211, :216).  Here both passes walk their track from index 0, the pass "from the future" on the time-reversed copy: handing BOTH the
+    // bucket's sigma as it is reproduces exactly that pairing (mirrored errors in the pass from the future, the right ones from the past).
+    const double* d_sig_in = m->locerr_mode == 1 ? b.d_sigma : nullptr;
     XT_HIP(ctx, hipSetDevice(ctx->device));
     const size_t nel = (size_t)b.N * L * D;
     // time-reversed copy of the bucket for the pass "from the future", made on the device
@@ -2100,7 +2115,7 @@ extern "C" int extrack_refine_positions(extrack_ctx* ctx, const extrack_model* m
     int cap[2] = {0, 0};
     for (int pass = 0; pass < 2; ++pass) {
         if ((rc = xt_upload_blob(ctx, blobs[pass]))) return rc;
-        if ((rc = xt_refine_launch(ctx, m, src[pass], b.N, L, D, threshold, max_nb_states, 0, 0, 0, nullptr, nullptr, nullptr, &cap[pass]))) return rc;
+        if ((rc = xt_refine_launch(ctx, m, src[pass], d_sig_in, b.N, L, D, threshold, max_nb_states, 0, 0, 0, nullptr, nullptr, nullptr, &cap[pass]))) return rc;
     }
     // row blocks: both passes' records of a block stay within the memory budget (EXTRACK_REFINE_BUDGET_MB, default 16 GiB of the 288 GB);
     // the merge plan only depends on the pilot tracks, which every launch re-walks, so the blocks are independent
@@ -2126,7 +2141,7 @@ extern "C" int extrack_refine_positions(extrack_ctx* ctx, const extrack_model* m
         const int64_t rows = std::min<int64_t>(RB, b.N - row0);
         for (int pass = 0; pass < 2; ++pass) {
             if ((rc = xt_upload_blob(ctx, blobs[pass]))) return rc;
-            if ((rc = xt_refine_launch(ctx, m, src[pass], b.N, L, D, threshold, max_nb_states, row0, rows, cap[pass], (double*)ctx->rf_buf[XT_RF_REC0 + pass],
+            if ((rc = xt_refine_launch(ctx, m, src[pass], d_sig_in, b.N, L, D, threshold, max_nb_states, row0, rows, cap[pass], (double*)ctx->rf_buf[XT_RF_REC0 + pass],
                                        (uint8_t*)ctx->rf_buf[XT_RF_NEW0 + pass], (int32_t*)ctx->rf_buf[XT_RF_CNT0 + pass], nullptr)))
                 return rc;
         }
@@ -2147,6 +2162,7 @@ extern "C" int extrack_refine_positions(extrack_ctx* ctx, const extrack_model* m
         ra.cap_f = cap[0];
         ra.cap_p = cap[1];
         ra.l2 = m->locerr[0] * m->locerr[0];
+        ra.sigma = d_sig_in ? d_sig_in + (size_t)row0 * L : nullptr;
         for (int s2 = 0; s2 < S; ++s2) ra.logF[s2] = log(m->Fs[s2]);
         const int grid = (int)(((int64_t)rows * L + 255) / 256);
         if (D == 1) hipLaunchKernelGGL(xt_refine_combine<1>, dim3(grid), dim3(256), 0, ctx->stream, ra);

@@ -2,10 +2,12 @@
 
 Same name, arguments and result as the reference; the two threshold-fusion passes (get_LC_Km_Ks, :48-204) and the combination of the
 predictions from the future and from the past (get_pos_PDF, :207-298) run in HIP kernels through ``extrack_refine_positions`` of the
-C ABI.  Built for what the reference's own array reshapes support: ONE global localisation error (a float or a 1-element array) and
-nb_substeps = 1; per-peak error dicts are refused (the reference pairs them with the wrong positions in its time-reversed pass,
-refined_localization.py:69-70).  Like the reference, every length bucket is processed as one chunk: its first 30 tracks decide
-which state sequences are merged."""
+C ABI.  Built for what the reference's own array reshapes carry through: ONE global localisation error (a float or a 1-element array)
+or a dict of per-peak errors ``{len: sigma[n_tracks, len, 1]}``, nb_substeps = 1.  Per-peak errors are used exactly as the reference uses
+them - it reverses the error array but not the track in get_LC_Km_Ks (refined_localization.py:64-65 vs :115), so its pass "from the
+future" pairs every position with its mirror image's error; that pairing is reproduced (oracle/oracle_refine.py, pinned to 50
+reference-generated buckets), per-dimension errors and ``[n, len, dims]`` dicts are refused as the reference's reshapes refuse them.
+Like the reference, every length bucket is processed as one chunk: its first 30 tracks decide which state sequences are merged."""
 import numpy as np
 
 from .engine import TrackSet
@@ -17,13 +19,13 @@ def position_refinement(all_tracks, LocErr, ds, Fs, TrMat, frame_len=7, threshol
     """all_tracks: {str(len): ndarray[n_tracks, len, dims]}; LocErr: localisation error (std); ds: diffusion lengths sqrt(2 D dt);
     Fs: initial fractions; TrMat: per-step transition probabilities.  Returns ({len: refined positions [n, len, dims]},
     {len: refined stds [n, len]})."""
-    if isinstance(LocErr, dict):
-        raise NotImplementedError("position refinement is built for one global localisation error (float), not per-peak error dicts")
-    le = np.atleast_1d(np.asarray(LocErr, dtype=np.float64)).ravel()
-    if len(le) != 1:
-        raise NotImplementedError("position refinement is built for one global localisation error (the reference's reshapes assume it, "
-                                  "extrack/refined_localization.py:276)")
-    print("LocErr_type", "array")
+    per_peak = isinstance(LocErr, dict)
+    if not per_peak:
+        le = np.atleast_1d(np.asarray(LocErr, dtype=np.float64)).ravel()
+        if len(le) != 1:
+            raise ValueError("position refinement takes one global localisation error (float) or a dict of per-peak errors "
+                             "{len: [n_tracks, len, 1]} (the reference's reshapes assume it, extrack/refined_localization.py:276)")
+    print("LocErr_type", "dict" if per_peak else "array")
     ds, Fs, TrMat = np.asarray(ds, float), np.asarray(Fs, float), np.asarray(TrMat, float)
     S = len(ds)
     all_mus, all_sigmas = {}, {}
@@ -34,9 +36,14 @@ def position_refinement(all_tracks, LocErr, ds, Fs, TrMat, frame_len=7, threshol
         if len(Cs) == 0:
             all_mus[l], all_sigmas[l] = np.zeros((0, int(l), Cs.shape[2])), np.zeros((0, int(l)))
             continue
-        ts = TrackSet([Cs], device=device)
+        sig = None
+        if per_peak:
+            sig = np.asarray(LocErr[l], dtype=np.float64)
+            if sig.shape != (Cs.shape[0], Cs.shape[1], 1):
+                raise ValueError("per-peak localisation errors must be arrays [n_tracks, len, 1] matching all_tracks[%r]" % l)
+        ts = TrackSet([Cs], [sig] if per_peak else None, device=device)
         try:
-            model = ts.make_model(le[None, None], ds, Fs, TrMat, 0.0, [], 1, frame_len)
+            model = ts.make_model(None if per_peak else le[None, None], ds, Fs, TrMat, 0.0, [], 1, frame_len)
             all_mus[l], all_sigmas[l] = ts.ctx.refine_positions(model, 0, threshold, max_nb_states)
         finally:
             ts.close()

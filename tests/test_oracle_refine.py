@@ -22,3 +22,21 @@ def test_position_refinement_matches_reference():
         worst_sig = max(worst_sig, np.abs(sigs[str(row["L"])] - g("sig")).max())
     assert worst_mu < 1e-10 and worst_sig < 1e-10, (worst_mu, worst_sig)
     print("refine cases", len(meta), "worst |d mu|", worst_mu, "worst |d sigma|", worst_sig)
+
+
+def test_position_refinement_per_peak_errors_matches_reference():
+    """Per-peak localisation errors {len: sigma[N, len, 1]} as the reference computes them, its pairing of errors and positions in the pass
+    "from the future" included (oracle_refine's docstring): 50 reference-generated buckets (2 - 16 positions, 1 - 45 tracks, 1 - 3 dims)."""
+    from oracle import oracle_refine as OR
+    meta = json.load(open(os.path.join(GOLDEN, "refine_pp_cases.json")))
+    data = np.load(os.path.join(GOLDEN, "refine_pp_cases.npz"))
+    worst_mu = worst_sig = 0.0
+    for row in meta:
+        pre = "p%04d_" % row["id"]
+        g = lambda k: data[pre + k]
+        key = str(row["L"])
+        mus, sigs = OR.position_refinement({key: g("Cs")}, {key: g("sigma")}, g("ds"), g("Fs"), g("T"), row["F"], row["threshold"], row["max_nb_states"])
+        worst_mu = max(worst_mu, np.abs(mus[key] - g("mu")).max())
+        worst_sig = max(worst_sig, np.abs(sigs[key] - g("sig")).max())
+    assert len(meta) == 50 and worst_mu < 1e-10 and worst_sig < 1e-10, (worst_mu, worst_sig)
+    print("per-peak refine cases", len(meta), "worst |d mu|", worst_mu, "worst |d sigma|", worst_sig)
