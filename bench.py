@@ -147,7 +147,7 @@ def _flop_model(lengths_counts, S, F, ns, D):
     return float(sum(n * max(L - 2, 0) for L, n in lengths_counts)) * (S ** F) * per_entry
 
 
-def other_configs(device, no_cpu_baseline=False):
+def other_configs(device, no_cpu_baseline=False, no_fits=False):
     """configs[2] and configs[4] on the same GPU (N = 1 only, outside the timed region): ms per evaluation / tracks per second with
     the HIP-event kernel time, algorithmic bytes (one read of the tracks; posteriors add their output) and the flop model."""
     import torch
@@ -219,8 +219,12 @@ def other_configs(device, no_cpu_baseline=False):
     model = tracking._objective_model(P(vals), ts, DT, CELL, None, 3, 1, 6, 1)
     # two untimed evaluations: the first learns the sequence counts (LDS sizing), the second allocates the second stream's launch buffers
     wall, kms, v = timed(lambda: ts.loglik_th(model, 0.2, 120, 2000), 5, warm=2)
+    ts.th_freeze_plan(True)
+    wallz, kmsz, vz = timed(lambda: ts.loglik_th(model, 0.2, 120, 2000), 5, warm=1)
+    ts.th_freeze_plan(False)
     out["c3_loglik_threshold"] = {"what": "configs[2] through the threshold-fusion kernels (v1.6.3 defaults, frame_len 6)", "ms_per_eval": wall * 1e3,
-                                  "kernel_ms": kms, "algorithmic_bytes": nbytes, "hbm_gbs": nbytes / (kms * 1e-3) / 1e9, "neg_loglik": -v}
+                                  "kernel_ms": kms, "algorithmic_bytes": nbytes, "hbm_gbs": nbytes / (kms * 1e-3) / 1e9, "neg_loglik": -v,
+                                  "frozen_plan_ms_per_eval": wallz * 1e3, "frozen_plan_kernel_ms": kmsz, "frozen_plan_same_value": bool(vz == v)}
     # ... and its exact gradient at the frozen plan (extrack_loglik_th_grad, round 4): what an optimiser iteration of the v1.6.3 objective costs
     for _ in range(2):
         gv, gg = gradient.objective_and_gradient(pg, ts, DT, CELL, 3, 1, 6, names=names, threshold_fusion=(0.2, 120, 2000))
@@ -238,7 +242,7 @@ def other_configs(device, no_cpu_baseline=False):
     p0 = tracking.generate_params(nb_states=3, LocErr_type=1, LocErr_bounds=[0.005, 0.1], D_max=3, estimated_Ds=[0.0001, 0.02, 0.4],
                                   estimated_Fs=[0.3, 0.3], estimated_transition_rates=0.1)
     fits3 = {}
-    for grad in (None, "fd"):
+    for grad in (() if no_fits else (None, "fd")):
         with contextlib.redirect_stdout(io.StringIO()):
             t0 = time.perf_counter()
             r = tracking.param_fitting(tracks, DT, params=p0, nb_states=3, frame_len=6, cell_dims=CELL, verbose=0, device=device, gradient=grad)
@@ -246,15 +250,16 @@ def other_configs(device, no_cpu_baseline=False):
         fits3["default" if grad is None else grad] = {"seconds": t_fit, "objective_calls": int(r.nfev), "gradient_calls": int(getattr(r, "ngev", 0)),
                                                        "neg_loglik": float(r.residual[0]),
                                                        "fitted": {k: float(r.params[k].value) for k in ("D1", "D2", "LocErr", "F0", "F1")}}
-    out["c3_full_fit_F6"] = {"what": "configs[2]: param_fitting on 1e6 tracks, 3 states, 46 buckets, frame_len 6, BFGS from a generic start (incl. the upload); "
-                                     "'default' = gradient=None (timing probe -> reverse-mode gradient), 'fd' = finite differences like the reference",
-                             "seconds": fits3["default"]["seconds"], "objective_calls": fits3["default"]["objective_calls"],
-                             "gradient_calls": fits3["default"]["gradient_calls"], "neg_loglik": fits3["default"]["neg_loglik"], "fit": fits3,
-                             "simulated": {"D1": 0.04, "D2": 0.25, "LocErr": LOCERR, "F0": 0.3, "F1": 0.3}}
+    if fits3:
+        out["c3_full_fit_F6"] = {"what": "configs[2]: param_fitting on 1e6 tracks, 3 states, 46 buckets, frame_len 6, BFGS from a generic start (incl. the upload); "
+                                         "'default' = gradient=None (timing probe -> reverse-mode gradient), 'fd' = finite differences like the reference",
+                                 "seconds": fits3["default"]["seconds"], "objective_calls": fits3["default"]["objective_calls"],
+                                 "gradient_calls": fits3["default"]["gradient_calls"], "neg_loglik": fits3["default"]["neg_loglik"], "fit": fits3,
+                                 "simulated": {"D1": 0.04, "D2": 0.25, "LocErr": LOCERR, "F0": 0.3, "F1": 0.3}}
     # the same fit of the objective extrack.tracking.param_fitting minimises in v1.6.3 (threshold fusion): default = the frozen-plan driver
     # (plan, minimise at that plan with the exact gradient, re-plan), fd = the reference's finite-difference BFGS
     fits3t = {}
-    for grad in (None, "fd"):
+    for grad in (() if no_fits else (None, "fd")):
         with contextlib.redirect_stdout(io.StringIO()):
             t0 = time.perf_counter()
             r = tracking.param_fitting(tracks, DT, params=p0, nb_states=3, frame_len=6, cell_dims=CELL, verbose=0, device=device, gradient=grad, fusion="threshold")
@@ -263,24 +268,26 @@ def other_configs(device, no_cpu_baseline=False):
                                                         "neg_loglik": float(r.residual[0]), "gradient_path": getattr(r, "gradient_path", None),
                                                         "gradient_why": getattr(r, "gradient_why", None), "plan_rounds": int(getattr(r, "plan_rounds", 0)),
                                                         "fitted": {k: float(r.params[k].value) for k in ("D1", "D2", "LocErr", "F0", "F1")}}
-    out["c3_full_fit_threshold"] = {"what": "configs[2] with fusion='threshold' (v1.6.3's objective): param_fitting on 1e6 tracks, 3 states, 46 buckets, frame_len 6 from the "
-                                            "same generic start; 'default' = gradient=None (probe -> frozen-plan gradient, plan / minimise / re-plan rounds), 'fd' = finite "
-                                            "differences of the re-planning objective like the reference",
-                                    "seconds": fits3t["default"]["seconds"], "objective_calls": fits3t["default"]["objective_calls"],
-                                    "gradient_calls": fits3t["default"]["gradient_calls"], "neg_loglik": fits3t["default"]["neg_loglik"], "fit": fits3t}
+    if fits3t:
+        out["c3_full_fit_threshold"] = {"what": "configs[2] with fusion='threshold' (v1.6.3's objective): param_fitting on 1e6 tracks, 3 states, 46 buckets, frame_len 6 from "
+                                                "the same generic start; 'default' = gradient=None (probe -> frozen-plan gradient, plan / minimise / re-plan rounds), 'fd' = "
+                                                "finite differences of the re-planning objective like the reference",
+                                        "seconds": fits3t["default"]["seconds"], "objective_calls": fits3t["default"]["objective_calls"],
+                                        "gradient_calls": fits3t["default"]["gradient_calls"], "neg_loglik": fits3t["default"]["neg_loglik"], "fit": fits3t}
     del tracks
     # the same for the headline dataset (configs[1]: 1e6 x 30, 2 states, 7 free parameters): analytic gradient vs finite differences
     c2 = {str(LEN): synth.brownian_tracks(N_TRACKS, LEN, DS_COEF, TRMAT, FS, LOCERR, DT, DIMS, seed=0)}
     p2 = tracking.generate_params(nb_states=2, LocErr_type=1, LocErr_bounds=[0.005, 0.1], D_max=3, estimated_Ds=[0.0001, 0.1], estimated_Fs=[0.5],
                                   estimated_transition_rates=0.05)
     fits2 = {}
-    for grad in (None, "fd"):
+    for grad in (() if no_fits else (None, "fd")):
         with contextlib.redirect_stdout(io.StringIO()):
             t0 = time.perf_counter()
             r = tracking.param_fitting(c2, DT, params=p2, nb_states=2, frame_len=6, cell_dims=CELL, verbose=0, device=device, gradient=grad)
             fits2["default" if grad is None else grad] = {"seconds": time.perf_counter() - t0, "objective_calls": int(r.nfev),
                                                            "gradient_calls": int(getattr(r, "ngev", 0)), "neg_loglik": float(r.residual[0])}
-    out["c2_full_fit_F6"] = {"what": "configs[1] data: param_fitting on 1e6 x 30, 2 states, frame_len 6 from a generic start; 'default' = gradient=None "
+    if fits2:
+        out["c2_full_fit_F6"] = {"what": "configs[1] data: param_fitting on 1e6 x 30, 2 states, frame_len 6 from a generic start; 'default' = gradient=None "
                                      "(timing probe -> one-pass analytic gradient, tangents in registers), 'fd' = finite differences like the reference", "fit": fits2}
     del c2
     # ---- configs[4]: 5e5 tracks x 60, 4 states, nb_substeps 3 (frame_len 4) + predict_Bs (nb_substeps 1, frame_len 5)
@@ -329,6 +336,33 @@ def other_configs(device, no_cpu_baseline=False):
         out["c5_loglik_ns3_F4"]["cpu_port_c"] = {"tracks_per_s": len(smp) / dtc, "cores": cores, "sample": "%d tracks" % len(smp)}
     except Exception as e:
         out["c5_loglik_ns3_F4"]["cpu_port_c"] = {"error": str(e)}
+    # ---- models the LDS kernels used to refuse (round 4, csrc/xt_big.h: one lane per track, sequence state in global memory)
+    try:
+        big = {}
+        for S_, F_, nb_, Lb in ((5, 6, 20000, 20), (2, 12, 100000, 30)):
+            Tmb = np.full((S_, S_), 0.05 / (S_ - 1))
+            Tmb[np.arange(S_), np.arange(S_)] = 0.95
+            Dsb = list(np.linspace(0.0, 0.5, S_))
+            Csb = synth.brownian_tracks(nb_, Lb, Dsb, Tmb, [1.0 / S_] * S_, seed=50 + S_)
+            vb = dict(LocErr=0.02, pBL=0.1)
+            for i in range(S_):
+                vb["D%d" % i], vb["F%d" % i] = max(Dsb[i], 1e-4), 1.0 / S_
+                for j in range(S_):
+                    if i != j:
+                        vb["p%d%d" % (i, j)] = 0.05 / (S_ - 1)
+            ts = tracking.TrackSet([Csb], device=device)
+            mb = tracking._objective_model(P(vb), ts, DT, CELL, None, S_, 1, F_, 1)
+            wall, kms, v = timed(lambda: ts.loglik(mb), 2)
+            big["%d_states_F%d" % (S_, F_)] = {"tracks": nb_, "len": Lb, "sequences_per_track": S_ ** F_, "ms_per_eval": wall * 1e3, "kernel_ms": kms,
+                                               "tracks_per_s": nb_ / (kms * 1e-3), "state_bytes_streamed_per_eval": 2.0 * nb_ * (Lb - 2) * (S_ ** F_) * 36,
+                                               "neg_loglik": -v, "launch": ts.ctx.last_launch_info()}
+            ts.close()
+            del Csb
+        out["big_models_global_state"] = dict(big, what="fixed-window likelihood of models whose sequence state does not fit a workgroup (5 states at the reference's "
+                                              "default frame_len 6: 15 625 sequences per track; 2 states at frame_len 12: 2 048 groups): refused until round 3, now one "
+                                              "lane per track with the state streamed through global memory")
+    except Exception as e:  # noqa: BLE001
+        out["big_models_global_state"] = {"error": str(e)}
     # ---- configs[0]-size dataset (a real experiment: ~7 000 tracks in 16 length buckets): one evaluation of both objectives and a whole fit
     Ds2, Tm2, Fs2 = [0.0, 0.25], [[0.9, 0.1], [0.1, 0.9]], [0.6, 0.4]
     sizes = synth.bucket_sizes_geometric(6730, list(range(5, 21)), 0.85)
@@ -339,16 +373,19 @@ def other_configs(device, no_cpu_baseline=False):
     model = tracking._objective_model(P(v2), ts, DT, CELL, None, 2, 1, 6, 1)
     w_win, k_win, _ = timed(lambda: ts.loglik(model), 50, warm=2)
     w_th, k_th, _ = timed(lambda: ts.loglik_th(model, 0.2, 120, 2000), 50, warm=2)
+    ts.th_freeze_plan(True)
+    w_thz, k_thz, _ = timed(lambda: ts.loglik_th(model, 0.2, 120, 2000), 50, warm=2)
+    ts.th_freeze_plan(False)
     ts.close()
     fits = {}
-    for grad in ("analytic", "fd", None):
+    for grad in (() if no_fits else ("analytic", "fd", None)):
         with contextlib.redirect_stdout(io.StringIO()):
             t0 = time.perf_counter()
             r = tracking.param_fitting(small, DT, nb_states=2, frame_len=6, cell_dims=CELL, verbose=0, gradient=grad, device=device)
             fits["default" if grad is None else grad] = {"seconds": time.perf_counter() - t0, "objective_calls": int(r.nfev),
                                                           "gradient_calls": int(getattr(r, "ngev", 0)), "neg_loglik": float(r.residual[0])}
     fits_th = {}
-    for grad in ("analytic", "fd"):
+    for grad in (() if no_fits else ("analytic", "fd")):
         with contextlib.redirect_stdout(io.StringIO()):
             t0 = time.perf_counter()
             r = tracking.param_fitting(small, DT, nb_states=2, frame_len=6, cell_dims=CELL, verbose=0, gradient=grad, device=device, fusion="threshold")
@@ -357,7 +394,8 @@ def other_configs(device, no_cpu_baseline=False):
     out["c1_like_small_dataset"] = {"what": "6 730 tracks in 16 length buckets (5-20 positions), 2 states, frame_len 6: one evaluation, and param_fitting from the "
                                             "default start with the exact gradient / with finite differences",
                                     "window_ms_per_eval": w_win * 1e3, "window_kernel_ms": k_win, "threshold_ms_per_eval": w_th * 1e3,
-                                    "threshold_kernels_ms": k_th, "fit": fits, "fit_threshold_fusion": fits_th}
+                                    "threshold_kernels_ms": k_th, "threshold_frozen_plan_ms_per_eval": w_thz * 1e3, "threshold_frozen_plan_kernel_ms": k_thz,
+                                    "fit": fits, "fit_threshold_fusion": fits_th}
     # ---- state-duration histograms and position refinement on 1e5 tracks x 30
     from extrack_amd.histograms import len_hist
     from extrack_amd.refined_localization import position_refinement
@@ -481,6 +519,7 @@ def main(argv=None):
     ap.add_argument("--tracks", type=int, default=None, help="tracks per GPU (c2) / in total (c2s, c4); default = the BASELINE config")
     ap.add_argument("--no-extra", action="store_true", help="skip the configs[2] / configs[4] measurements after the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fits", action="store_true", help="extra block: single evaluations of every kernel only, no whole param_fitting runs (profiler passes)")
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
                     help="process-group backend: nccl = RCCL over xGMI (the measurement); gloo = rehearsal of the multi-rank control flow on a box "
                          "without GPUs (needs --rehearsal-context; nothing it prints is a measurement)")
@@ -621,14 +660,27 @@ def main(argv=None):
             th_val = ts.loglik_th(model, 0.2, 120, 2000)
             th_ms.append(ts.ctx.last_kernel_ms())
         th_dt = (time.perf_counter() - t1) / max(3, a.steps // 2)
-        th = {"what": "P_Cs_inter_bound_stats_th path (threshold 0.2, max_nb_states 120, chunk 2000): plan + apply kernels",
+        ts.th_freeze_plan(True)   # the plan of the last evaluation kept: what the optimiser sees between two re-plannings (apply kernel only)
+        for _ in range(2):
+            ts.loglik_th(model, 0.2, 120, 2000)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(max(3, a.steps // 2)):
+            fz_val = ts.loglik_th(model, 0.2, 120, 2000)
+        fz_dt = (time.perf_counter() - t1) / max(3, a.steps // 2)
+        fz_k = ts.ctx.last_kernel_ms()
+        ts.th_freeze_plan(False)
+        th = {"frozen_plan": {"what": "the same evaluation with the merge plan of the previous one kept (extrack_th_freeze_plan): no plan kernel, no read-back - every "
+                                      "evaluation between two re-plannings of a frozen-plan fit", "ms_per_eval": fz_dt * 1e3, "kernel_ms": fz_k,
+                              "same_value": bool(fz_val == th_val)},
+              "what": "P_Cs_inter_bound_stats_th path (threshold 0.2, max_nb_states 120, chunk 2000): plan + apply kernels",
               "value": 1.0 / th_dt, "unit": "1e6-track LL evals/s", "ms_per_eval": th_dt * 1e3, "kernels_ms": float(np.mean(th_ms)),
               "hbm_gbs": a.tracks * LEN * DIMS * 8 / (float(np.mean(th_ms)) * 1e-3) / 1e9, "neg_loglik": -th_val,
               "launch": ts.ctx.last_launch_info()}
     ts.close()
     extra = None
     if on_gpu and world == 1 and a.config == "c2" and a.tracks == N_TRACKS and not a.no_extra:
-        extra = other_configs(local, a.no_cpu_baseline)
+        extra = other_configs(local, a.no_cpu_baseline, a.no_fits)
         # configs[3] on ONE GPU: the N = 1 point of the strong-scaling curve `scaling_runs.c4` reports at N > 1
         scaling_runs["c4"] = run_config("c4", None)[0]
     if comm is not None:
