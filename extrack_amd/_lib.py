@@ -17,7 +17,7 @@ EXPORTS = [
     "extrack_loglik", "extrack_loglik_async", "extrack_predict", "extrack_last_kernel_ms",
     "extrack_last_launch_info", "extrack_p_stay_table", "extrack_loglik_th", "extrack_loglik_th_async", "extrack_th_plan_step",
     "extrack_predict_th", "extrack_loglik_grad", "extrack_loglik_grad_async", "extrack_last_grad_ms", "extrack_segment_len_hist", "extrack_refine_positions",
-    "extrack_sequence_columns", "extrack_sequence_matrix", "extrack_loglik_th_grad", "extrack_loglik_th_grad_async", "extrack_th_freeze_plan",
+    "extrack_sequence_columns", "extrack_sequence_matrix", "extrack_loglik_th_grad", "extrack_loglik_th_grad_async", "extrack_th_freeze_plan", "extrack_sequence_matrix_th",
 ]
 
 _dp = C.POINTER(C.c_double)
@@ -117,6 +117,7 @@ def load():
     lib.extrack_loglik_th_grad.argtypes = [vp, C.POINTER(ExtrackModel), C.c_double, i32, i32, i32, C.POINTER(ExtrackModelTangent), _dp, vp]
     lib.extrack_loglik_th_grad_async.argtypes = [vp, C.POINTER(ExtrackModel), C.c_double, i32, i32, i32, C.POINTER(ExtrackModelTangent), vp]
     lib.extrack_th_freeze_plan.argtypes = [vp, i32]
+    lib.extrack_sequence_matrix_th.argtypes = [vp, C.POINTER(ExtrackModel), i32, C.c_double, i32, vp, i64, C.POINTER(i64)]
     if lib.extrack_abi_version() != 6:
         raise ImportError("libextrack_hip.so ABI version mismatch")
     _lib = lib
@@ -293,6 +294,17 @@ class Context:
         n, arr, keep = self._pack_tangents(model, tangents)
         self._check(self._lib.extrack_loglik_grad_async(self._h, C.byref(model.c), n, arr, C.c_void_p(d_out_ptr)))
         return n
+
+    def sequence_matrix_th(self, model, bucket_id, threshold=0.2, max_nb_states=120):
+        """LP[N, n_cols] of the threshold-fusion kernel for one bucket taken as one chunk, without the leaving term (extrack_sequence_matrix_th)."""
+        N = self.buckets[bucket_id][0]
+        nc = C.c_int64(0)
+        self._check(self._lib.extrack_sequence_matrix_th(self._h, C.byref(model.c), int(bucket_id), C.c_double(threshold), int(max_nb_states), None, 0,
+                                                         C.byref(nc)))
+        out = np.empty((N, nc.value))
+        self._check(self._lib.extrack_sequence_matrix_th(self._h, C.byref(model.c), int(bucket_id), C.c_double(threshold), int(max_nb_states),
+                                                         out.ctypes.data_as(C.c_void_p), nc.value, C.byref(nc)))
+        return out
 
     def th_freeze_plan(self, on):
         """Threshold-fusion evaluations follow the plan of the last planning evaluation (on) / decide their own again (off)."""

@@ -1215,6 +1215,8 @@ static int xt_th_run_group(extrack_ctx* ctx, const extrack_model* m, const std::
             k.gnew = b.th_gnew;
             k.hdr = b.th_hdr;
             k.status = ctx->d_th_status + (size_t)(i ? chunk_end[i - 1] : 0) * 4;
+            k.seq_out = b.d_seqth;
+            k.seq_stride = b.seqth_stride;
         }
         if ((rc = xt_th_upload_small(ctx, (void**)&ctx->d_th_desc, &ctx->th_desc_cap, desc.data(), desc.size() * sizeof(XtThBucket)))) return rc;
         if ((rc = xt_th_upload_small(ctx, (void**)&ctx->d_th_cend, &ctx->th_cend_cap, chunk_end.data(), chunk_end.size() * sizeof(int32_t)))) return rc;
@@ -1250,6 +1252,8 @@ static int xt_th_run_group(extrack_ctx* ctx, const extrack_model* m, const std::
             k.gnew = b.th_gnew;
             k.hdr = b.th_hdr;
             k.status = ctx->d_th_status + (size_t)(i ? chunk_end[i - 1] : 0) * 4;
+            k.seq_out = b.d_seqth;
+            k.seq_stride = b.seqth_stride;
         }
         if ((rc = xt_th_upload_small(ctx, (void**)&ctx->d_th_desc, &ctx->th_desc_cap, desc.data(), desc.size() * sizeof(XtThBucket)))) return rc;
         if ((rc = xt_th_upload_small(ctx, (void**)&ctx->d_th_cend, &ctx->th_cend_cap, chunk_end.data(), chunk_end.size() * sizeof(int32_t)))) return rc;
@@ -1609,6 +1613,75 @@ extern "C" int extrack_th_freeze_plan(extrack_ctx* ctx, int32_t on)
 {
     if (!ctx) return EXTRACK_E_INVALID;
     ctx->th_frozen = on != 0;
+    return EXTRACK_OK;
+}
+
+// Per-sequence log-probabilities of the threshold-fusion kernel for ONE bucket taken as one chunk (what P_Cs_inter_bound_stats_th returns first,
+// extrack/tracking.py:650, before the caller's log-sum): lp host [n][n_cols] with n_cols = (sequences alive after the last merge) x
+// n_states^nb_substeps, column (g, r) = g * n_states^nb_substeps + r in the reference's order; WITHOUT the leaving / bleaching term of isBL
+// tracks (a further expansion by n_states^nb_substeps that the caller adds: its factors depend on the model only).  First call with lp ==
+// nullptr to get *n_cols_out.  For small inputs: n * n_cols doubles cross the host.
+extern "C" int extrack_sequence_matrix_th(extrack_ctx* ctx, const extrack_model* m, int32_t bucket_id, double threshold, int32_t max_nb_states,
+                                          double* lp, int64_t n_cols_cap, int64_t* n_cols_out)
+{
+    if (!ctx || !n_cols_out) return xt_fail(ctx, EXTRACK_E_INVALID, "null argument");
+    if (bucket_id < 0 || bucket_id >= (int)ctx->buckets.size()) return xt_fail(ctx, EXTRACK_E_INVALID, "bucket id out of range");
+    int rc = xt_validate_model(ctx, m);
+    if (rc) return rc;
+    XtBucket& b = ctx->buckets[bucket_id];
+    if (b.d_dt) return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "sequence matrix: per-track time steps are not served");
+    if (!(threshold >= 0.0)) return xt_fail(ctx, EXTRACK_E_INVALID, "threshold must be >= 0");
+    if (m->frame_len <= m->nb_substeps || m->frame_len > 15) return xt_fail(ctx, EXTRACK_E_INVALID, "frame_len must be in (nb_substeps, 15]");
+    XT_HIP(ctx, hipSetDevice(ctx->device));
+    XtModelHost mh;
+    xt_model_host(m, mh);
+    std::vector<double> blob;
+    int G = 0;
+    std::string err = xt_th_build_blob(mh, blob, G);
+    if (!err.empty()) return xt_fail(ctx, EXTRACK_E_INVALID, err);
+    if ((rc = xt_upload_blob(ctx, blob))) return rc;
+    const int32_t chunk = (int32_t)std::min<int64_t>(b.N, (int64_t)1 << 30);  // the whole bucket is one chunk: its first 30 tracks decide the merges
+    std::vector<XtBucket*> one(1, &b);
+    const bool was_frozen = ctx->th_frozen;
+    ctx->th_frozen = false;
+    size_t poff = 0;
+    if ((rc = xt_grow_partials(ctx, 64))) return rc;
+    b.d_seqth = nullptr;
+    rc = xt_th_run_group(ctx, m, one, threshold, max_nb_states, chunk, G, false, poff, nullptr);  // plans (and evaluates once)
+    if (rc) {
+        ctx->th_frozen = was_frozen;
+        return rc;
+    }
+    XT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // sequences alive after the last merge step (L - 2); two-position tracks have no merge: the S initial ones
+    int32_t hd[2] = {0, m->n_states};
+    if (b.L >= 3) XT_HIP(ctx, hipMemcpy(hd, b.th_hdr + (size_t)(b.L - 2) * 2, sizeof(hd), hipMemcpyDeviceToHost));
+    const int64_t ncols = (int64_t)hd[1] * G;
+    *n_cols_out = ncols;
+    if (!lp) {
+        ctx->th_frozen = was_frozen;
+        return EXTRACK_OK;
+    }
+    if (n_cols_cap < ncols) {
+        ctx->th_frozen = was_frozen;
+        return xt_fail(ctx, EXTRACK_E_INVALID, "sequence matrix: output capacity too small");
+    }
+    const size_t nbytes = (size_t)b.N * (size_t)ncols * sizeof(double);
+    if ((rc = xt_reserve_preds(ctx, nbytes))) {
+        ctx->th_frozen = was_frozen;
+        return rc;
+    }
+    b.d_seqth = ctx->d_preds;
+    b.seqth_stride = (int)ncols;
+    ctx->th_frozen = true;  // the plan just made, followed once more with the per-sequence output switched on
+    poff = 0;
+    rc = xt_th_run_group(ctx, m, one, threshold, max_nb_states, chunk, G, false, poff, nullptr);
+    b.d_seqth = nullptr;
+    b.seqth_stride = 0;
+    ctx->th_frozen = was_frozen;
+    if (rc) return rc;
+    XT_HIP(ctx, hipMemcpyAsync(lp, ctx->d_preds, nbytes, hipMemcpyDeviceToHost, ctx->stream));
+    XT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return EXTRACK_OK;
 }
 

@@ -233,6 +233,8 @@ struct XtBucket {
     int32_t* th_status = nullptr;
     int th_capE = 0, th_chunk = 0;
     int64_t th_nchunks = 0;
+    double* d_seqth = nullptr;  // transient (extrack_sequence_matrix_th): per-sequence output of the apply kernel, not owned by the bucket
+    int seqth_stride = 0;
     int th_maxG = -1, th_sumE = 0;  // of that plan: largest group count of a step / largest sum of expanded sequences over the steps, over the bucket's chunks (-1: no valid plan)
 };
 

@@ -82,6 +82,8 @@ struct XtThBucket {
     uint8_t* gnew;
     int32_t* hdr;
     int32_t* status;
+    double* seq_out;       // [N][seq_stride] log-probability of every (final parent, new digits) sequence at the last position, WITHOUT the
+    int32_t seq_stride;    // leaving term (extrack_sequence_matrix_th), or nullptr
 };
 
 struct XtThArgs {
@@ -119,6 +121,8 @@ struct XtThArgs {
     int32_t pair_lanes_max_p;  // pilot counts up to this use one lane per (pivot, candidate) pair in the grouping, more use ballots
     int32_t stP, stE;      // global workspace only: capacities of the LDS staging copy of the pilots' means / stds that the
                            // grouping reads (0: none); steps with more sequences read the workspace directly
+    double* seq_out;            // single-bucket form of XtThBucket::seq_out / seq_stride
+    int32_t seq_stride;
     const XtThBucket* buckets;  // device array [nbuckets], or nullptr: the single bucket described by the fields above
     const int32_t* chunk_end;   // device array [nbuckets]: exclusive prefix sum of the buckets' chunk counts
     int32_t nbuckets;
@@ -186,6 +190,8 @@ XT_HD XtThBucket xt_th_bind(const XtThArgs& a, int gch, int& lc)
         k.gnew = a.gnew;
         k.hdr = a.hdr;
         k.status = a.status;
+        k.seq_out = a.seq_out;
+        k.seq_stride = a.seq_stride;
         lc = gch;
         return k;
     }
@@ -217,6 +223,8 @@ XT_HD XtThBucket xt_th_bind(const XtThArgs& a, int gch, int& lc)
     k.gnew = tab[lo].gnew;
     k.hdr = tab[lo].hdr;
     k.status = tab[lo].status;
+    k.seq_out = tab[lo].seq_out;
+    k.seq_stride = tab[lo].seq_stride;
     return k;
 }
 
@@ -1609,6 +1617,11 @@ XT_HD void xt_th_apply_body(const XtThArgs& a, Ctx& cx)
                     int j, n2;
                     xt_exp_tab(-quad, p, j, n2);
                     acc.add(zq * TF[o + r] * (gf * T64[j]) * p, eq + n2);
+                    if (bk.seq_out) {  // the reference's per-sequence matrix (tracking.py:632-650), before its leaving term: the caller expands that
+                        const double wq = zq * TAB[(stay ? 1 : 0) * S * G + o + r] * (gf * T64[j]) * p;
+                        bk.seq_out[(first + x) * (int64_t)bk.seq_stride + g * G + r] =
+                            nanflag[x] ? NAN : (wq > 0.0 ? log(wq) + (double)(eq + n2) * XT_LN2 + bk.ll_const : (wq == 0.0 ? -INFINITY : NAN));
+                    }
                 }
                 nxt.zm(idx) = acc.m;
                 nxt.ze(idx) = acc.e;

@@ -280,6 +280,54 @@ def P_Cs_inter_bound_stats(Cs, LocErr, ds, Fs, TrMat, pBL=0.1, isBL=1, cell_dims
         ts.close()
 
 
+def P_Cs_inter_bound_stats_th(Cs, LocErr, ds, Fs, TrMat, pBL=0.1, isBL=1, cell_dims=[0.5], nb_substeps=1, frame_len=6, do_preds=0, min_len=3,
+                              threshold=0.2, max_nb_states=120, device=0, return_matrix=False):
+    """Mirror of extrack/tracking.py:427-650 (the kernel extrack.tracking runs in v1.6.3): the whole of ``Cs`` is ONE chunk, its first 30
+    tracks decide which state sequences are merged (:678-679).  Returns ``(LP, cur_Bs_cat, preds)``:
+      * ``LP``: by default ``LP_C[:, None]`` - the likelihood kernels reduce the per-sequence matrix in place, and its log-sum over axis 1 is
+        all the reference's callers take from it (Proba_Cs, :778-787).  ``return_matrix=True`` gives the reference's ``LP[N, nB]`` itself,
+        column by column (the sequences alive after the last merge x the new states of the last step, x the states of the leaving step for
+        isBL tracks, :611-633) - for small inputs: the matrix goes through host memory (extrack_sequence_matrix_th).
+      * ``cur_Bs_cat`` is None: the reference's state-history array is internal to its grouping rule and read by no caller (:778, :790).
+      * ``preds``: the posteriors [N, len, S] when ``do_preds`` (what predict_Bs takes, :790), else ``[]``."""
+    ts, le = _one_bucket(Cs, LocErr, isBL, min_len, device)
+    try:
+        ds, TrMat = np.asarray(ds, float), np.asarray(TrMat, float)
+        S, ns = len(ds), int(nb_substeps)
+        model = ts.make_model(le, ds, Fs, TrMat, pBL, cell_dims, ns, frame_len)
+        N = len(Cs)
+        preds = []
+        if do_preds:
+            if ns != 1:
+                raise ValueError("state predictions require nb_substeps == 1")
+            preds = ts.predict_th(model, threshold, max_nb_states, nb_max=max(N, 1))[0]
+        if not return_matrix:
+            return ts.loglik_th(model, threshold, max_nb_states, chunk=max(N, 1), per_track=True)[1][:, None], None, preds
+        LP = ts.ctx.sequence_matrix_th(model, 0, threshold, max_nb_states)
+        if isBL:
+            # the leaving / bleaching step (:611-630): every sequence is expanded once more by the S^ns states of that step, new index =
+            # old * S^ns + r2; its factor depends on the model only: the ns transitions from the sequence's newest state through the digits of r2
+            # (digit 0 = newest) and the chance to leave the field of view or bleach from r2's newest state - p_stay indexed by the raw
+            # state (:624)
+            G = S ** ns
+            ps = engine.p_stay_table(ds, S, ns, cell_dims)
+            r2 = np.arange(G)
+            dig = np.stack([(r2 // S ** c) % S for c in range(ns)], 1)  # [G, ns], column 0 = newest
+            logT = np.log(TrMat)
+            LL = np.zeros((S, G))
+            for prev in range(S):
+                chain = np.concatenate([dig, np.full((G, 1), prev)], 1)  # newest ... oldest = the sequence's newest state
+                for c in range(ns):
+                    LL[prev] += logT[chain[:, c + 1], chain[:, c]]
+                e = ps[dig[:, 0]]
+                LL[prev] += np.log(pBL + (1 - e) - pBL * (1 - e))
+            newest = np.arange(LP.shape[1]) % S  # column (g, r): digit 0 of r is the sequence's newest state
+            LP = (LP[:, :, None] + LL[newest][None]).reshape(N, -1)
+        return LP, None, preds
+    finally:
+        ts.close()
+
+
 # ------------------------------------------------------------------------------------------------------------
 # objective
 # ------------------------------------------------------------------------------------------------------------

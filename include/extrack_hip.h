@@ -193,6 +193,15 @@ int extrack_loglik_th_grad_async(extrack_ctx* ctx, const extrack_model* model, d
  * handed between two re-plannings (extrack_amd.tracking.param_fitting does: plan, minimise at that plan with the exact gradient,
  * re-plan, until the plan no longer changes).  on = 0: every evaluation decides its own plan again (the reference's semantics). */
 int extrack_th_freeze_plan(extrack_ctx* ctx, int32_t on);
+/* Per-sequence log-probabilities of the threshold-fusion kernel for ONE bucket taken as ONE chunk - the first return value of
+ * P_Cs_inter_bound_stats_th (extrack/tracking.py:427, returned at :650) before Proba_Cs' log-sum (:780-787): lp host [n][n_cols], n_cols =
+ * (state sequences alive after the last merge) x n_states^nb_substeps, column g * n_states^nb_substeps + r as in the reference; for isBL
+ * buckets (len != model->max_len) WITHOUT the leaving / bleaching term, a further expansion by n_states^nb_substeps whose factors depend
+ * on the model only (tracking.py:611-630; extrack_amd.tracking.P_Cs_inter_bound_stats_th adds it).  Call with lp == NULL first: *n_cols_out
+ * receives n_cols (it depends on the merges, i.e. on the data).  For callers of the reference function that read the matrix, on small
+ * inputs (n * n_cols doubles cross the host); the likelihood path never forms it. */
+int extrack_sequence_matrix_th(extrack_ctx* ctx, const extrack_model* model, int32_t bucket_id, double threshold, int32_t max_nb_states,
+                               double* lp, int64_t n_cols_cap, int64_t* n_cols_out);
 /* Device time (ms) of the gradient kernels of the last extrack_loglik_grad / extrack_loglik_th_grad (or _async) call (waits for them). */
 int extrack_last_grad_ms(extrack_ctx* ctx, float* ms);
 
