@@ -18,6 +18,8 @@ EXPORTS = [
     "extrack_last_launch_info", "extrack_p_stay_table", "extrack_loglik_th", "extrack_loglik_th_async", "extrack_th_plan_step",
     "extrack_predict_th", "extrack_loglik_grad", "extrack_loglik_grad_async", "extrack_last_grad_ms", "extrack_segment_len_hist", "extrack_refine_positions",
     "extrack_sequence_columns", "extrack_sequence_matrix", "extrack_loglik_th_grad", "extrack_loglik_th_grad_async", "extrack_th_freeze_plan", "extrack_sequence_matrix_th",
+    "extrack_multi_create", "extrack_multi_destroy", "extrack_multi_last_error", "extrack_multi_device_count", "extrack_multi_uses_rccl",
+    "extrack_multi_context", "extrack_multi_upload_bucket", "extrack_multi_clear_buckets", "extrack_multi_loglik",
 ]
 
 _dp = C.POINTER(C.c_double)
@@ -118,6 +120,18 @@ def load():
     lib.extrack_loglik_th_grad_async.argtypes = [vp, C.POINTER(ExtrackModel), C.c_double, i32, i32, i32, C.POINTER(ExtrackModelTangent), vp]
     lib.extrack_th_freeze_plan.argtypes = [vp, i32]
     lib.extrack_sequence_matrix_th.argtypes = [vp, C.POINTER(ExtrackModel), i32, C.c_double, i32, vp, i64, C.POINTER(i64)]
+    lib.extrack_multi_create.argtypes = [i32, C.POINTER(i32), i32, C.POINTER(vp)]
+    lib.extrack_multi_destroy.argtypes = [vp]
+    lib.extrack_multi_destroy.restype = None
+    lib.extrack_multi_last_error.argtypes = [vp]
+    lib.extrack_multi_last_error.restype = C.c_char_p
+    lib.extrack_multi_device_count.argtypes = [vp]
+    lib.extrack_multi_uses_rccl.argtypes = [vp]
+    lib.extrack_multi_context.argtypes = [vp, i32]
+    lib.extrack_multi_context.restype = vp
+    lib.extrack_multi_upload_bucket.argtypes = [vp, vp, i64, i32, i32, vp, i32]
+    lib.extrack_multi_clear_buckets.argtypes = [vp]
+    lib.extrack_multi_loglik.argtypes = [vp, C.POINTER(ExtrackModel), _dp]
     if lib.extrack_abi_version() != 6:
         raise ImportError("libextrack_hip.so ABI version mismatch")
     _lib = lib
@@ -408,6 +422,55 @@ class Context:
         info = (C.c_int32 * 6)()
         self._check(self._lib.extrack_last_launch_info(self._h, C.byref(info)))
         return dict(zip(("blocks", "threads", "lds_bytes", "tracks_per_block", "blocks_per_cu", "compute_units"), list(info)))
+
+
+class MultiContext:
+    """One process, several GPUs (extrack_multi_* of include/extrack_hip.h): every device keeps a contiguous row range of every bucket, an
+    evaluation ends with one all-reduce of the scalar over RCCL (``use_rccl``: 0 host sum, 1 RCCL when loadable, 2 RCCL or error).  The
+    multi-process form of the same partitioning is ``extrack_amd.distributed``."""
+
+    def __init__(self, devices, use_rccl=1):
+        self._lib = load()
+        ids = (C.c_int32 * len(devices))(*[int(d) for d in devices])
+        h = C.c_void_p()
+        rc = self._lib.extrack_multi_create(len(devices), ids, int(use_rccl), C.byref(h))
+        if rc != 0:
+            raise ExtrackError(rc, self._lib.extrack_multi_last_error(None).decode())
+        self._h = h
+        self.devices = [int(d) for d in devices]
+
+    def _check(self, rc):
+        if rc != 0:
+            raise ExtrackError(rc, self._lib.extrack_multi_last_error(self._h).decode())
+
+    @property
+    def uses_rccl(self):
+        return bool(self._lib.extrack_multi_uses_rccl(self._h))
+
+    def upload_bucket(self, tracks, sigma=None):
+        tracks = _f64(tracks)
+        N, L, D = tracks.shape
+        KS, sp = 0, None
+        if sigma is not None:
+            sigma = _f64(sigma)
+            KS, sp = sigma.shape[2], sigma.ctypes.data_as(C.c_void_p)
+        self._check(self._lib.extrack_multi_upload_bucket(self._h, tracks.ctypes.data_as(C.c_void_p), N, L, D, sp, KS))
+
+    def loglik(self, model):
+        tot = C.c_double(0.0)
+        self._check(self._lib.extrack_multi_loglik(self._h, C.byref(model.c), C.byref(tot)))
+        return tot.value
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.extrack_multi_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def p_stay_table_c(ds, nb_substeps, cell_dims):

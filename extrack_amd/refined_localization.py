@@ -5,8 +5,8 @@ predictions from the future and from the past (get_pos_PDF, :207-298) run in HIP
 C ABI.  Built for what the reference's own array reshapes carry through: ONE global localisation error (a float or a 1-element array)
 or a dict of per-peak errors ``{len: sigma[n_tracks, len, 1]}``, nb_substeps = 1.  Per-peak errors are used exactly as the reference uses
 them - it reverses the error array but not the track in get_LC_Km_Ks (refined_localization.py:64-65 vs :115), so its pass "from the
-future" pairs every position with its mirror image's error; that pairing is reproduced (oracle/oracle_refine.py, pinned to 50
-reference-generated buckets), per-dimension errors and ``[n, len, dims]`` dicts are refused as the reference's reshapes refuse them.
+future" pairs every position with its mirror image's error; that pairing is reproduced (pinned by 50 reference-generated buckets,
+tests/golden/refine_pp_cases.*), per-dimension errors and ``[n, len, dims]`` dicts are refused as the reference's reshapes refuse them.
 Like the reference, every length bucket is processed as one chunk: its first 30 tracks decide which state sequences are merged."""
 import numpy as np
 

@@ -265,6 +265,29 @@ int extrack_last_launch_info(const extrack_ctx* ctx, int32_t info[6]);
 int extrack_p_stay_table(const double* ds, int32_t n_states, int32_t nb_substeps, const double* cell_dims,
                          int32_t n_cell_dims, double* out);
 
+/* ---- one process, several GPUs -------------------------------------------------------------------------------------------------------
+ * The reference parallelises with multiprocessing.Pool.map over track chunks and sums the per-chunk results (extrack/tracking.py:1061-1069).
+ * A host without torch.distributed (option B) drives all the GPUs of a node from one thread through these entry points:
+ * every device keeps a contiguous row range of every uploaded bucket, an evaluation runs the likelihood kernel on all devices at once and ends
+ * with ONE all-reduce of the scalar over RCCL / xGMI (ncclCommInitAll over the listed devices at creation, ncclAllReduce(sum, double, 1) per
+ * evaluation).  use_rccl: 0 = sum the per-device totals on the host; 1 = RCCL when librccl.so can be loaded (at run time, no link-time
+ * dependency) and the devices are distinct, else the host sum; 2 = RCCL or EXTRACK_E_UNSUPPORTED.  The multi-PROCESS form of the same
+ * partitioning (one rank per GPU, torch.distributed) is extrack_amd/distributed.py. */
+typedef struct extrack_multi extrack_multi;
+int extrack_multi_create(int32_t n_devices, const int32_t* device_ids, int32_t use_rccl, extrack_multi** out);
+void extrack_multi_destroy(extrack_multi* m);
+const char* extrack_multi_last_error(const extrack_multi* m);
+int32_t extrack_multi_device_count(const extrack_multi* m);
+int32_t extrack_multi_uses_rccl(const extrack_multi* m);
+/* The per-device context i (owned by m): for the single-device entry points above on one shard, e.g. extrack_predict. */
+extrack_ctx* extrack_multi_context(extrack_multi* m, int32_t i);
+/* One length bucket, host [n][len][dims] (+ per-peak errors): device r receives the rows [r n / w, (r + 1) n / w) (balanced to one row). */
+int extrack_multi_upload_bucket(extrack_multi* m, const double* tracks, int64_t n, int32_t len, int32_t dims, const double* sigma,
+                                int32_t sigma_dims);
+int extrack_multi_clear_buckets(extrack_multi* m);
+/* sum(LL) over all buckets on all devices (as extrack_loglik; model->min_len / max_len are the dataset-global values). */
+int extrack_multi_loglik(extrack_multi* m, const extrack_model* model, double* total_ll);
+
 #ifdef __cplusplus
 }
 #endif

@@ -260,3 +260,30 @@ def test_c5_predict_Bs_full_size():
     assert np.abs(pr[:16] - ref[:16]).max() < TOL_PRED and np.abs(pr[-8:] - ref[16:]).max() < TOL_PRED
     half = T.predict_Bs({"60": Cs[250000:]}, 0.02, p, cell_dims=[1], nb_states=4, frame_len=5)["60"]
     assert np.abs(half - pr[250000:]).max() < 1e-12  # the posterior sums use LDS atomics: order-dependent in the last bits
+
+
+def test_single_process_multi_device_entry_points():
+    """extrack_multi_* (one process, several GPUs; include/extrack_hip.h): the row sharding, the concurrent per-device evaluations and the sum.
+    This box has one GPU: the same device listed twice gives two shards with two contexts (RCCL refuses duplicate devices, so the totals are
+    summed on the host - the path a node without librccl takes); with one device the communicator is not needed at all.  The 8-GPU RCCL path
+    (ncclCommInitAll + one grouped ncclAllReduce per evaluation) is exercised by the driver's multi-GPU node only."""
+    from extrack_amd import _lib, synth, tracking as T
+    tracks = _c3_tracks(3000, seed0=40)
+    _, lst, _ = T.engine.sort_buckets(tracks)
+    ts = T.TrackSet(lst)
+    model = T._objective_model(_params(C3_VALS), ts, 0.02, [1], None, 3, 1, 4, 1)
+    ref = ts.loglik(model)
+    for devs in ([0], [0, 0], [0, 0, 0]):
+        mc = _lib.MultiContext(devs, use_rccl=1)
+        try:
+            for b in lst:
+                mc.upload_bucket(b)
+            got = mc.loglik(model)
+            got2 = mc.loglik(model)
+            assert not mc.uses_rccl
+        finally:
+            mc.close()
+        assert got == got2 and abs(got - ref) < 1e-12 * abs(ref), (devs, got, ref)
+    ts.close()
+    with pytest.raises(_lib.ExtrackError):
+        _lib.MultiContext([99])
