@@ -542,7 +542,7 @@ def _fit_threshold_frozen_plan(params, fargs, method, ts, max_rounds=6):
     every round; ``plan_rounds`` says how many plans were used."""
     from . import lmfit_compat
     nfev = ngev = 0
-    cur, fit, f_prev, rounds = params, None, None, 0
+    cur, fit, f_prev, rounds, hinv = params, None, None, 0, None
     a = list(fargs)
     a[7] = 0  # the planning evaluations between the rounds are silent
     import contextlib
@@ -556,7 +556,19 @@ def _fit_threshold_frozen_plan(params, fargs, method, ts, max_rounds=6):
             if not np.isfinite(f_plan):
                 raise ValueError("the starting parameters are invalid for the model (objective = inf)")
             ts.th_freeze_plan(True)
-            fit = lmfit_compat.minimize_with_gradient(cum_Proba_Cs, cur, args=fargs, method=method, nan_policy="propagate", fcn_grad=cum_Proba_Cs_grad)
+            # later rounds start at the previous round's minimiser: they also start from its inverse-Hessian estimate (scipy's BFGS takes one)
+            # instead of re-learning the curvature from the identity
+            kw = {}
+            if hinv is not None and str(method).lower() == "bfgs":
+                kw["options"] = {"hess_inv0": hinv}
+            fit = lmfit_compat.minimize_with_gradient(cum_Proba_Cs, cur, args=fargs, method=method, nan_policy="propagate", fcn_grad=cum_Proba_Cs_grad, **kw)
+            h = getattr(getattr(fit, "scipy_result", None), "hess_inv", None)
+            hinv = None
+            if isinstance(h, np.ndarray) and np.all(np.isfinite(h)):
+                h = (np.asarray(h, float) + np.asarray(h, float).T) / 2
+                w = np.linalg.eigvalsh(h)
+                if w.min() > 1e-10 * w.max():  # scipy insists on a positive definite start; a round that ended on a failed line search may not leave one
+                    hinv = h
             nfev += int(fit.nfev)
             ngev += int(getattr(fit, "ngev", 0))
             ts.th_freeze_plan(False)
