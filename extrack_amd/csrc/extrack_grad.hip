@@ -326,7 +326,12 @@ static int xt_grad_enqueue(extrack_ctx* ctx, const extrack_model* m, int32_t n_d
                 const int src = i < NF ? full[i] : uni[i - NF];
                 XT_HIP(ctx, hipMemcpyAsync(ctx->d_dblob2 + (size_t)i * TB, ctx->d_dblob + (size_t)src * TB, (size_t)TB * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
             }
-            const int npass = (NF + 7) / 8, per = (NF + npass - 1) / npass;
+            static const int r2_maxnp = [] {
+                const char* e = getenv("EXTRACK_R2_MAXNP");
+                const int v = e ? atoi(e) : 8;
+                return v >= 1 && v <= 8 ? v : 8;
+            }();
+            const int npass = (NF + r2_maxnp - 1) / r2_maxnp, per = (NF + npass - 1) / npass;
             double lo = INFINITY, hi = -INFINITY;
             for (int k = 0; k < m->locerr_dims && k < 3; ++k) {
                 lo = std::min(lo, m->locerr[k] * m->locerr[k]);

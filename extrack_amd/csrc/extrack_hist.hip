@@ -64,7 +64,7 @@ extern "C" int extrack_segment_len_hist(extrack_ctx* ctx, const extrack_model* m
     memset(&a, 0, sizeof(a));
     a.bits = S <= 2 ? 1 : (S <= 4 ? 2 : 3);
     a.HW = (L * a.bits + 63) / 64;
-    if (a.HW > XT_HIST_MAXW) return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "track too long for the state-history words (len * bits per state <= 256)");
+    if (a.HW > XT_HIST_MAXW) return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "track too long for the state-history words (len * bits per state <= 4096)");
     a.K = max_nb_states;
     a.PC = std::max(max_nb_states, S * S);
     if ((int64_t)a.PC * S > 16384) return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "max_nb_states * n_states > 16384 is not built");

@@ -21,7 +21,7 @@
 #pragma once
 #include "xt_math.h"
 
-#define XT_HIST_MAXW 4  // history words (64 bits each): len * bits_per_state <= 256
+#define XT_HIST_MAXW 64  // history words (64 bits each) per sequence, a run-time count: len * bits_per_state <= 4096 (2 states: 4096 positions, 3 - 4: 2048, 5 - 8: 1365)
 #define XT_HIST_EPT 8   // register path of the ranking sort: at most this many candidates per thread (2048 candidates at 256 threads)
 
 struct XtHistArgs {

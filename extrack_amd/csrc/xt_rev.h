@@ -293,7 +293,11 @@ XT_HD void xt_rev_body(const XtKernelArgs& a, const XtRevArgs& ra, Ctx& cx)
             load_c(t, ct);
             load_l2(t, l2t, sct, srt);
             merge(zm, ze, mm, uu, aj, mb, ub, Wm, We);
+#if defined(XT_REV_DIAG) && (XT_REV_DIAG & 2)
+            if (act && t == 1) {
+#else
             if (act) {
+#endif
                 double* lg = LOG + (int64_t)(t - 1) * sdoubles;
                 lg[g] = Wm;
                 XT_UNROLL
@@ -470,7 +474,11 @@ XT_HD void xt_rev_body(const XtKernelArgs& a, const XtRevArgs& ra, Ctx& cx)
             if (t == 1) {
                 init_members(ctn, l2n, zm, ze, mm, uu);
             } else {
+#if defined(XT_REV_DIAG) && (XT_REV_DIAG & 1)
+                const double* lg = LOG;
+#else
                 const double* lg = LOG + (int64_t)(t - 2) * sdoubles;
+#endif
                 const double* TTs = TAB + ((t - 1 >= stay_from ? 1 : 0) * S) * G;
                 XT_UNROLL
                 for (int Q = 0; Q < G; ++Q) {

@@ -211,7 +211,8 @@ int extrack_last_grad_ms(extrack_ctx* ctx, float* ms);
  * history; after each position at most max_nb_states sequences survive, ranked by their probability including the next position's
  * predictive density (histograms.py:185-203; len_hist's default is 500).  model->nb_substeps must be 1; model->min_len is the
  * reference's min_l (smallest track length of the dataset), isBL = (len != model->max_len) as elsewhere.
- * Limits: len * bits_per_state <= 256 (bits = 1 / 2 / 3 for <= 2 / 4 / 8 states), max_nb_states * n_states <= 16384. */
+ * Limits: len * bits_per_state <= 4096 (bits = 1 / 2 / 3 for <= 2 / 4 / 8 states), max_nb_states * n_states <= 16384, and the staged track +
+ * candidate arrays + histogram must fit the 160 KiB LDS of a CU (refused with EXTRACK_E_UNSUPPORTED otherwise). */
 int extrack_segment_len_hist(extrack_ctx* ctx, const extrack_model* model, int32_t bucket_id, int32_t max_nb_states, double* hist);
 
 /* Refined positions of one bucket (extrack/refined_localization.py:304-338 position_refinement -> get_pos_PDF :207 -> get_LC_Km_Ks :48):

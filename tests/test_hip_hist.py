@@ -87,6 +87,25 @@ def test_hist_larger_dataset_vs_oracle_and_shard_additivity(capsys):
     assert h.shape == (40, 3) and np.all(h >= 0) and h[-1].sum() == 0.0
 
 
+def test_hist_long_tracks_many_history_words():
+    """Histories longer than the 256 bits of rounds 2 - 3 (round 4: a run-time number of 64-bit words): 3 states x 200 positions (7 words),
+    2 states x 400 (7 words), 5 states x 90 (3 bits per state, 5 words) against the numpy oracle."""
+    from extrack_amd import histograms as H, synth
+    from oracle import oracle_hist as OH
+    rng = np.random.default_rng(5)
+    for S, L, N, K in ((3, 200, 3, 40), (2, 400, 3, 30), (5, 90, 2, 60)):
+        Tm = rng.uniform(0.02, 0.12, (S, S))
+        Tm[np.arange(S), np.arange(S)] = 0
+        Tm[np.arange(S), np.arange(S)] = 1 - Tm.sum(1)
+        ds = np.sort(rng.uniform(0.005, 0.2, S))
+        Fs = rng.dirichlet(np.ones(S) * 3)
+        Cs = synth.brownian_tracks(N, L, list(ds ** 2 / (2 * 0.02)), Tm, list(Fs), seed=100 + S)
+        LE = np.array([[[0.02]]])
+        _, _, h = H.P_segment_len(Cs, LE, ds, Fs, Tm, min_l=3, pBL=0.05, isBL=1, cell_dims=[1.0], max_nb_states=K)
+        ref = OH.p_segment_len(Cs, LE, ds, Fs, Tm, min_l=3, pBL=0.05, isBL=1, cell_dims=[1.0], max_nb_states=K)
+        assert h.shape == ref.shape and np.abs(h - ref).max() < 1e-9 * N, (S, L, np.abs(h - ref).max())
+
+
 def test_hist_argument_errors_and_nan():
     from extrack_amd import _lib, histograms as H, synth
     Cs = synth.brownian_tracks(8, 6, [0.0, 0.25], [[.9, .1], [.1, .9]], [.6, .4], seed=1)
@@ -95,9 +114,9 @@ def test_hist_argument_errors_and_nan():
         H.P_segment_len(Cs, LE, [0.01, 0.1], [.5, .5], np.array([[.9, .1], [.1, .9]]), nb_substeps=2)
     with pytest.raises(ValueError):
         H.P_segment_len(Cs[:, :1], LE, [0.01, 0.1], [.5, .5], np.array([[.9, .1], [.1, .9]]))
-    with pytest.raises(_lib.ExtrackError):  # 200 positions x 2 bits do not fit the 256-bit histories
-        H.P_segment_len(synth.brownian_tracks(2, 200, [0.0, 0.1, 0.2], np.full((3, 3), 1 / 3), [.3, .3, .4], seed=2), LE, [0.01, 0.05, 0.1],
-                        [.3, .3, .4], np.full((3, 3), 1 / 3))
+    with pytest.raises(_lib.ExtrackError):  # 2100 positions x 2 bits do not fit the 4096-bit histories
+        H.P_segment_len(synth.brownian_tracks(2, 2100, [0.0, 0.1, 0.2], np.full((3, 3), 1 / 3), [.3, .3, .4], seed=2), LE, [0.01, 0.05, 0.1],
+                        [.3, .3, .4], np.full((3, 3), 1 / 3), max_nb_states=20)
     Cs[3, 2, 0] = np.nan
     _, _, h = H.P_segment_len(Cs, LE, [0.01, 0.1], [.5, .5], np.array([[.9, .1], [.1, .9]]), min_l=3)
     assert np.all(np.isnan(h))
