@@ -17,6 +17,7 @@ EXPORTS = [
     "extrack_loglik", "extrack_loglik_async", "extrack_predict", "extrack_last_kernel_ms",
     "extrack_last_launch_info", "extrack_p_stay_table", "extrack_loglik_th", "extrack_loglik_th_async", "extrack_th_plan_step",
     "extrack_predict_th", "extrack_loglik_grad", "extrack_loglik_grad_async", "extrack_last_grad_ms", "extrack_segment_len_hist", "extrack_refine_positions",
+    "extrack_refine_pos_pdf",
     "extrack_sequence_columns", "extrack_sequence_matrix", "extrack_loglik_th_grad", "extrack_loglik_th_grad_async", "extrack_th_freeze_plan", "extrack_sequence_matrix_th",
     "extrack_multi_create", "extrack_multi_destroy", "extrack_multi_last_error", "extrack_multi_device_count", "extrack_multi_uses_rccl",
     "extrack_multi_context", "extrack_multi_upload_bucket", "extrack_multi_clear_buckets", "extrack_multi_loglik",
@@ -112,6 +113,7 @@ def load():
     lib.extrack_loglik_grad_async.argtypes = [vp, C.POINTER(ExtrackModel), i32, C.POINTER(ExtrackModelTangent), vp]
     lib.extrack_segment_len_hist.argtypes = [vp, C.POINTER(ExtrackModel), i32, i32, vp]
     lib.extrack_refine_positions.argtypes = [vp, C.POINTER(ExtrackModel), i32, C.c_double, i32, vp, vp]
+    lib.extrack_refine_pos_pdf.argtypes = [vp, C.POINTER(ExtrackModel), i32, C.c_double, i32, vp, i64, vp, vp, vp]
     lib.extrack_last_grad_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.extrack_sequence_columns.argtypes = [i32, i32, i32, i32, i32]
     lib.extrack_sequence_columns.restype = i64
@@ -354,6 +356,23 @@ class Context:
         self._check(self._lib.extrack_refine_positions(self._h, C.byref(model.c), int(bucket_id), C.c_double(threshold), int(max_nb_states),
                                                        mu.ctypes.data_as(C.c_void_p), sg.ctypes.data_as(C.c_void_p)))
         return mu, sg
+
+    def refine_pos_pdf(self, model, bucket_id, threshold=0.1, max_nb_states=1000):
+        """The Gaussian mixture of every position of one bucket (get_pos_PDF, extrack/refined_localization.py:207-298): three lists over the
+        positions of means [n, n_comp, dims], stds [n, n_comp, 1] and log-weights [n, n_comp]."""
+        N, L, D, KS = self.buckets[bucket_id]
+        counts = np.zeros(L, np.int32)
+        args = (self._h, C.byref(model.c), int(bucket_id), C.c_double(threshold), int(max_nb_states), counts.ctypes.data_as(C.c_void_p))
+        self._check(self._lib.extrack_refine_pos_pdf(*args, 0, None, None, None))  # sizing call
+        tot = int(counts.sum())
+        means, stds, logw = np.zeros((tot, N, D)), np.zeros((tot, N)), np.zeros((tot, N))
+        self._check(self._lib.extrack_refine_pos_pdf(*args, tot, means.ctypes.data_as(C.c_void_p), stds.ctypes.data_as(C.c_void_p),
+                                                     logw.ctypes.data_as(C.c_void_p)))
+        off = np.concatenate(([0], np.cumsum(counts)))
+        cut = lambda a, k: a[off[k]:off[k + 1]]
+        return ([np.ascontiguousarray(cut(means, k).transpose(1, 0, 2)) for k in range(L)],
+                [np.ascontiguousarray(cut(stds, k).T)[:, :, None] for k in range(L)],
+                [np.ascontiguousarray(cut(logw, k).T) for k in range(L)])
 
     def last_grad_ms(self):
         ms = C.c_float(0)

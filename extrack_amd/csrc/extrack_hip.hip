@@ -1934,6 +1934,12 @@ struct XtRefineArgs {
     double l2;             // squared localisation error (global), or
     const double* sigma;   // per-peak localisation errors [N][L] of these rows (nullptr: the global one)
     double logF[XT_MAX_STATES];
+    // the mixture itself (get_pos_PDF's return values, refined_localization.py:298), xt_refine_components only: component j of position k at
+    // row comp_off[k] + j of means [.][N][D], stds [.][N], logw [.][N]
+    const int64_t* comp_off;
+    double* comp_mean;
+    double* comp_std;
+    double* comp_logw;
 };
 
 // One thread per (track, position): softmax-weighted mean of the pair means / root mean of the pair variances
@@ -2025,6 +2031,86 @@ __global__ void __launch_bounds__(256) xt_refine_combine(XtRefineArgs a)
     }
     for (int d = 0; d < D; ++d) a.mu_out[(x * L + k) * D + d] = smu[d] / sw;
     a.sig_out[x * L + k] = sqrt(ssg / sw);
+}
+
+// The Gaussian mixture of every position as the reference returns it from get_pos_PDF (refined_localization.py:207-298): same pair walk as
+// xt_refine_combine, in the reference's component order - end positions: the sequences of the pass's last record; positions between: for
+// every state s, (sequences from the future whose state at this position is s) x (sequences from the past with state s), the former outer.
+// For inspection of small inputs (every component of every track goes through HBM); the refinement proper never materialises them.
+template <int D>
+__global__ void __launch_bounds__(256) xt_refine_components(XtRefineArgs a)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.N * a.L) return;
+    const int k = (int)(i / a.N);
+    const int64_t x = i - (int64_t)k * a.N;
+    const int L = a.L, R = 2 + D;
+    double c[D];
+    for (int d = 0; d < D; ++d) c[d] = a.tracks[(x * L + k) * D + d];
+    const double l2k = a.sigma ? a.sigma[x * L + k] * a.sigma[x * L + k] : a.l2;
+    const double l2q = a.sigma ? a.sigma[x * L + (L - 1)] * a.sigma[x * L + (L - 1)] : a.l2;
+    int64_t row = a.comp_off[k];
+    // the recording kernel keeps the -dims/2 log(2 pi) of every integration step out of the weights (the likelihood kernels add them once per
+    // track): the records this position combines went through len - 2 (end positions) or len - 3 steps together
+    const double wconst = -0.5 * D * log(2.0 * M_PI) * (double)((k == 0 || k == L - 1) ? L - 2 : L - 3);
+    auto put = [&](double w, const double* mu, double var) {
+        for (int d = 0; d < D; ++d) a.comp_mean[(row * a.N + x) * D + d] = mu[d];
+        a.comp_std[row * a.N + x] = sqrt(var);
+        a.comp_logw[row * a.N + x] = w + wconst;
+        ++row;
+    };
+    if (k == 0 || k == L - 1) {
+        const int cap = k == 0 ? a.cap_f : a.cap_p;
+        const double* rec = (k == 0 ? a.fut : a.past) + ((int64_t)(L - 2) * cap * R) * a.N + x;
+        const uint8_t* nw = (k == 0 ? a.fut_new : a.past_new) + (int64_t)(L - 2) * cap;
+        const int n = (k == 0 ? a.fut_cnt : a.past_cnt)[L - 2];
+        for (int q = 0; q < n; ++q) {
+            const double* r = rec + (int64_t)q * R * a.N;
+            const double lp = r[0], sd = r[(int64_t)(1 + D) * a.N], v = sd * sd + l2k, vq = sd * sd + l2q;
+            double dsq = 0.0, mu[D];
+            for (int d = 0; d < D; ++d) {
+                const double m = r[(int64_t)(1 + d) * a.N];
+                dsq += (c[d] - m) * (c[d] - m);
+                mu[d] = (m * l2k + c[d] * sd * sd) / v;
+            }
+            const double lk = -0.5 * D * log(2.0 * M_PI * v) - dsq / (2.0 * v);
+            const double lkq = -0.5 * D * log(2.0 * M_PI * vq) - dsq / (2.0 * vq);
+            // the pass from the past runs with neutral initial fractions 1 / S (refined_localization.py:216): a constant the read-out cancels
+            put(lp + lk + lkq + (k == 0 ? a.logF[nw[q]] : -log((double)a.S)), mu, l2k * sd * sd / v);
+        }
+    } else {
+        const double* rf = a.fut + ((int64_t)(L - 2 - k) * a.cap_f * R) * a.N + x;
+        const double* rp = a.past + ((int64_t)(k - 1) * a.cap_p * R) * a.N + x;
+        const uint8_t* nf = a.fut_new + (int64_t)(L - 2 - k) * a.cap_f;
+        const uint8_t* np_ = a.past_new + (int64_t)(k - 1) * a.cap_p;
+        const int n1 = a.fut_cnt[L - 2 - k], n2 = a.past_cnt[k - 1];
+        for (int st = 0; st < a.S; ++st)
+            for (int q1 = 0; q1 < n1; ++q1) {
+                if (nf[q1] != st) continue;
+                const double* r1 = rf + (int64_t)q1 * R * a.N;
+                const double lp1 = r1[0], s1 = r1[(int64_t)(1 + D) * a.N];
+                const double v12 = s1 * s1 + l2k, vA = s1 * s1 * l2k / v12;
+                double muA[D], d1 = 0.0;
+                for (int d = 0; d < D; ++d) {
+                    const double m1 = r1[(int64_t)(1 + d) * a.N];
+                    muA[d] = (m1 * l2k + c[d] * s1 * s1) / v12;
+                    d1 += (m1 - c[d]) * (m1 - c[d]);
+                }
+                const double lk1 = -0.5 * D * log(2.0 * M_PI * v12) - d1 / (2.0 * v12);
+                for (int q2 = 0; q2 < n2; ++q2) {
+                    if (np_[q2] != st) continue;
+                    const double* r2 = rp + (int64_t)q2 * R * a.N;
+                    const double s3 = r2[(int64_t)(1 + D) * a.N], v3 = vA + s3 * s3;
+                    double d2 = 0.0, mu[D];
+                    for (int d = 0; d < D; ++d) {
+                        const double m3 = r2[(int64_t)(1 + d) * a.N];
+                        d2 += (muA[d] - m3) * (muA[d] - m3);
+                        mu[d] = (muA[d] * s3 * s3 + m3 * vA) / v3;
+                    }
+                    put(lp1 + r2[0] + lk1 - 0.5 * D * log(2.0 * M_PI * v3) - d2 / (2.0 * v3), mu, vA * s3 * s3 / v3);
+                }
+            }
+    }
 }
 
 // Time-reversed copy of a bucket [N][L][D] on the device (the pass "from the future" walks the track backwards).
@@ -2139,10 +2225,18 @@ static int xt_refine_launch(extrack_ctx* ctx, const extrack_model* m, const doub
     }
 }
 
-extern "C" int extrack_refine_positions(extrack_ctx* ctx, const extrack_model* m, int32_t bucket_id, double threshold, int32_t max_nb_states,
-                                        double* mu, double* sigma)
+// Request for the mixture components (extrack_refine_pos_pdf); nullptr: the refined positions only.
+struct XtPdfOut {
+    int32_t* counts;   // [L] components per position (always filled)
+    int64_t capacity;  // rows the three arrays below hold
+    double* means;     // nullptr: counts only
+    double* stds;
+    double* logw;
+};
+
+static int xt_refine_run(extrack_ctx* ctx, const extrack_model* m, int32_t bucket_id, double threshold, int32_t max_nb_states, double* mu, double* sigma,
+                         const XtPdfOut* pdf)
 {
-    if (!ctx || !mu || !sigma) return xt_fail(ctx, EXTRACK_E_INVALID, "null argument");
     int rc = xt_validate_model(ctx, m);
     if (rc) return rc;
     if (bucket_id < 0 || bucket_id >= (int)ctx->buckets.size()) return xt_fail(ctx, EXTRACK_E_INVALID, "bucket id out of range");
@@ -2200,6 +2294,8 @@ extern "C" int extrack_refine_positions(extrack_ctx* ctx, const extrack_model* m
     const size_t per_row = (size_t)(L - 1) * (size_t)(cap[0] + cap[1]) * R * sizeof(double);
     int64_t RB = (int64_t)std::max<size_t>(XT_TH_PILOT, budget / per_row);
     RB = std::min<int64_t>(RB, b.N);
+    if (pdf && RB < b.N)
+        return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "the mixture components are returned for buckets whose records fit ONE row block (EXTRACK_REFINE_BUDGET_MB, default 16 GiB): pass fewer tracks");
     for (int pass = 0; pass < 2; ++pass) {
         if ((rc = xt_rf_reserve(ctx, XT_RF_REC0 + pass, (size_t)(L - 1) * (size_t)RB * cap[pass] * R * sizeof(double)))) return rc;
         if ((rc = xt_rf_reserve(ctx, XT_RF_NEW0 + pass, (size_t)(L - 1) * cap[pass]))) return rc;
@@ -2238,17 +2334,89 @@ extern "C" int extrack_refine_positions(extrack_ctx* ctx, const extrack_model* m
         ra.sigma = d_sig_in ? d_sig_in + (size_t)row0 * L : nullptr;
         for (int s2 = 0; s2 < S; ++s2) ra.logF[s2] = log(m->Fs[s2]);
         const int grid = (int)(((int64_t)rows * L + 255) / 256);
-        if (D == 1) hipLaunchKernelGGL(xt_refine_combine<1>, dim3(grid), dim3(256), 0, ctx->stream, ra);
-        else if (D == 2) hipLaunchKernelGGL(xt_refine_combine<2>, dim3(grid), dim3(256), 0, ctx->stream, ra);
-        else hipLaunchKernelGGL(xt_refine_combine<3>, dim3(grid), dim3(256), 0, ctx->stream, ra);
-        XT_HIP(ctx, hipGetLastError());
+        if (!pdf) {
+            if (D == 1) hipLaunchKernelGGL(xt_refine_combine<1>, dim3(grid), dim3(256), 0, ctx->stream, ra);
+            else if (D == 2) hipLaunchKernelGGL(xt_refine_combine<2>, dim3(grid), dim3(256), 0, ctx->stream, ra);
+            else hipLaunchKernelGGL(xt_refine_combine<3>, dim3(grid), dim3(256), 0, ctx->stream, ra);
+            XT_HIP(ctx, hipGetLastError());
+            continue;
+        }
+        // ---- mixture components (one row block): count them on the host from the passes' plans, then one thread per (track, position)
+        std::vector<int32_t> cnt[2];
+        std::vector<uint8_t> nw[2];
+        for (int pass = 0; pass < 2; ++pass) {
+            cnt[pass].resize(L - 1);
+            nw[pass].resize((size_t)(L - 1) * cap[pass]);
+            XT_HIP(ctx, hipMemcpyAsync(cnt[pass].data(), ctx->rf_buf[XT_RF_CNT0 + pass], (size_t)(L - 1) * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+            XT_HIP(ctx, hipMemcpyAsync(nw[pass].data(), ctx->rf_buf[XT_RF_NEW0 + pass], nw[pass].size(), hipMemcpyDeviceToHost, ctx->stream));
+        }
+        XT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        std::vector<int64_t> off(L + 1, 0);
+        for (int k = 0; k < L; ++k) {
+            int64_t n = 0;
+            if (k == 0 || k == L - 1) {
+                n = cnt[k == 0 ? 0 : 1][L - 2];
+            } else {
+                for (int st = 0; st < S; ++st) {
+                    int64_t n1 = 0, n2 = 0;
+                    for (int q = 0; q < cnt[0][L - 2 - k]; ++q) n1 += nw[0][(size_t)(L - 2 - k) * cap[0] + q] == st;
+                    for (int q = 0; q < cnt[1][k - 1]; ++q) n2 += nw[1][(size_t)(k - 1) * cap[1] + q] == st;
+                    n += n1 * n2;
+                }
+            }
+            if (n > INT32_MAX) return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "too many mixture components at one position");
+            pdf->counts[k] = (int32_t)n;
+            off[k + 1] = off[k] + n;
+        }
+        if (!pdf->means) continue;
+        if (off[L] > pdf->capacity) return xt_fail(ctx, EXTRACK_E_INVALID, "mixture component arrays too small (sum of the counts of a counts-only call)");
+        const size_t rows_c = (size_t)off[L] * (size_t)rows;
+        double* d_comp = nullptr;
+        int64_t* d_off = nullptr;
+        hipError_t e = hipMalloc(&d_comp, std::max<size_t>(rows_c, 1) * (D + 2) * sizeof(double));
+        if (e == hipSuccess) e = hipMalloc(&d_off, (size_t)(L + 1) * sizeof(int64_t));
+        if (e == hipSuccess) e = hipMemcpyAsync(d_off, off.data(), (size_t)(L + 1) * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) {
+            ra.comp_off = d_off;
+            ra.comp_mean = d_comp;
+            ra.comp_std = d_comp + rows_c * D;
+            ra.comp_logw = d_comp + rows_c * (D + 1);
+            if (D == 1) hipLaunchKernelGGL(xt_refine_components<1>, dim3(grid), dim3(256), 0, ctx->stream, ra);
+            else if (D == 2) hipLaunchKernelGGL(xt_refine_components<2>, dim3(grid), dim3(256), 0, ctx->stream, ra);
+            else hipLaunchKernelGGL(xt_refine_components<3>, dim3(grid), dim3(256), 0, ctx->stream, ra);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess && rows_c) e = hipMemcpyAsync(pdf->means, ra.comp_mean, rows_c * D * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess && rows_c) e = hipMemcpyAsync(pdf->stds, ra.comp_std, rows_c * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess && rows_c) e = hipMemcpyAsync(pdf->logw, ra.comp_logw, rows_c * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        (void)hipFree(d_comp);
+        (void)hipFree(d_off);
+        if (e != hipSuccess) return xt_fail(ctx, EXTRACK_E_HIP, std::string("mixture components: ") + hipGetErrorString(e));
     }
     XT_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     ctx->timed = true;
-    XT_HIP(ctx, hipMemcpyAsync(mu, d_mu, nel * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    XT_HIP(ctx, hipMemcpyAsync(sigma, d_sig, (size_t)b.N * L * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (!pdf) {
+        XT_HIP(ctx, hipMemcpyAsync(mu, d_mu, nel * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        XT_HIP(ctx, hipMemcpyAsync(sigma, d_sig, (size_t)b.N * L * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    }
     XT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return EXTRACK_OK;
+}
+
+extern "C" int extrack_refine_positions(extrack_ctx* ctx, const extrack_model* m, int32_t bucket_id, double threshold, int32_t max_nb_states,
+                                        double* mu, double* sigma)
+{
+    if (!ctx || !mu || !sigma) return xt_fail(ctx, EXTRACK_E_INVALID, "null argument");
+    return xt_refine_run(ctx, m, bucket_id, threshold, max_nb_states, mu, sigma, nullptr);
+}
+
+extern "C" int extrack_refine_pos_pdf(extrack_ctx* ctx, const extrack_model* m, int32_t bucket_id, double threshold, int32_t max_nb_states,
+                                      int32_t* counts, int64_t capacity, double* means, double* stds, double* logw)
+{
+    if (!ctx || !counts || capacity < 0 || (means && (!stds || !logw))) return xt_fail(ctx, EXTRACK_E_INVALID, "null argument");
+    XtPdfOut pdf = {counts, capacity, means, stds, logw};
+    return xt_refine_run(ctx, m, bucket_id, threshold, max_nb_states, nullptr, nullptr, &pdf);
 }
 
 extern "C" int extrack_th_plan_step(extrack_ctx* ctx, int32_t bucket_id, int64_t chunk_index, int32_t t, int32_t* n_expanded,

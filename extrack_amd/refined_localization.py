@@ -12,7 +12,7 @@ import numpy as np
 
 from .engine import TrackSet
 
-__all__ = ["position_refinement"]
+__all__ = ["position_refinement", "get_pos_PDF"]
 
 
 def position_refinement(all_tracks, LocErr, ds, Fs, TrMat, frame_len=7, threshold=0.1, max_nb_states=1000, device=0):
@@ -48,3 +48,28 @@ def position_refinement(all_tracks, LocErr, ds, Fs, TrMat, frame_len=7, threshol
         finally:
             ts.close()
     return all_mus, all_sigmas
+
+
+def get_pos_PDF(Cs, LocErr, ds, Fs, TrMat, frame_len=7, threshold=0.2, max_nb_states=1000, device=0):
+    """Mirror of extrack/refined_localization.py:207-298 for one array of tracks ``Cs[n_tracks, len, dims]``: the Gaussian mixture that
+    describes every position given all the others.  ``LocErr``: the 3-D array position_refinement hands over (``[[[error]]]`` or per-peak
+    ``[n_tracks, len, 1]``) or a float.  Returns ``(all_pos_means, all_pos_stds, all_pos_weights)``: lists over the positions of
+    ``[n_tracks, n_comp, dims]``, ``[n_tracks, n_comp, 1]``, ``[n_tracks, n_comp]`` (log-weights), components in the reference's order.
+    Meant for inspection: every component of every track is copied to the host (position_refinement never materialises them)."""
+    Cs = np.asarray(Cs, dtype=np.float64)
+    if Cs.ndim != 3 or Cs.shape[1] < 2 or len(Cs) == 0:
+        raise ValueError("Cs must be a non-empty array [n_tracks, len >= 2, dims]")
+    le = np.asarray(LocErr, dtype=np.float64)
+    per_peak = le.ndim == 3 and le.shape[1] == Cs.shape[1] and le.shape[1] > 1
+    if per_peak:
+        if le.shape != (Cs.shape[0], Cs.shape[1], 1):
+            raise ValueError("per-peak localisation errors must be an array [n_tracks, len, 1] matching Cs")
+    elif le.size != 1:
+        raise ValueError("LocErr must be one global localisation error or per-peak errors [n_tracks, len, 1]")
+    ts = TrackSet([Cs], [le] if per_peak else None, device=device)
+    try:
+        model = ts.make_model(None if per_peak else le.reshape(1, 1, 1), np.asarray(ds, float), np.asarray(Fs, float), np.asarray(TrMat, float), 0.0, [], 1,
+                              frame_len)
+        return ts.ctx.refine_pos_pdf(model, 0, threshold, max_nb_states)
+    finally:
+        ts.close()

@@ -31,6 +31,9 @@
  *       (histograms.py:294-373) accumulates over chunks of 50 tracks.
  *   extrack_refine_positions
  *       get_pos_PDF + the weighted read-out of position_refinement for one bucket (extrack/refined_localization.py:207-338).
+ *   extrack_refine_pos_pdf
+ *       get_pos_PDF's own return values (extrack/refined_localization.py:207-298): means / stds / log-weights of every component of the
+ *       Gaussian mixture of every position, for inspection of small buckets.
  *   extrack_loglik_grad
  *       extrack_loglik AND its exact gradient in one pass.  It replaces the finite-difference loop that the reference's
  *       optimiser runs around cum_Proba_Cs (lmfit.minimize at extrack/tracking.py:1371: BFGS evaluates the objective
@@ -225,6 +228,16 @@ int extrack_segment_len_hist(extrack_ctx* ctx, const extrack_model* model, int32
  * locerr_dims 1), frame_len; nb_substeps must be 1; p_stay / pBL / min_len / max_len are not used.  Tracks need >= 3 positions. */
 int extrack_refine_positions(extrack_ctx* ctx, const extrack_model* model, int32_t bucket_id, double threshold, int32_t max_nb_states,
                              double* mu, double* sigma);
+
+/* The mixture extrack_refine_positions reads out, as get_pos_PDF returns it (extrack/refined_localization.py:207-298: all_pos_means,
+ * all_pos_stds, all_pos_weights).  counts host [len]: components of every position, in the reference's order (end positions: the
+ * sequences of the pass's last record; between: for every state, sequences from the future x sequences from the past that agree on it).
+ * With cum[k] = counts[0] + ... + counts[k - 1], component j of position k of track x is means[((cum[k] + j) * n + x) * dims + d],
+ * stds / logw[(cum[k] + j) * n + x] (host; `capacity` = rows each array holds >= the sum of the counts).  means == NULL: counts only
+ * (the sizing call).  Same model fields and limits as extrack_refine_positions; the bucket's records must fit one row block
+ * (EXTRACK_REFINE_BUDGET_MB), EXTRACK_E_UNSUPPORTED otherwise - the components of a large bucket are not meant to leave the GPU. */
+int extrack_refine_pos_pdf(extrack_ctx* ctx, const extrack_model* model, int32_t bucket_id, double threshold, int32_t max_nb_states,
+                           int32_t* counts, int64_t capacity, double* means, double* stds, double* logw);
 
 /* Threshold-fusion log-likelihood (the kernel extrack.tracking.param_fitting / cum_Proba_Cs call in v1.6.3,
  * extrack/tracking.py:427-743).  Which state sequences are merged at a step is decided from the first 30 tracks

@@ -117,3 +117,46 @@ def test_position_refinement_per_peak_larger_bucket_in_row_blocks():
     finally:
         del os.environ["EXTRACK_REFINE_BUDGET_MB"]
     assert np.array_equal(mb[key], mus[key]) and np.array_equal(sb[key], sigs[key])
+
+
+def test_get_pos_pdf_components_golden():
+    """get_pos_PDF's return values through extrack_refine_pos_pdf (round 4): 40 reference-generated buckets (2 - 11 positions, 1 - 36 tracks,
+    global and per-peak errors): the number of components of every position exactly, means / stds to 1e-9, log-weights to 1e-8; the
+    read-out of the components reproduces position_refinement."""
+    from extrack_amd import refined_localization as RL
+    meta = json.load(open(os.path.join(GOLDEN, "refine_pdf_cases.json")))
+    data = np.load(os.path.join(GOLDEN, "refine_pdf_cases.npz"))
+    worst = 0.0
+    for row in meta:
+        pre = "d%04d_" % row["id"]
+        g = lambda k: data[pre + k]
+        means, stds, wts = RL.get_pos_PDF(g("Cs"), g("sigma"), g("ds"), g("Fs"), g("T"), row["F"], row["threshold"], row["max_nb_states"])
+        assert [w.shape[1] for w in wts] == list(g("counts")), row
+        assert all(s.shape == w.shape + (1,) for s, w in zip(stds, wts)) and all(m.shape[:2] == w.shape for m, w in zip(means, wts))
+        dm = np.abs(np.concatenate(means, 1) - g("means")).max()
+        dsg = np.abs(np.concatenate([s[:, :, 0] for s in stds], 1) - g("stds")).max()
+        dw = np.abs(np.concatenate(wts, 1) - g("logw")).max()
+        assert dm < 1e-9 and dsg < 1e-9 and dw < 1e-8, (row, dm, dsg, dw)
+        worst = max(worst, dm, dsg, dw)
+    assert len(meta) == 40
+    print("get_pos_PDF cases", len(meta), "worst difference", worst)
+    # read-out of the components (refined_localization.py:329-337) = position_refinement on the same bucket
+    row = meta[12]
+    g = lambda k: data["d%04d_" % row["id"] + k]
+    key = str(row["L"])
+    le = {key: g("sigma")} if row["per_peak"] else float(g("sigma").ravel()[0])
+    mus, sigs = RL.position_refinement({key: g("Cs")}, le, g("ds"), g("Fs"), g("T"), row["F"], row["threshold"], row["max_nb_states"])
+    means, stds, wts = RL.get_pos_PDF(g("Cs"), g("sigma"), g("ds"), g("Fs"), g("T"), row["F"], row["threshold"], row["max_nb_states"])
+    for k, (pm, ps, pw) in enumerate(zip(means, stds, wts)):
+        P = np.exp(pw - pw.max(1, keepdims=True))
+        assert np.abs((P[:, :, None] * pm).sum(1) / P.sum(1)[:, None] - mus[key][:, k]).max() < 1e-12
+        assert np.abs(((P * ps[:, :, 0] ** 2).sum(1) / P.sum(1)) ** 0.5 - sigs[key][:, k]).max() < 1e-12
+    # a bucket whose records do not fit one row block is refused (the components of a large bucket are not meant to leave the GPU)
+    from extrack_amd import _lib
+    os.environ["EXTRACK_REFINE_BUDGET_MB"] = "1"
+    try:
+        rng = np.random.default_rng(0)
+        with pytest.raises(_lib.ExtrackError):
+            RL.get_pos_PDF(np.cumsum(rng.normal(0, 0.05, (3000, 30, 2)), 1), 0.02, [0.01, 0.09], [0.5, 0.5], np.array([[0.9, 0.1], [0.1, 0.9]]), 6, 0.1, 100)
+    finally:
+        del os.environ["EXTRACK_REFINE_BUDGET_MB"]
