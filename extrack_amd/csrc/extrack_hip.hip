@@ -1259,7 +1259,7 @@ static int xt_th_run_group(extrack_ctx* ctx, const extrack_model* m, const std::
         if ((rc = xt_th_upload_small(ctx, (void**)&ctx->d_th_cend, &ctx->th_cend_cap, chunk_end.data(), chunk_end.size() * sizeof(int32_t)))) return rc;
         a.buckets = ctx->d_th_desc;
         a.chunk_end = ctx->d_th_cend;
-        const int grid = (int)std::min<int64_t>(a.nchunks, (int64_t)ctx->n_cu * 2);
+        int grid = (int)std::min<int64_t>(a.nchunks, (int64_t)ctx->n_cu * 2);
         // pilot-track state: in LDS when the sequence counts of the previous evaluation (+25 %) fit 64 KiB, else in a global
         // workspace sized for the full plan capacity
         size_t lds = (size_t)xt_th_plan_lds_doubles(S, G, capE, D, K) * sizeof(double);
@@ -1278,6 +1278,10 @@ static int xt_th_run_group(extrack_ctx* ctx, const extrack_model* m, const std::
             }
         }
         a.ws_lds = lds_mode ? 1 : 0;
+        // more expanded sequences per step than the LDS holds plan arrays for (4 states x 3 substeps: 4^4 x 4^3 = 16 384 at the second position):
+        // the per-step plan arrays move to the global workspace too
+        a.plan_glb = (!lds_mode && capE > XT_TH_MAXCAP) ? 1 : 0;
+        if (a.plan_glb) lds = (size_t)xt_th_plan_lds_doubles(S, G, capE, D, K, XT_TH_CMAT_WORDS, true) * sizeof(double);
         a.stP = a.stE = 0;
         if (lds_mode && ctx->th_stage_in_lds_mode) {
             const size_t st = (size_t)a.pcap * ((size_t)a.wsP * D + (size_t)a.wsE * K) * sizeof(double);
@@ -1297,8 +1301,11 @@ static int xt_th_run_group(extrack_ctx* ctx, const extrack_model* m, const std::
                 lds += st;
             }
         }
-        a.ws_stride = xt_th_ws_doubles(a.wsP, a.wsE, D, K, F, NS, S, a.pcap);
+        a.ws_stride = xt_th_ws_doubles(a.wsP, a.wsE, D, K, F, NS, S, a.pcap) + (a.plan_glb ? xt_th_plan_glb_doubles(capE) : 0);
         if (!lds_mode) {
+            // the compatibility bit matrix of a workgroup grows with capE^2 (32 MiB at 16 384): fewer workgroups in flight keep the workspace below ~24 GiB
+            const size_t per_wg = (size_t)a.ws_stride * sizeof(double);
+            grid = (int)std::max<size_t>(1, std::min<size_t>((size_t)grid, ((size_t)24 << 30) / per_wg));
             const size_t need = (size_t)a.ws_stride * grid * sizeof(double);
             if (need > ctx->th_ws_cap) {
                 XT_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1361,8 +1368,8 @@ static int xt_th_run_group(extrack_ctx* ctx, const extrack_model* m, const std::
         int ncap = capE;
         while (ncap < std::max(maxE, maxG)) ncap *= 2;
         if (ncap == capE) ncap *= 2;
-        if (ncap > XT_TH_MAXCAP)
-            return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "more than 8192 live state sequences per step (threshold fusion expands every sequence by n_states^nb_substeps before it merges): raise threshold, lower max_nb_states or nb_substeps - or use the fixed-window kernel (fusion='window' / extrack_loglik), which serves this model");
+        if (ncap > XT_TH_MAXCAP_FIT)
+            return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "more than 32768 live state sequences per step (threshold fusion expands every sequence by n_states^nb_substeps before it merges): raise threshold, lower max_nb_states or nb_substeps - or use the fixed-window kernel (fusion='window' / extrack_loglik), which serves this model");
         ctx->th_capE = ncap;
     }
     if (after_plan) return (*after_plan)(a, D, K, maxG, Lmax);  // the plan is all the caller wanted (frozen-plan gradient, extrack_thgrad.hip)

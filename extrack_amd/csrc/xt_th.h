@@ -61,7 +61,8 @@
     } while (0)
 #endif
 #define XT_TH_STAGE 8   // positions staged in LDS per refill (apply kernel)
-#define XT_TH_MAXCAP 8192
+#define XT_TH_MAXCAP 8192       // expanded sequences per step whose plan arrays (10 B each) stay in LDS: prediction / refinement modes stop here
+#define XT_TH_MAXCAP_FIT 32768  // likelihood (fit) mode: beyond XT_TH_MAXCAP the per-step plan arrays move to the global workspace (XtThArgs::plan_glb)
 #define XT_TH_CMAT_WORDS 2048  // LDS budget (32-bit words) of the pivot -> candidate compatibility bit matrix
 #define XT_TH_GPW 4      // single-buffer apply kernel: merge groups per wavefront held in registers
 
@@ -121,6 +122,8 @@ struct XtThArgs {
     int32_t pair_lanes_max_p;  // pilot counts up to this use one lane per (pivot, candidate) pair in the grouping, more use ballots
     int32_t stP, stE;      // global workspace only: capacities of the LDS staging copy of the pilots' means / stds that the
                            // grouping reads (0: none); steps with more sequences read the workspace directly
+    int32_t plan_glb;      // 1 (global workspace, fit mode only): the per-step plan arrays (member words, newest states, member / group-start
+                           // lists: 10 B per expanded sequence) live at the head of the workgroup's workspace slice instead of LDS - capE > XT_TH_MAXCAP
     double* seq_out;            // single-bucket form of XtThBucket::seq_out / seq_stride
     int32_t seq_stride;
     const XtThBucket* buckets;  // device array [nbuckets], or nullptr: the single bucket described by the fields above
@@ -286,13 +289,14 @@ XT_HD int64_t xt_th_ws_doubles(int wsP, int wsE, int D, int K, int F, int NS, in
     if (preds) n += (int64_t)pcap * wsE + ((int64_t)pcap * wsE + 1) / 2 + 2 * (int64_t)pcap * wsP + 8;
     return n;
 }
-XT_HD int xt_th_plan_lds_doubles(int S, int G, int capE, int D, int K, int cmat_words = XT_TH_CMAT_WORDS)
+XT_HD int64_t xt_th_plan_glb_doubles(int capE) { return (10 * (int64_t)capE + 2 + 7) / 8 + 2; }
+XT_HD int xt_th_plan_lds_doubles(int S, int G, int capE, int D, int K, int cmat_words = XT_TH_CMAT_WORDS, bool plan_glb = false)
 {
     // tables | per-track scalars | wave counts | compatibility bit matrix + grouped flags | bytes: mpk u32[capE], newest[2][capE],
-    // mem u16[capE], gst u16[capE + 1]
+    // mem u16[capE], gst u16[capE + 1] (plan_glb: those in the global workspace)
     (void)D;
     (void)K;
-    const int bytes = 4 * capE + 2 * capE + 2 * capE + 2 * (capE + 1);
+    const int bytes = plan_glb ? 0 : 4 * capE + 2 * capE + 2 * capE + 2 * (capE + 1);
     return ((xt_tab_doubles(S, G) + 1) & ~1) + XT_TH_PILOT + 8 + (cmat_words + 1) / 2 + (capE + 63) / 64 + 1 + (bytes + 7) / 8 + 2;
 }
 XT_HD int xt_th_apply_lds_doubles(int S, int G, int capG, int TT, int D, int K, int KS, int L, int plan_cap, bool uni, bool single = false)
@@ -483,22 +487,26 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
     uint32_t* cmatL = (uint32_t*)(wcnt + 16);
     const int cmw = a.cmat_words > 0 ? a.cmat_words : XT_TH_CMAT_WORDS;  // LDS words reserved for the bit matrix
     uint32_t* gbitsL = cmatL + cmw + (cmw & 1);
-    uint32_t* mpk = gbitsL + 2 * ((capE + 63) / 64) + 2;
+    double* wh = a.ws + (int64_t)cx.block() * a.ws_stride;  // [plan arrays (plan_glb)] history part (prediction mode), then the state part unless it is in LDS
+    // per-step plan arrays: LDS, or (compile-time global-workspace variant of the fit mode only, so that every other variant keeps
+    // LDS-typed pointers) the head of the workgroup's workspace slice
+    const bool plan_glb = WS == 0 && !PREDS && a.plan_glb != 0;
+    uint32_t* mpk = plan_glb ? (uint32_t*)wh : gbitsL + 2 * ((capE + 63) / 64) + 2;
     uint8_t* newA = (uint8_t*)(mpk + capE);
     uint8_t* newB = newA + capE;
     uint16_t* mem = (uint16_t*)(newB + capE);
     uint16_t* gst = mem + capE;
+    if (plan_glb) wh += xt_th_plan_glb_doubles(capE);
 
     // pilot-track state: LDS when the learned capacities fit (a.ws_lds), else this workgroup's slice of the global workspace
     // (then the grouping works on an LDS copy of the two arrays it reads over and over: pilots' means and stds)
     const int wsP = a.wsP, wsE = a.wsE, stP = a.stP, stE = a.stE;
     // staging copy: after the LDS-resident state when that is in LDS too (then it only serves to give the compiler LDS-typed
     // addresses instead of flat ones for the hot pair loop)
-    double* stM = smem + xt_th_plan_lds_doubles(S, G, capE, D, K, cmw) +
+    double* stM = smem + xt_th_plan_lds_doubles(S, G, capE, D, K, cmw, plan_glb) +
                   (ws_lds ? xt_th_ws_doubles(wsP, wsE, D, K, F, NS, S, a.pcap, PREDS) : 0);  // [PC][stP][D]
     double* stS = stM + (int64_t)a.pcap * stP * D;                  // [PC][stE][K]
-    double* wh = a.ws + (int64_t)cx.block() * a.ws_stride;  // history part (prediction mode), then the state part unless it is in LDS
-    double* w = ws_lds ? smem + xt_th_plan_lds_doubles(S, G, capE, D, K, cmw) : wh + xt_th_hist_doubles(wsE, a.pcap, PREDS, L);
+    double* w = ws_lds ? smem + xt_th_plan_lds_doubles(S, G, capE, D, K, cmw, plan_glb) : wh + xt_th_hist_doubles(wsE, a.pcap, PREDS, L);
     const int plane = PC * wsE;  // sE plane
     typedef XtThView<D, K, false> View;
     View A, B;

@@ -246,7 +246,8 @@ int extrack_refine_pos_pdf(extrack_ctx* ctx, const extrack_model* model, int32_t
  * model->frame_len is the number of most recent states whose equality forces a merge; threshold and
  * max_nb_states as in tracking.py:427 (threshold is multiplied by 1.2 at every step with more than
  * max_nb_states live sequences).  Time steps: fixed (in model->ds) or per track (extrack_set_bucket_dt).
- * total_ll / per_track as in extrack_loglik. */
+ * total_ll / per_track as in extrack_loglik.  Limit: 32 768 expanded sequences (live sequences x n_states^nb_substeps) at any step
+ * (EXTRACK_E_UNSUPPORTED beyond; 8192 for extrack_predict_th / extrack_refine_positions). */
 int extrack_loglik_th(extrack_ctx* ctx, const extrack_model* model, double threshold, int32_t max_nb_states, int32_t chunk,
                       double* total_ll, double* per_track);
 /* Same evaluation, the scalar left in device memory (d_total_ll, 8 bytes) for a following RCCL all-reduce on the context's

@@ -444,14 +444,16 @@ extern "C" int xt_emul_th_run(const double* tracks, const double* sigma, long lo
     }
     a.pcap = chunk < XT_TH_PILOT ? chunk : XT_TH_PILOT;
     a.pair_lanes_max_p = getenv("XT_EMUL_TH_PAIR_LANES") ? atoi(getenv("XT_EMUL_TH_PAIR_LANES")) : 4;
-    a.ws_stride = xt_th_ws_doubles(a.wsP, a.wsE, D, K, F, NS, S, a.pcap);
+    // per-step plan arrays in the global workspace (what the library does beyond XT_TH_MAXCAP expanded sequences; XT_EMUL_TH_PLAN_GLB forces it)
+    a.plan_glb = (!a.ws_lds && (capE > XT_TH_MAXCAP || getenv("XT_EMUL_TH_PLAN_GLB"))) ? 1 : 0;
+    a.ws_stride = xt_th_ws_doubles(a.wsP, a.wsE, D, K, F, NS, S, a.pcap) + (a.plan_glb ? xt_th_plan_glb_doubles(capE) : 0);
     std::vector<double> ws((size_t)a.ws_stride * plan_blocks, 0.0);
     a.ws = ws.data();
     if (getenv("XT_EMUL_TH_STP")) {  // exercise the LDS staging copy used with the global workspace
         a.stP = atoi(getenv("XT_EMUL_TH_STP"));
         a.stE = atoi(getenv("XT_EMUL_TH_STE"));
     }
-    const size_t plan_lds = xt_th_plan_lds_doubles(S, G, capE, D, K) +
+    const size_t plan_lds = xt_th_plan_lds_doubles(S, G, capE, D, K, XT_TH_CMAT_WORDS, a.plan_glb != 0) +
                             (a.ws_lds ? (size_t)a.ws_stride : 0) + (size_t)a.pcap * (a.stP * D + a.stE * K) + 8;
     const int plan_threads = apply_threads;  // same block size for both kernels in the emulation
 #define TH_RUN(BODY, NB, NT, LDS)                                                                             \
@@ -463,7 +465,16 @@ extern "C" int xt_emul_th_run(const double* tracks, const double* sigma, long lo
         else if (D == 3 && K == 3) th_emul_blocks(NB, NT, LDS, [&](HostCtx& cx) { BODY<3, 3, false>(a, cx); });      \
         else return -3;                                                                                       \
     } while (0)
-    TH_RUN(xt_th_plan_body, plan_blocks, plan_threads, plan_lds);
+    if (a.plan_glb) {  // the compile-time global-workspace variant (the only one that honours plan_glb)
+        if (D == 1 && K == 1) th_emul_blocks(plan_blocks, plan_threads, plan_lds, [&](HostCtx& cx) { xt_th_plan_body<1, 1, false, 0>(a, cx); });
+        else if (D == 2 && K == 1) th_emul_blocks(plan_blocks, plan_threads, plan_lds, [&](HostCtx& cx) { xt_th_plan_body<2, 1, false, 0>(a, cx); });
+        else if (D == 2 && K == 2) th_emul_blocks(plan_blocks, plan_threads, plan_lds, [&](HostCtx& cx) { xt_th_plan_body<2, 2, false, 0>(a, cx); });
+        else if (D == 3 && K == 1) th_emul_blocks(plan_blocks, plan_threads, plan_lds, [&](HostCtx& cx) { xt_th_plan_body<3, 1, false, 0>(a, cx); });
+        else if (D == 3 && K == 3) th_emul_blocks(plan_blocks, plan_threads, plan_lds, [&](HostCtx& cx) { xt_th_plan_body<3, 3, false, 0>(a, cx); });
+        else return -3;
+    } else {
+        TH_RUN(xt_th_plan_body, plan_blocks, plan_threads, plan_lds);
+    }
     if (hdr_out) memcpy(hdr_out, hdr.data(), hdr.size() * sizeof(int32_t));
     if (members_out) memcpy(members_out, mem.data(), mem.size() * sizeof(uint16_t));
     if (gstart_out) memcpy(gstart_out, gst.data(), gst.size() * sizeof(uint16_t));

@@ -215,3 +215,51 @@ def test_th_bodies_with_per_track_time_steps():
             nll += 1
     assert nll >= 10 and npr >= 10 and worst_ll < 1e-10 and worst_pr < 1e-9, (nll, npr, worst_ll, worst_pr)
     print("dt cases: LL", nll, worst_ll, "posteriors", npr, worst_pr)
+
+
+def test_th_plan_arrays_in_global_workspace(monkeypatch):
+    """The per-step plan arrays (member words, newest states, member / group-start lists) at the head of the global workspace instead of
+    LDS - what the library does beyond 8192 expanded sequences per step - forced on a 3-state case: groups identical to the oracle's."""
+    monkeypatch.setenv("XT_EMUL_TH_PLAN_GLB", "1")
+    E = _emul()
+    rng = np.random.default_rng(6)
+    S, ns, F, L, N = 3, 1, 5, 8, 33
+    ds = np.array([0.004, 0.03, 0.11])
+    Fs = np.array([0.3, 0.3, 0.4])
+    T = np.array([[0.9, 0.07, 0.03], [0.05, 0.9, 0.05], [0.03, 0.07, 0.9]])
+    Cs = np.cumsum(rng.normal(0, 1, (N, L, 2)) * ds[rng.integers(0, S, (N, L, 1))], 1) + rng.normal(0, 0.02, (N, L, 2))
+    LE = np.full((1, 1, 1), 0.02)
+    ps = p_stay_table(ds, S, ns, [1.0])
+    tr = []
+    ref = OT.proba_cs_th(Cs, LE, ds, Fs, T, 0.1, 1, [1.0], ns, F, 5, 0.15, 60)
+    OT.p_cs_inter_bound_stats_th(Cs, LE, ds, Fs, T, 0.1, 1, [1.0], ns, F, 0, 5, 0.15, 60, trace=tr)
+    ll, tot, plan, hdr, status = E.run_th(Cs, LE, ds, Fs, T, 0.1, 1, ps, ns, F, 5, 0.15, 60, chunk=N, capE=512, TT=8, threads=128, nblocks=1)
+    assert status[:, 0].max() == 0
+    for i, t in enumerate(range(2, L - 1)):
+        assert [list(g) for g in tr[i]] == [list(g) for g in plan[0][t]], t
+    assert np.abs(ll - ref).max() < 1e-10
+
+
+@pytest.mark.skipif(not os.environ.get("XT_SLOW_TESTS"), reason="2 minutes of CPU-thread emulation (16 384 sequences): XT_SLOW_TESTS=1; the GPU suite runs the same case")
+def test_th_more_than_8192_expanded_sequences():
+    """4 states x 3 substeps (the C5 model): 4^4 = 256 sequences after the first position, 256 x 4^3 = 16 384 expanded at the second - beyond
+    the 8192 whose plan arrays fit the LDS (refused until round 4).  Merge groups identical to the oracle's, LL within 1e-10."""
+    E = _emul()
+    rng = np.random.default_rng(12)
+    S, ns, F, L, N = 4, 3, 4, 4, 3
+    ds = np.array([0.003, 0.02, 0.06, 0.15])
+    Fs = np.array([0.25, 0.3, 0.2, 0.25])
+    T = np.full((S, S), 0.02) + np.diag([0.01, 0.0, 0.015, 0.005])
+    T[np.arange(S), np.arange(S)] = 0
+    T[np.arange(S), np.arange(S)] = 1 - T.sum(1)
+    Cs = np.cumsum(rng.normal(0, 1, (N, L, 2)) * ds[rng.integers(0, S, (N, L, 1))], 1) + rng.normal(0, 0.02, (N, L, 2))
+    LE = np.full((1, 1, 1), 0.02)
+    ps = p_stay_table(ds, S, ns, [1.0])
+    tr = []
+    ref = OT.proba_cs_th(Cs, LE, ds, Fs, T, 0.1, 1, [1.0], ns, F, 3, 0.3, 120)
+    OT.p_cs_inter_bound_stats_th(Cs, LE, ds, Fs, T, 0.1, 1, [1.0], ns, F, 0, 3, 0.3, 120, trace=tr)
+    ll, tot, plan, hdr, status = E.run_th(Cs, LE, ds, Fs, T, 0.1, 1, ps, ns, F, 3, 0.3, 120, chunk=N, capE=16384, TT=1, threads=256, nblocks=1)
+    assert status[:, 0].max() == 0 and status[0, 1] == 16384, status
+    for i, t in enumerate(range(2, L - 1)):
+        assert [list(g) for g in tr[i]] == [list(g) for g in plan[0][t]], t
+    assert np.abs(ll - ref).max() < 1e-10
