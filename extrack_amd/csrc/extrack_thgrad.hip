@@ -5,6 +5,7 @@
 
 #include "xt_grad_host.h"
 #include "xt_thgrad.h"
+#include "xt_thgrad2.h"
 
 // one lane per track; state in a per-wavefront region of global memory (coalesced rows, served by L2 / Infinity Cache): the kernel is bound
 // by memory latency - what counts is the number of wavefronts a CU holds (registers: XT_THG_WAVES per SIMD; LDS: the accumulator rows)
@@ -17,6 +18,19 @@ __global__ void __launch_bounds__(256, RG ? XT_THG_WAVES : 1) xt_thg_kernel(XtTh
     DevCtx cx;
     xt_thg_body<D, K, RG>(a, ga, cx);
 }
+// second mapping (xt_thgrad2.h): lanes = (sequence, track), live state in LDS, one log record per (step, merged sequence, track)
+#ifndef XT_THG2_WAVES
+#define XT_THG2_WAVES 2
+#endif
+template <int D, int K, int NE>
+__global__ void __launch_bounds__(256, XT_THG2_WAVES) xt_thg2_kernel(XtThArgs a, XtThGradArgs ga)
+{
+    DevCtx cx;
+    xt_thg2_body<D, K, NE>(a, ga, cx);
+}
+template <int D, int K>
+static const void* xt_thg2_kernel_ptr(int ne) { return ne <= 1 ? (const void*)xt_thg2_kernel<D, K, 1> : (const void*)xt_thg2_kernel<D, K, 4>; }
+
 template <int D, int K>
 static const void* xt_thg_kernel_ptr(bool rg) { return rg ? (const void*)xt_thg_kernel<D, K, true> : (const void*)xt_thg_kernel<D, K, false>; }
 
@@ -83,6 +97,79 @@ static int xt_th_grad_enqueue(extrack_ctx* ctx, const extrack_model* m, double t
         memset(&ga, 0, sizeof(ga));
         ga.TB = TB;
         ga.capP = std::max(maxG, S);
+        // ---- the (sequence, track)-lane kernel (xt_thgrad2.h) for models with few live sequences.  Measured (MI355X, 1e6 tracks): 2 states x 30
+        // positions, 12 live sequences: 15.0 ms against 23.9 ms of the one-lane-per-track kernel below (256 threads, 64 tracks per tile, 4 lanes
+        // per track; 128:32 16.6, 256:32 18.0, 64:16 20.6 ms); 3 states, lengths 5 - 50, ~33 live sequences: 52.8 ms at best (128 threads, 8
+        // tracks) against 51 ms - the tile's LDS (14 doubles per sequence and track) leaves 6 wavefronts per CU, the kernel below wins or ties.
+        // EXTRACK_THG_KERNEL=1 | 2 forces one, EXTRACK_THG2_THREADS / _TT / _LDS_KB set the tile
+        {
+            int want = ga.capP <= 16 ? 2 : 1;
+            if (const char* ev = getenv("EXTRACK_THG_KERNEL")) want = atoi(ev);
+            int NT = 256;
+            if (const char* ev = getenv("EXTRACK_THG2_THREADS")) NT = atoi(ev) == 64 ? 64 : (atoi(ev) == 128 ? 128 : 256);
+            int lpt = 4;
+            while (lpt < S) lpt *= 2;  // few lanes per track (every lane walks several sequences): what the sweep above favours
+            int TT = std::max(2, std::min(64, NT / lpt));
+            if (const char* ev = getenv("EXTRACK_THG2_TT")) TT = std::max(2, std::min(64, atoi(ev)));
+            while (TT & (TT - 1)) TT &= TT - 1;
+            auto lds2 = [&](int tt) { return (size_t)xt_thg2_lds_doubles(S, G, ga.capP, a.capE, tt, D, K, NT, TB) * sizeof(double); };
+            size_t lds_cap = 80 * 1024;  // two workgroups per CU
+            if (const char* ev = getenv("EXTRACK_THG2_LDS_KB")) lds_cap = (size_t)std::max(16, std::min(160, atoi(ev))) * 1024;
+            while (TT > 2 && lds2(TT) > lds_cap) TT >>= 1;
+            const int LPT = NT / TT;
+            if (want == 2 && lds2(TT) <= lds_cap && LPT >= S && S * G <= 4 * LPT && a.capE <= 4096) {
+                const size_t lds = lds2(TT);
+                a.TT = TT;
+                a.logTT = 0;
+                while ((1 << a.logTT) < TT) ++a.logTT;
+                ga.ws_stride = xt_thg2_ws_doubles(ga.capP, Lmax, TT, D, K, G);
+                const int blocks_per_cu = (int)std::max<size_t>(1, std::min<size_t>((size_t)XT_THG2_WAVES * 256 / NT, (160 * 1024) / lds));
+                const int64_t tpc = ((int64_t)a.chunk + TT - 1) / TT;  // tiles per chunk
+                int64_t target = (int64_t)ctx->n_cu * blocks_per_cu * 2;
+                int64_t bpc = std::max<int64_t>(1, std::min<int64_t>((target + a.nchunks - 1) / a.nchunks, tpc));
+                a.bpc = (int32_t)bpc;
+                const int grid = (int)(a.nchunks * bpc);
+                int rc2;
+                if ((rc2 = xt_thg_reserve(ctx, &ctx->d_revlog, &ctx->revlog_cap, (size_t)grid * (size_t)ga.ws_stride))) return rc2;
+                const size_t need = (rows + (size_t)grid) * (size_t)(1 + TB);
+                if (need > ctx->gpartials_cap) {
+                    double* nw = nullptr;
+                    XT_HIP(ctx, hipMalloc(&nw, need * 2 * sizeof(double)));
+                    if (ctx->d_gpartials) {
+                        if (rows) XT_HIP(ctx, hipMemcpyAsync(nw, ctx->d_gpartials, rows * (size_t)(1 + TB) * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+                        XT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                        (void)hipFree(ctx->d_gpartials);
+                    }
+                    ctx->d_gpartials = nw;
+                    ctx->gpartials_cap = need * 2;
+                }
+                ga.ws = ctx->d_revlog;
+                ga.gpartials = ctx->d_gpartials + rows * (size_t)(1 + TB);
+                const int ne = S * G <= LPT ? 1 : 4;
+                const void* kp = nullptr;
+                if (D == 1 && K == 1) kp = xt_thg2_kernel_ptr<1, 1>(ne);
+                else if (D == 2 && K == 1) kp = xt_thg2_kernel_ptr<2, 1>(ne);
+                else if (D == 2 && K == 2) kp = xt_thg2_kernel_ptr<2, 2>(ne);
+                else if (D == 3 && K == 1) kp = xt_thg2_kernel_ptr<3, 1>(ne);
+                else if (D == 3 && K == 3) kp = xt_thg2_kernel_ptr<3, 3>(ne);
+                else return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "frozen-plan gradient: track / error dimensionality not built");
+                if (lds > 64 * 1024) XT_HIP(ctx, hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                void* kargs[2] = {(void*)&a, (void*)&ga};
+                XT_HIP(ctx, hipLaunchKernel(kp, dim3(grid), dim3(NT), kargs, lds, ctx->stream));
+                XT_HIP(ctx, hipGetLastError());
+                rows += (size_t)grid;
+                ctx->launch_info[0] = grid;
+                ctx->launch_info[1] = NT;
+                ctx->launch_info[2] = (int32_t)lds;
+                ctx->launch_info[3] = TT;
+                ctx->launch_info[4] = blocks_per_cu;
+                ctx->launch_info[5] = ctx->n_cu;
+                if (getenv("EXTRACK_TH_DEBUG"))
+                    fprintf(stderr, "[thgrad2] chunks %d maxG %d Lmax %d | threads %d TT %d lanes/track %d lds %zu bpc %d grid %d log/block %.2f MB total %.1f MB\n", a.nchunks, maxG, Lmax,
+                            NT, TT, LPT, lds, a.bpc, grid, ga.ws_stride * 8.0 / 1048576.0, grid * ga.ws_stride * 8.0 / 1048576.0);
+                return EXTRACK_OK;
+            }
+        }
         // wavefronts per workgroup: the accumulator rows of a wavefront decide how many wavefronts a CU holds
         const size_t row_bytes = (size_t)xt_thg_rows(S, G) * 64 * sizeof(double);
         int rows_global = row_bytes > 16 * 1024 ? 1 : 0;

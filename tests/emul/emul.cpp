@@ -24,6 +24,7 @@
 #include "../../extrack_amd/csrc/xt_tables.h"
 #include "../../extrack_amd/csrc/xt_th.h"
 #include "../../extrack_amd/csrc/xt_thgrad.h"
+#include "../../extrack_amd/csrc/xt_thgrad2.h"
 #include "../../extrack_amd/csrc/xt_big.h"
 
 struct EmulLauncher {
@@ -549,6 +550,28 @@ extern "C" int xt_emul_th_run(const double* tracks, const double* sigma, long lo
         ga.ws = gws.data();
         ga.gpartials = gp.data();
         a.ll_out = g_thg_ll;
+        int nrows = grid * NW;
+        const int TT2 = getenv("XT_EMUL_THG2") ? atoi(getenv("XT_EMUL_THG2")) : 0;  // tracks per tile of the (sequence, track)-lane body (xt_thgrad2.h)
+        if (TT2 > 0) {
+            a.TT = TT2;
+            a.logTT = 0;
+            while ((1 << a.logTT) < TT2) ++a.logTT;
+            const int threads2 = 64 * NW, LPT = threads2 / TT2;
+            if (LPT < S || S * G > 4 * LPT) return -8;
+            ga.ws_stride = xt_thg2_ws_doubles(ga.capP, L, TT2, D, K, G);
+            gws.assign((size_t)ga.ws_stride * grid, xt_emul_poison() ? NAN : 0.0);
+            ga.ws = gws.data();
+            const size_t glds2 = (size_t)xt_thg2_lds_doubles(S, G, ga.capP, capE, TT2, D, K, threads2, TB);
+#define TH_GRAD2(DD, KK) th_emul_blocks(grid, threads2, glds2, [&](HostCtx& cx) { if (S * G <= LPT) xt_thg2_body<DD, KK, 1>(a, ga, cx); else xt_thg2_body<DD, KK, 4>(a, ga, cx); })
+            if (D == 1 && K == 1) TH_GRAD2(1, 1);
+            else if (D == 2 && K == 1) TH_GRAD2(2, 1);
+            else if (D == 2 && K == 2) TH_GRAD2(2, 2);
+            else if (D == 3 && K == 1) TH_GRAD2(3, 1);
+            else if (D == 3 && K == 3) TH_GRAD2(3, 3);
+            else return -3;
+#undef TH_GRAD2
+            nrows = grid;
+        } else {
         const size_t glds = (size_t)xt_thg_lds_doubles(S, G, NW, capE, ga.rows_global != 0);
 #define TH_GRAD(DD, KK) th_emul_blocks(grid, 64 * NW, glds, [&](HostCtx& cx) { if (ga.rows_global) xt_thg_body<DD, KK, true>(a, ga, cx); else xt_thg_body<DD, KK, false>(a, ga, cx); })
         if (D == 1 && K == 1) TH_GRAD(1, 1);
@@ -558,9 +581,10 @@ extern "C" int xt_emul_th_run(const double* tracks, const double* sigma, long lo
         else if (D == 3 && K == 3) TH_GRAD(3, 3);
         else return -3;
 #undef TH_GRAD
+        }
         std::vector<double> adj(TB, 0.0);
         g_thg_out[0] = 0.0;
-        for (int w = 0; w < grid * NW; ++w) {
+        for (int w = 0; w < nrows; ++w) {
             g_thg_out[0] += gp[(size_t)w * (1 + TB)];
             for (int c = 0; c < TB; ++c) adj[c] += gp[(size_t)w * (1 + TB) + 1 + c];
         }

@@ -14,7 +14,7 @@ def lib():
         so = os.path.join(HERE, "libxt_emul.so")
         src = os.path.join(HERE, "emul.cpp")
         hdrs = [os.path.join(HERE, "..", "..", "extrack_amd", "csrc", h) for h in ("xt_kernel.h", "xt_math.h", "xt_tables.h", "xt_dispatch.h", "xt_th.h", "xt_entry.h", "xt_fast2.h", "xt_grad.h",
-                                                                                             "xt_grad_host.h", "xt_thgrad.h", "xt_big.h", "xt_hist.h", "xt_hist_host.h", "xt_reg2.h", "xt_gradr.h", "xt_rev.h", "xt_seqmat.h")]
+                                                                                             "xt_grad_host.h", "xt_thgrad.h", "xt_thgrad2.h", "xt_big.h", "xt_hist.h", "xt_hist_host.h", "xt_reg2.h", "xt_gradr.h", "xt_rev.h", "xt_seqmat.h")]
         if not os.path.exists(so) or any(os.path.getmtime(f) > os.path.getmtime(so) for f in [src, os.path.join(HERE, "emul_r2.cpp"), os.path.join(HERE, "emul_gradr.cpp"), os.path.join(HERE, "emul_rev.cpp"), os.path.join(HERE, "emul_ctx.h")] + hdrs):
             import subprocess
             units = ["emul.cpp", "emul_r2.cpp", "emul_gradr.cpp", "emul_rev.cpp"]  # compiled side by side: emul_r2.cpp unrolls the whole step loop per instance

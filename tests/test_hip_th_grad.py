@@ -64,12 +64,15 @@ def _check_case(T, OT, rng, Cs, LE, ds, Fs, Tm, pBL, isBL, cell_dims, ns, F, min
     return abs(ll - ll0) / max(abs(ll0), 1.0), float((np.abs(g - fd) / np.maximum(np.abs(fd), 1e-3 * np.abs(fd).max())).max())
 
 
-def test_th_grad_golden_ll_cases_vs_frozen_plan_differences():
-    """The 200 log-likelihood cases of the reference-generated fixture (2 - 4 states, nb_substeps 1 - 2, 2 - 25 positions, 1 - 60 tracks,
+@pytest.mark.parametrize("kernel", ["1", "2"])
+def test_th_grad_golden_ll_cases_vs_frozen_plan_differences(kernel, monkeypatch):
+    """Both gradient kernels (EXTRACK_THG_KERNEL: 1 = one lane per track, csrc/xt_thgrad.h; 2 = one lane per (sequence, track), csrc/xt_thgrad2.h,
+    where its tile fits - the launcher's own choice is 2 for up to 16 live sequences).  The 200 log-likelihood cases of the reference-generated fixture (2 - 4 states, nb_substeps 1 - 2, 2 - 25 positions, 1 - 60 tracks,
     scalar / per-peak errors, isBL 0 / 1, thresholds 0.05 - 0.5, max_nb_states 8 - 120): value = extrack_loglik_th's, gradient along three
     random dense model directions = the derivative of the oracle at the plan of the evaluation."""
     from extrack_amd import tracking as T
     from oracle import oracle_th as OT
+    monkeypatch.setenv("EXTRACK_THG_KERNEL", kernel)
     meta = json.load(open(os.path.join(GOLDEN, "th_kernel_cases.json")))
     data = np.load(os.path.join(GOLDEN, "th_kernel_cases.npz"))
     rng = np.random.default_rng(2026)
@@ -89,11 +92,13 @@ def test_th_grad_golden_ll_cases_vs_frozen_plan_differences():
         worst_v, worst_g = max(worst_v, r[0]), max(worst_g, r[1])
         served += 1
     assert served + skipped == 200 and served >= 170, (served, skipped)
-    print("th grad golden cases: served", served, "refused", skipped, "worst rel value diff", worst_v, "worst rel gradient error", worst_g)
+    print("th grad golden cases, kernel", kernel, ": served", served, "refused", skipped, "worst rel value diff", worst_v, "worst rel gradient error", worst_g)
 
 
-def test_th_grad_extra_cases():
-    """Second fixture: 1-D / 3-D tracks, per-dimension and per-peak errors, nb_substeps up to 3, 5 states."""
+@pytest.mark.parametrize("kernel", ["1", "2"])
+def test_th_grad_extra_cases(kernel, monkeypatch):
+    """Second fixture: 1-D / 3-D tracks, per-dimension and per-peak errors, nb_substeps up to 3, 5 states; both gradient kernels."""
+    monkeypatch.setenv("EXTRACK_THG_KERNEL", kernel)
     from extrack_amd import tracking as T
     from oracle import oracle_th as OT
     meta = json.load(open(os.path.join(GOLDEN, "th_kernel_cases_extra.json")))
