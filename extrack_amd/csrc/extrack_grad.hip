@@ -48,6 +48,11 @@ __global__ void __launch_bounds__(256) xt_grad_reduce(const double* __restrict__
         }
     }
 }
+// out[i] += add[i]: the launch groups after the first leave {sum LL, gradient} in a scratch row that is added to the evaluation's result
+__global__ void __launch_bounds__(64) xt_grad_add_kernel(double* __restrict__ out, const double* __restrict__ add, int n)
+{
+    for (int i = threadIdx.x; i < n; i += 64) out[i] += add[i];
+}
 static XtGradDst xt_grad_dst_identity(int base)
 {
     XtGradDst d;
@@ -186,7 +191,11 @@ static int xt_grad_enqueue(extrack_ctx* ctx, const extrack_model* m, int32_t n_d
     }
     if (order.size() > (size_t)XT_DESC_CAP / 2) return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "too many buckets");
 
-    if (groups.size() > 1) return xt_fail(ctx, EXTRACK_E_UNSUPPORTED, "gradient: buckets of different dimensionality / error layout in one dataset");
+    // more than one launch group (more than XT_MAX_BUCKETS track lengths, or buckets of different layouts): the groups after the first write
+    // {sum LL, gradient} to a scratch row that is added to d_out in stream order
+    double* const d_out_final = d_out;
+    if (groups.size() > 1 && (rc = xt_grad_reserve(ctx, &ctx->d_gtmp, &ctx->gtmp_cap, (size_t)n_dir + 1))) return rc;
+    int group_index = 0;
     size_t doff = xt_desc_base(ctx);
     // per-block partial sums of every pass of the evaluation, one after the other (a pass has at most 32 blocks per CU)
     size_t poff = 0;
@@ -195,6 +204,12 @@ static int xt_grad_enqueue(extrack_ctx* ctx, const extrack_model* m, int32_t n_d
     if (!ctx->evg1) XT_HIP(ctx, hipEventCreate(&ctx->evg1));
     XT_HIP(ctx, hipEventRecord(ctx->evg0, ctx->stream));
     for (auto& g : groups) {
+        double* const d_out = group_index == 0 ? d_out_final : ctx->d_gtmp;  // (shadows the parameter inside the loop)
+        poff = 0;  // the previous group's reductions precede this group's kernels in the stream: the partial-sum rows are free again
+        auto group_done = [&]() {
+            if (group_index > 0) hipLaunchKernelGGL(xt_grad_add_kernel, dim3(1), dim3(64), 0, ctx->stream, d_out_final, ctx->d_gtmp, n_dir + 1);
+            ++group_index;
+        };
         const XtBucket& b0 = *g[0];
         const int D = b0.D;
         int K;
@@ -306,6 +321,7 @@ static int xt_grad_enqueue(extrack_ctx* ctx, const extrack_model* m, int32_t n_d
                 ctx->launch_info[4] = occ;
                 ctx->launch_info[5] = ctx->n_cu;
                 doff += g.size();
+                group_done();
                 continue;
             }
         }
@@ -403,6 +419,7 @@ static int xt_grad_enqueue(extrack_ctx* ctx, const extrack_model* m, int32_t n_d
                 ctx->launch_info[5] = ctx->n_cu;
             }
             doff += g.size();
+            group_done();
             continue;
         }
         // ---- 2 - 4 members per group, <= 256 groups per track: state and tangents in registers, LDS as the exchange medium (xt_gradr.h)
@@ -478,6 +495,7 @@ static int xt_grad_enqueue(extrack_ctx* ctx, const extrack_model* m, int32_t n_d
                     ctx->launch_info[5] = ctx->n_cu;
                 }
                 doff += g.size();
+                group_done();
                 continue;
             }
         }
@@ -558,7 +576,9 @@ static int xt_grad_enqueue(extrack_ctx* ctx, const extrack_model* m, int32_t n_d
             ctx->launch_info[5] = ctx->n_cu;
         }
         doff += g.size();
+        group_done();
     }
+    XT_HIP(ctx, hipGetLastError());
     XT_HIP(ctx, hipEventRecord(ctx->evg1, ctx->stream));
     ctx->grad_timed = true;
     return EXTRACK_OK;

@@ -275,6 +275,7 @@ extern "C" void extrack_destroy(extrack_ctx* ctx)
     if (ctx->d_dblob2) (void)hipFree(ctx->d_dblob2);
     if (ctx->ev_dblob) (void)hipEventDestroy(ctx->ev_dblob);
     if (ctx->d_gout) (void)hipFree(ctx->d_gout);
+    if (ctx->d_gtmp) (void)hipFree(ctx->d_gtmp);
     if (ctx->d_revlog) (void)hipFree(ctx->d_revlog);
     if (ctx->d_revadj) (void)hipFree(ctx->d_revadj);
     for (int i = 0; i < extrack_ctx::RF_SLOTS; ++i)

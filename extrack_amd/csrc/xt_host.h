@@ -287,6 +287,8 @@ struct extrack_ctx {
     bool grad_timed = false;        // ... whose time has not been read yet
     double* d_gout = nullptr;       // gradient path: {sum LL, gradient} of the synchronous entry point
     size_t gout_cap = 0;
+    double* d_gtmp = nullptr;       // ... of the launch groups after the first (added to the result in stream order)
+    size_t gtmp_cap = 0;
     double* d_partials = nullptr;
     size_t partials_cap = 0;
     static constexpr int RF_SLOTS = 10;   // position refinement: grow-only device buffers kept between calls (extrack_hip.hip: XT_RF_*)

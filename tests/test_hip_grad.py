@@ -258,3 +258,33 @@ def test_default_gradient_choice_follows_the_timing_probe(capsys):
     assert t_auto < t_fd  # the probe's promise: never the slower way
     assert f3.ngev > 0 and f3.residual[0] <= f3fd.residual[0] + 1e-6 * abs(f3fd.residual[0])
     assert t3_auto < t3_fd
+
+
+@pytest.mark.parametrize("S", [2, 3])
+def test_gradient_more_track_lengths_than_one_launch_serves(S):
+    """78 distinct track lengths (3 - 80): more than the 64 length buckets one launch serves, so the evaluation runs two launch groups whose
+    {sum LL, gradient} are added on the device (refused with E_UNSUPPORTED until round 4).  Whole dataset = sum over the two halves of the
+    buckets, value = extrack_loglik's; 2 states (tangents in registers) and 3 states (reverse mode)."""
+    from extrack_amd import gradient, synth, tracking as T
+    if S == 2:
+        Ds, Tm, Fs = [0.0, 0.25], np.array([[0.9, 0.1], [0.1, 0.9]]), [0.6, 0.4]
+        pg = T.generate_params(nb_states=2, LocErr_type=1, estimated_Ds=[1e-3, 0.25], estimated_LocErr=[0.02], estimated_Fs=[0.6], estimated_transition_rates=0.1)
+    else:
+        Ds, Tm, Fs = [0.0, 0.04, 0.25], np.array([[0.9, 0.07, 0.03], [0.05, 0.9, 0.05], [0.03, 0.07, 0.9]]), [0.3, 0.3, 0.4]
+        pg = T.generate_params(nb_states=3, LocErr_type=1, estimated_Ds=[1e-4, 0.04, 0.25], estimated_LocErr=[0.02], estimated_Fs=[0.3, 0.3],
+                               estimated_transition_rates=0.06)
+    lst = [synth.brownian_tracks(40 + (L % 7) * 30, L, Ds, Tm, Fs, seed=300 + L) for L in range(3, 81)]
+    names = gradient.free_names(pg)
+    F = 5
+    ts = T.TrackSet(lst)
+    v, g = gradient.objective_and_gradient(pg, ts, 0.02, [1], S, 1, F, names=names)
+    v0 = -ts.loglik(T._objective_model(pg, ts, 0.02, [1], None, S, 1, F, 1))
+    ts.close()
+    assert abs(v - v0) < 1e-12 * abs(v0), (v, v0)
+    parts = []
+    for half in (lst[:40], lst[40:]):
+        ts = T.TrackSet(half, min_len=3, max_len=80)
+        parts.append(gradient.objective_and_gradient(pg, ts, 0.02, [1], S, 1, F, names=names))
+        ts.close()
+    vs, gs = parts[0][0] + parts[1][0], parts[0][1] + parts[1][1]
+    assert abs(vs - v) < 1e-11 * abs(v) and np.allclose(gs, g, rtol=1e-9, atol=1e-9 * np.abs(g).max()), (vs, v, np.abs(gs - g).max())
