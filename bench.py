@@ -229,7 +229,7 @@ def other_configs(device, no_cpu_baseline=False, no_fits=False):
     for _ in range(2):
         gv, gg = gradient.objective_and_gradient(pg, ts, DT, CELL, 3, 1, 6, names=names, threshold_fusion=(0.2, 120, 2000))
     out["c3_loglik_th_grad"] = {"what": "configs[2] through the threshold-fusion kernels: -sum(LL) AND its exact gradient (13 free parameters) at the frozen plan of the "
-                                        "evaluation (plan kernel + xt_thg_kernel: one forward + one backward sweep, one lane per track)",
+                                        "evaluation (plan kernel + xt_thg_kernel: one forward + one backward sweep, one lane per track - ~33 live sequences per step)",
                                 "kernel_ms": ts.ctx.last_grad_ms(), "n_directions": len(names),
                                 "fd_equivalent_ms": (len(names) + 1) * out["c3_loglik_threshold"]["kernel_ms"], "grad_inf_norm": float(np.abs(gg).max()),
                                 "launch": ts.ctx.last_launch_info()}
@@ -286,6 +286,23 @@ def other_configs(device, no_cpu_baseline=False, no_fits=False):
             r = tracking.param_fitting(c2, DT, params=p2, nb_states=2, frame_len=6, cell_dims=CELL, verbose=0, device=device, gradient=grad)
             fits2["default" if grad is None else grad] = {"seconds": time.perf_counter() - t0, "objective_calls": int(r.nfev),
                                                            "gradient_calls": int(getattr(r, "ngev", 0)), "neg_loglik": float(r.residual[0])}
+    # the threshold-fusion objective of the same dataset and its exact gradient at the frozen plan (12 live sequences: csrc/xt_thgrad2.h)
+    try:
+        ts = tracking.TrackSet([c2[str(LEN)]], device=device)
+        pg2 = tracking.generate_params(nb_states=2, LocErr_type=1, estimated_Ds=[1e-3, 0.25], estimated_LocErr=[LOCERR], estimated_Fs=[0.6],
+                                       estimated_transition_rates=0.1)
+        names2 = gradient.free_names(pg2)
+        m2 = tracking._objective_model(pg2, ts, DT, CELL, None, 2, 1, 6, 1)
+        w2, k2, v2 = timed(lambda: ts.loglik_th(m2, 0.2, 120, 2000), 5, warm=2)
+        for _ in range(3):
+            gv2, gg2 = gradient.objective_and_gradient(pg2, ts, DT, CELL, 2, 1, 6, names=names2, threshold_fusion=(0.2, 120, 2000))
+        out["c2_loglik_th_grad"] = {"what": "configs[1] data through the threshold-fusion kernels: -sum(LL) AND its exact gradient (7 free parameters) at the frozen plan "
+                                            "(plan kernel + xt_thg2_kernel: lanes over (sequence, track), live state in LDS)",
+                                    "kernel_ms": ts.ctx.last_grad_ms(), "n_directions": len(names2), "objective_kernel_ms": k2,
+                                    "fd_equivalent_ms": (len(names2) + 1) * k2, "same_value": bool(abs(gv2 + v2) <= 1e-12 * abs(v2)), "launch": ts.ctx.last_launch_info()}
+        ts.close()
+    except Exception as e:  # noqa: BLE001
+        out["c2_loglik_th_grad"] = {"error": str(e)}
     if fits2:
         out["c2_full_fit_F6"] = {"what": "configs[1] data: param_fitting on 1e6 x 30, 2 states, frame_len 6 from a generic start; 'default' = gradient=None "
                                      "(timing probe -> one-pass analytic gradient, tangents in registers), 'fd' = finite differences like the reference", "fit": fits2}
@@ -321,6 +338,22 @@ def other_configs(device, no_cpu_baseline=False, no_fits=False):
                                "algorithmic_bytes": nbytes + obytes, "hbm_gbs": (nbytes + obytes) / (kms * 1e-3) / 1e9,
                                "rowsum_err": float(np.abs(pr[0].sum(-1) - 1).max()), "launch": ts.ctx.last_launch_info()}
     del pr
+    # the same model (4 states x 3 substeps) through the kernel v1.6.3's param_fitting calls: 4^4 x 4^3 = 16 384 expanded sequences at the
+    # second position - beyond the 8192 whose plan arrays fit the LDS, refused until round 4
+    try:
+        import math
+        Tsub = 1 - np.exp(-(Tm - np.diag(np.diag(Tm))) / 3)
+        Tsub[np.arange(4), np.arange(4)] = 0
+        Tsub[np.arange(4), np.arange(4)] = 1 - Tsub.sum(1)
+        dsb = np.sqrt(2 * np.maximum(np.array([0.0, 0.02, 0.1, 0.5]), 1e-4) * DT)
+        m16 = ts.make_model(np.array([[[LOCERR]]]), dsb, np.array([.25] * 4), Tsub, 0.1, tuple(CELL), 3, 4)
+        w16, k16, v16 = timed(lambda: ts.loglik_th(m16, 0.2, 120, 2000), 2, warm=1)
+        out["c5_loglik_threshold_ns3"] = {"what": "configs[4] model (4 states, nb_substeps 3, frame_len 4) through the threshold-fusion kernels: 16 384 expanded sequences "
+                                                  "at the second position, the plan kernel's per-step arrays in its global workspace",
+                                          "ms_per_eval": w16 * 1e3, "kernel_ms": k16, "tracks_per_s": N5 / w16, "finite": bool(math.isfinite(v16)),
+                                          "launch": ts.ctx.last_launch_info()}
+    except Exception as e:  # noqa: BLE001
+        out["c5_loglik_threshold_ns3"] = {"error": str(e)}
     ts.close()
     # CPU side of the same configs (plain-C restatement, OpenMP, bounded samples)
     try:
