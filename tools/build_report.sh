@@ -8,7 +8,7 @@ done
 wait
 python3 - "$@" <<'PY'
 import re, sys
-pat = sys.argv[1] if len(sys.argv) > 1 else r'xt_ll_r2_kernelILi6ELi2ELi1|xt_ll_s2_kernelILi6ELi2ELi1|xt_grad_r2_kernelILi6ELi2ELi1ELi[67]|xt_rev_kernelILi[34]ELi2ELi1|xt_gradr_kernelILi3ELi2ELi1|xt_track_kernelILi[234]ELi2ELi1ELb[01]ELi256|xt_th_(plan|apply)_kernelILi2ELi1|xt_grad_kernelILi3ELi2ELi1ELi256|xt_hist_kernelILi2ELi1ELi256|xt_entry_kernelILi64ELi2ELi1ELi256|xt_refine_combineILi2|xt_thg_kernelILi2ELi1|xt_big_kernelILi2ELi1'
+pat = sys.argv[1] if len(sys.argv) > 1 else r'xt_ll_r2_kernelILi6ELi2ELi1|xt_ll_s2_kernelILi6ELi2ELi1|xt_grad_r2_kernelILi6ELi2ELi1ELi[67]|xt_rev_kernelILi[34]ELi2ELi1|xt_gradr_kernelILi3ELi2ELi1|xt_track_kernelILi[234]ELi2ELi1ELb[01]ELi256|xt_th_(plan|apply)_kernelILi2ELi1|xt_grad_kernelILi3ELi2ELi1ELi256|xt_hist_kernelILi2ELi1ELi256|xt_entry_kernelILi64ELi2ELi1ELi256|xt_refine_combineILi2|xt_thg_kernelILi2ELi1|xt_thg2_kernelILi2ELi1|xt_big_kernelILi2ELi1|xt_refine_componentsILi2'
 for u in ("extrack_hip", "extrack_grad", "extrack_hist", "extrack_rev", "extrack_gradr", "extrack_reg2_f6", "extrack_thgrad"):
     txt = open('/tmp/xt_report_%s.log' % u).read()
     for b in txt.split('Function Name:')[1:]:
