@@ -53,40 +53,74 @@ XT_HD int xt_f2_swz(int w)
     return s;
 }
 
-// exp(x), x <= 0, table-driven: x = (64 e + j) ln2/64 + r, |r| <= ln2/128, exp(x) = 2^e * T64[j] * P5(r).
-// Two independent evaluations are interleaved instruction by instruction (a wave alone can only issue a DEPENDENT
-// fp64 FMA every few issue slots).  Returns p (without the table factor), the table index j and the exponent e.
-// |rel err| < 3e-16 (truncation r^6/720 < 4e-17).  Clamp: see XT_TCLAMP (xt_math.h).
+// exp(x), x <= 0, for the two register-resident 2-state kernels (this file and xt_reg2.h): x = (1024 e + j) ln2/1024 + r, |r| <= ln2/2048,
+// exp(x) = 2^e * TB[j] * P3(r) with a 1024-entry table TB[j] = 2^(j/1024) that every workgroup builds in its LDS from the blob's 32-entry
+// table (xt_f2_build_exp_table).  These kernels are bound by fp64 VALU issue (VALU busy 1.00): the 8 KiB of LDS buy two FMAs per exponential,
+// four per step - a timing experiment with a shortened polynomial measured 3.00 -> 2.86 ms on the headline workload (round 4); bank
+// conflicts of the lookups do not matter there (a conflict-free 32-entry table changed nothing).  P3 = 1 + r (1 + r (c2 + r / 6)),
+// c2 = 1/2 + a^2 / 24 (the r^4 term folded in, a = ln2 / 2048): |rel err| < 1.5e-16 in exact arithmetic.
+// n = 1024 x / ln2 exceeds 32 bits at the clamp (XT_TCLAMP): the exponent e = n >> 10 is cut out of the 64-bit pattern of the magic-number
+// sum (one v_alignbit), j is the low 10 bits.  Two independent evaluations are interleaved instruction by instruction (a wave alone can only
+// issue a DEPENDENT fp64 FMA every few issue slots).  Returns p (without the table factor), the table index j and the exponent e.
 #define XT_F2_XCLAMP XT_TCLAMP
+#define XT_F2_EXP_ENTRIES 1024
+#define XT_F2_EXP_BYTES (XT_F2_EXP_ENTRIES * 8)
+#define XT_F2_EXP_SCALE 1477.3197218702985       // 1024 / ln2
+#define XT_F2_EXP_HI (-6.769015308236703e-04)    // -ln2 / 1024, high part (1/32 of xt_math.h's: exact) ...
+#define XT_F2_EXP_LO (-1.2691901263564344e-11)   // ... and the rest
+#define XT_F2_EXP_C2 0.5000000047728719          // 1/2 + a^2 / 24, a = ln2 / 2048
+XT_HD void xt_f2_exp_bits(double t, int& j, int& e)
+{
+    union {
+        double d;
+        unsigned long long u;
+    } v;
+    v.d = t;  // 1.5 * 2^52 + n: the mantissa field holds 2^51 + n in two's complement
+    j = (int)(v.u & (XT_F2_EXP_ENTRIES - 1));
+    e = (int)(unsigned int)(v.u >> 10);  // bits 41 .. 10: n >> 10 for |n| < 2^41 (the 2^51 and the exponent field lie above)
+}
 XT_HD void xt_exp_tab_x2(double x0, double x1, double& p0, double& p1, int& j0, int& j1, int& e0, int& e1)
 {
     x0 = x0 > XT_F2_XCLAMP ? x0 : XT_F2_XCLAMP;
     x1 = x1 > XT_F2_XCLAMP ? x1 : XT_F2_XCLAMP;
-    const double t0 = xt_fma(x0, 92.33248261689366, XT_MAGIC);  // integer part in the low 32 bits (xt_math.h)
-    const double t1 = xt_fma(x1, 92.33248261689366, XT_MAGIC);
+    const double t0 = xt_fma(x0, XT_F2_EXP_SCALE, XT_MAGIC);  // integer part in the low bits of the mantissa (xt_math.h)
+    const double t1 = xt_fma(x1, XT_F2_EXP_SCALE, XT_MAGIC);
     const double k0 = t0 - XT_MAGIC;
     const double k1 = t1 - XT_MAGIC;
-    double r0 = xt_fma(k0, -0.010830424493178725, x0);
-    double r1 = xt_fma(k1, -0.010830424493178725, x1);
-    r0 = xt_fma(k0, -2.030704202170295e-10, r0);
-    r1 = xt_fma(k1, -2.030704202170295e-10, r1);
-    double q0 = 8.33333333333333333333e-03, q1 = 8.33333333333333333333e-03;  // 1/120
+    double r0 = xt_fma(k0, XT_F2_EXP_HI, x0);
+    double r1 = xt_fma(k1, XT_F2_EXP_HI, x1);
+    r0 = xt_fma(k0, XT_F2_EXP_LO, r0);
+    r1 = xt_fma(k1, XT_F2_EXP_LO, r1);
+    double q0 = 1.66666666666666666667e-01, q1 = 1.66666666666666666667e-01;
 #define XT_H2(C)              \
     q0 = xt_fma(q0, r0, (C)); \
     q1 = xt_fma(q1, r1, (C));
-    XT_H2(4.16666666666666666667e-02)
-    XT_H2(1.66666666666666666667e-01)
-    XT_H2(0.5)
+    XT_H2(XT_F2_EXP_C2)
     XT_H2(1.0)
     XT_H2(1.0)
 #undef XT_H2
     p0 = q0;
     p1 = q1;
-    const int n0 = xt_lo32(t0), n1 = xt_lo32(t1);
-    j0 = n0 & 63;
-    j1 = n1 & 63;
-    e0 = n0 >> 6;
-    e1 = n1 >> 6;
+    xt_f2_exp_bits(t0, j0, e0);
+    xt_f2_exp_bits(t1, j1, e1);
+}
+// TB[i] = 2^(i / 1024) = T32[i >> 5] * exp((i & 31) ln2 / 1024) at byte offset `off` of the workgroup's LDS; T32: the blob's table (already
+// staged).  The second factor: Taylor to s^7 (s <= 0.021: truncation 1e-18).  Call between two workgroup barriers.
+template <class Ctx>
+XT_HD void xt_f2_build_exp_table(Ctx& cx, char* lds, int off, const double* T32)
+{
+    for (int i = cx.tid(); i < XT_F2_EXP_ENTRIES; i += cx.nthreads()) {
+        const double sv = (double)(i & 31) * (XT_LN2 / 1024.0);
+        double q = 1.0 / 5040.0;
+        q = xt_fma(q, sv, 1.0 / 720.0);
+        q = xt_fma(q, sv, 1.0 / 120.0);
+        q = xt_fma(q, sv, 1.0 / 24.0);
+        q = xt_fma(q, sv, 1.0 / 6.0);
+        q = xt_fma(q, sv, 0.5);
+        q = xt_fma(q, sv, 1.0);
+        q = xt_fma(q, sv, 1.0);
+        *(double*)(lds + off + i * 8) = T32[i >> 5] * q;
+    }
 }
 
 template <int F, int D, int K>
@@ -98,7 +132,8 @@ struct XtF2State {
 // Fixed LDS map of the fast path (bytes).  One array per field over all waves of the block, so that a field is reached
 // from the zm address by a compile-time offset - the exponents ze too: they sit in 8-byte slots (upper half unused), which
 // saves the address arithmetic a packed int array would need in every step.
-#define XT_F2_TAB_BYTES 1024                                   /* model blob: tables (288 B) + T64 exp table (512 B) */
+#define XT_F2_EXPB_OFF 1024                                    /* the 1024-entry exp table of xt_exp_tab_x2, built per workgroup */
+#define XT_F2_TAB_BYTES (1024 + XT_F2_EXP_BYTES)               /* model blob (tables 288 B + the blob's 32-entry exp table 512 B, NaN flags) + that table */
 #define XT_F2_T64_OFF ((XT_BLOB_HDR + XT_NTAB * 4) * 8)   /* the blob's T64 table (xt_tables.h) */
 #define XT_F2_NAN_OFF 832                                      /* int[XT_F2_WAVES][8]: track has a NaN position / sigma */
 #define XT_F2_ARR (XT_F2_WAVES * 128 * 8)                      /* bytes of one double field for all waves */
@@ -210,7 +245,7 @@ XT_HD void xt_f2_step(char* lds, const XtF2State<F, D, K>& st, const double* c, 
     for (int q = 0; q < 2; ++q) {
         const int aq = q ? a1 : a0;
         int en = We + n[q];
-        const double tj = xt_at<double>(lds, XT_F2_T64_OFF + j[q] * 8);
+        const double tj = xt_at<double>(lds, XT_F2_EXPB_OFF + j[q] * 8);
         double zn = (Wm * TT[q]) * (gf[q] * tj) * p[q];
         if (!LAZY) {
             // guarded steps (models outside the well-scaled bounds, e.g. a transition probability of 1e-200): the stored mantissa is
@@ -243,6 +278,8 @@ XT_HD void xt_ll_s2_body(const XtKernelArgs& a, Ctx& cx)
     // block-shared model tables + the 2^(j/64) table of the exponential
     const int ntab = xt_tab_doubles(2, 2);
     for (int i = cx.tid(); i < ntab; i += cx.nthreads()) smem[i] = xt_blob_ptr(a)[i];
+    cx.sync();
+    xt_f2_build_exp_table(cx, lds, XT_F2_EXPB_OFF, (const double*)(lds + XT_F2_T64_OFF));
     cx.sync();
     const double* hdr = smem;
     const double* TAB = smem + XT_BLOB_HDR;
@@ -437,7 +474,7 @@ XT_HD void xt_ll_s2_body(const XtKernelArgs& a, Ctx& cx)
                 int j[2], n[2];
                 xt_exp_tab_x2(x[0], x[1], p[0], p[1], j[0], j[1], n[0], n[1]);
                 for (int q = 0; q < 2; ++q)
-                    tot.add(zq * TAB[(vfin * 2 + prev) * 2 + q] * gf[q] * xt_at<double>(lds, XT_F2_T64_OFF + j[q] * 8) * p[q], eq + n[q]);
+                    tot.add(zq * TAB[(vfin * 2 + prev) * 2 + q] * gf[q] * xt_at<double>(lds, XT_F2_EXPB_OFF + j[q] * 8) * p[q], eq + n[q]);
             }
         }
         // reduce over the track's NG lanes (all lanes end with the same values)

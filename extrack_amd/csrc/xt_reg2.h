@@ -47,7 +47,7 @@ XT_HD int xt_r2_slot(int lane)
     return ts;
 }
 
-// LDS map (bytes): [model blob 1 KiB (as xt_fast2.h: tables, T64, NaN flags)] [tangent blocks NP x TB] [staged positions] [accumulators]
+// LDS map (bytes): [model blob 1 KiB (as xt_fast2.h: tables, 32-entry exp table, NaN flags)] [1024-entry exp table 8 KiB] [tangent blocks NP x TB] [staged positions] [accumulators]
 #define XT_R2_TAN0 XT_F2_TAB_BYTES
 #define XT_R2_TB 36  // xt_grad_tb_doubles(2, 2)
 #define XT_R2_MAXU 4  // uniform directions served by one launch (on top of its NP full ones)
@@ -169,7 +169,7 @@ XT_HD void xt_r2_step(Ctx& cx, char* lds, XtR2Lane<D, K, NP>& s, int tab, const 
     XT_UNROLL
     for (int q = 0; q < 2; ++q) {
         int en = We + n[q];
-        const double tj = xt_at<double>(lds, XT_F2_T64_OFF + j[q] * 8);
+        const double tj = xt_at<double>(lds, XT_F2_EXPB_OFF + j[q] * 8);
         double zn = (Wm * TT[q]) * (gf[q] * tj) * p[q];
         if (!LAZY) {
             en += xt_frexp_exp(zn);
@@ -339,6 +339,8 @@ XT_HD void xt_r2_body(const XtKernelArgs& a, const XtGradArgs& ga, Ctx& cx)
     // position's factor table tells the sequences apart: no per-step work at all (see the read-out below)
     const int NU = NP > 0 ? ga.NU : 0, NPT = NP + NU;
     for (int i = cx.tid(); i < NU * XT_R2_TB; i += cx.nthreads()) xt_at<double>(lds, XT_R2_TAN0 + (NP * XT_R2_TB + i) * 8) = ga.udblob[i];
+    cx.sync();
+    xt_f2_build_exp_table(cx, lds, XT_F2_EXPB_OFF, (const double*)(lds + XT_F2_T64_OFF));  // the 1024-entry table of xt_exp_tab_x2 from the blob's 32 entries
     cx.sync();
     const double* hdr = smem;
 
@@ -561,7 +563,7 @@ XT_HD void xt_r2_body(const XtKernelArgs& a, const XtGradArgs& ga, Ctx& cx)
                 XT_UNROLL
                 for (int q = 0; q < 2; ++q) {
                     const double tf = xt_at<double>(lds, XT_R2_TAB0 + vfin * 32 + (prev * 2 + q) * 8);
-                    wm[Q * 2 + q] = s.z[Q] * tf * gf[q] * xt_at<double>(lds, XT_F2_T64_OFF + j[q] * 8) * p[q];
+                    wm[Q * 2 + q] = s.z[Q] * tf * gf[q] * xt_at<double>(lds, XT_F2_EXPB_OFF + j[q] * 8) * p[q];
                     we[Q * 2 + q] = s.e[Q] + n[q];
                     tot.add(wm[Q * 2 + q], we[Q * 2 + q]);
                 }
