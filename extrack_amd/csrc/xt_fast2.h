@@ -153,10 +153,27 @@ XT_HD int xt_opaque(int v)
     return v;
 }
 
+// LDS access by byte offset.  On the device the offset IS the LDS address: the kernels' only LDS object is the dynamic array (xt_host.h), which
+// starts at address 0 (checked once per workgroup by xt_f2_check_lds_base), and the address is formed from the integer - written as
+// `lds + byte_off` the compiler keeps an add of the array's (zero) base in front of every data-dependent access: three 32-bit VALU
+// instructions per step of the headline kernel.
 template <class T>
 XT_HD T& xt_at(char* lds, int byte_off)
 {
+#if defined(__HIP_DEVICE_COMPILE__)
+    (void)lds;
+    return *(__attribute__((address_space(3))) T*)(unsigned int)byte_off;
+#else
     return *(T*)(lds + byte_off);
+#endif
+}
+XT_HD void xt_f2_check_lds_base(char* lds)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    if ((unsigned int)(unsigned long long)(__attribute__((address_space(3))) char*)lds != 0u) __builtin_trap();
+#else
+    (void)lds;
+#endif
 }
 
 // One recursion step at compile-time phase H.  c: position, l2: localisation variance(s), TT: transition row in use.
@@ -279,6 +296,7 @@ XT_HD void xt_ll_s2_body(const XtKernelArgs& a, Ctx& cx)
     const int ntab = xt_tab_doubles(2, 2);
     for (int i = cx.tid(); i < ntab; i += cx.nthreads()) smem[i] = xt_blob_ptr(a)[i];
     cx.sync();
+    xt_f2_check_lds_base(lds);
     xt_f2_build_exp_table(cx, lds, XT_F2_EXPB_OFF, (const double*)(lds + XT_F2_T64_OFF));
     cx.sync();
     const double* hdr = smem;

@@ -340,6 +340,7 @@ XT_HD void xt_r2_body(const XtKernelArgs& a, const XtGradArgs& ga, Ctx& cx)
     const int NU = NP > 0 ? ga.NU : 0, NPT = NP + NU;
     for (int i = cx.tid(); i < NU * XT_R2_TB; i += cx.nthreads()) xt_at<double>(lds, XT_R2_TAN0 + (NP * XT_R2_TB + i) * 8) = ga.udblob[i];
     cx.sync();
+    xt_f2_check_lds_base(lds);
     xt_f2_build_exp_table(cx, lds, XT_F2_EXPB_OFF, (const double*)(lds + XT_F2_T64_OFF));  // the 1024-entry table of xt_exp_tab_x2 from the blob's 32 entries
     cx.sync();
     const double* hdr = smem;
