@@ -173,14 +173,14 @@ def test_entry_parallel_body_on_multi_substep_cases(kernel_cases, monkeypatch):
     meta, data = kernel_cases
     worst, n = 0.0, 0
     for row in meta:
-        if row["ns"] < 2 or row["id"] % 6:
+        if row["ns"] < 2 or row["id"] % 9:
             continue
         x = case_inputs(row, data)
         ll, _, tot, _ = _run(row, x, False, nblocks=2)
         worst = max(worst, np.abs(ll - x["LPC"]).max())
         assert abs(tot - ll.sum()) < 1e-9
         n += 1
-    assert n > 60 and worst < 1e-10, (n, worst)
+    assert n > 40 and worst < 1e-10, (n, worst)
 
 
 @pytest.mark.parametrize("S,ns,F", [(2, 1, 6), (3, 1, 3), (2, 2, 3)])
