@@ -81,11 +81,15 @@ __global__ void __launch_bounds__(PREDS ? 256 : 1024, PREDS ? PW : 1) xt_th_plan
     xt_th_plan_body<D, K, PREDS, WS>(a, cx);
 }
 
-template <int D, int K, bool UNI, bool SINGLE, bool DT>
+// The wave-uniform two-buffer variant runs workgroups of up to 16 wavefronts, two per CU when the LDS allows: 24 wavefronts per CU need 6 per
+// SIMD, i.e. at most 80 VGPRs - the allocator takes 77.  Round 4 lost that twice (2 states x 30, 1e6 tracks, evaluation 2.65 -> 3.8 ms): a
+// branch with a log() compiled into every variant (now the SEQ instantiation) and two more non-inline constants in the exponential (reverted).
+// Asking for 6 waves per SIMD through the launch bound instead (79 VGPRs, no spill) changes the schedule: 2.92 ms - no bound here.
+template <int D, int K, bool UNI, bool SINGLE, bool DT, bool SEQ = false>
 __global__ void __launch_bounds__(1024) xt_th_apply_kernel(XtThArgs a)
 {
     DevCtx cx;
-    xt_th_apply_body<D, K, UNI, SINGLE, DT>(a, cx);
+    xt_th_apply_body<D, K, UNI, SINGLE, DT, SEQ>(a, cx);
 }
 
 // Fixed-order reduction of the per-block partial sums (deterministic for a given launch geometry).
@@ -946,12 +950,12 @@ static hipError_t xt_th_launch_plan(extrack_ctx* ctx, const XtThArgs& a, int gri
     return hipGetLastError();
 }
 
-template <int D, int K, bool UNI, bool SINGLE, bool DT>
+template <int D, int K, bool UNI, bool SINGLE, bool DT, bool SEQ = false>
 static hipError_t xt_th_launch_apply_vd(extrack_ctx* ctx, const XtThArgs& a, int grid, int threads, size_t lds, hipStream_t stream)
 {
-    hipError_t e = xt_th_set_lds(ctx, xt_th_apply_kernel<D, K, UNI, SINGLE, DT>, lds);
+    hipError_t e = xt_th_set_lds(ctx, xt_th_apply_kernel<D, K, UNI, SINGLE, DT, SEQ>, lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((xt_th_apply_kernel<D, K, UNI, SINGLE, DT>), dim3(grid), dim3(threads), lds, stream, a);
+    hipLaunchKernelGGL((xt_th_apply_kernel<D, K, UNI, SINGLE, DT, SEQ>), dim3(grid), dim3(threads), lds, stream, a);
     return hipGetLastError();
 }
 
@@ -963,10 +967,13 @@ static hipError_t xt_th_launch_apply_v(extrack_ctx* ctx, const XtThArgs& a, int 
 }
 
 // mode 0: general (fewer than 64 tracks per tile), 1: wave-uniform, two state buffers, 2: wave-uniform, one state buffer,
-// 3: general with one state buffer (more than 64 live sequences)
+// 3: general with one state buffer (more than 64 live sequences), 4: general + the per-sequence matrix of the last position
 template <int D, int K>
 static hipError_t xt_th_launch_apply(extrack_ctx* ctx, const XtThArgs& a, int grid, int threads, size_t lds, int mode, hipStream_t stream)
 {
+    if (mode == 4)
+        return a.blob_stride != 0 ? xt_th_launch_apply_vd<D, K, false, false, true, true>(ctx, a, grid, threads, lds, stream)
+                                  : xt_th_launch_apply_vd<D, K, false, false, false, true>(ctx, a, grid, threads, lds, stream);
     if (mode == 3) return xt_th_launch_apply_v<D, K, false, true>(ctx, a, grid, threads, lds, stream);
     if (mode == 2) return xt_th_launch_apply_v<D, K, true, true>(ctx, a, grid, threads, lds, stream);
     if (mode == 1) return xt_th_launch_apply_v<D, K, true, false>(ctx, a, grid, threads, lds, stream);
@@ -1407,6 +1414,13 @@ static int xt_th_run_group(extrack_ctx* ctx, const extrack_model* m, const std::
         }
     }
     if (TT == 64 && ctx->th_force_single && maxG <= 16 * XT_TH_GPW) single_buf = 1;
+    bool want_seq = false;  // extrack_sequence_matrix_th: only the general two-buffer variant writes the per-sequence matrix
+    for (int i = 0; i < nbk; ++i) want_seq = want_seq || bks[i]->d_seqth != nullptr;
+    if (want_seq) {
+        single_buf = 0;
+        TT = 32;
+        while (TT > 1 && (TT > chunk * 2 || lds_of(TT) > 48 * 1024)) TT >>= 1;
+    }
     while (TT > 1 && lds_of(TT, single_buf) > 160 * 1024) TT >>= 1;
     if (TT != 64 && single_buf && maxG > (1024 / TT) * XT_TH_GPW) single_buf = 0;
     const bool uni = TT == 64;
@@ -1435,7 +1449,7 @@ static int xt_th_run_group(extrack_ctx* ctx, const extrack_model* m, const std::
     const int grid = (int)(a.nchunks * bpc);
     if ((rc = xt_grow_partials(ctx, poff + (size_t)grid))) return rc;
     a.partials = ctx->d_partials + poff;
-#define XT_TH_APPLY_CALL(...) xt_th_launch_apply<__VA_ARGS__>(ctx, a, grid, threads, lds, uni ? (single_buf ? 2 : 1) : (single_buf ? 3 : 0), ctx->stream)
+#define XT_TH_APPLY_CALL(...) xt_th_launch_apply<__VA_ARGS__>(ctx, a, grid, threads, lds, want_seq ? 4 : (uni ? (single_buf ? 2 : 1) : (single_buf ? 3 : 0)), ctx->stream)
     if (D == 1 && K == 1) e = XT_TH_APPLY_CALL(1, 1);
     else if (D == 2 && K == 1) e = XT_TH_APPLY_CALL(2, 1);
     else if (D == 2 && K == 2) e = XT_TH_APPLY_CALL(2, 2);

@@ -54,10 +54,10 @@ XT_HD int xt_f2_swz(int w)
 }
 
 // exp(x), x <= 0, for the two register-resident 2-state kernels (this file and xt_reg2.h): x = (1024 e + j) ln2/1024 + r, |r| <= ln2/2048,
-// exp(x) = 2^e * TB[j] * P3(r) with a 1024-entry table TB[j] = 2^(j/1024) that every workgroup builds in its LDS from the blob's 32-entry
+// exp(x) = 2^e * TB[j] * P3(r) with a 1024-entry table TB[j] = 2^(j/1024) that every workgroup builds in its LDS from the blob's 64-entry
 // table (xt_f2_build_exp_table).  These kernels are bound by fp64 VALU issue (VALU busy 1.00): the 8 KiB of LDS buy two FMAs per exponential,
 // four per step - a timing experiment with a shortened polynomial measured 3.00 -> 2.86 ms on the headline workload (round 4); bank
-// conflicts of the lookups do not matter there (a conflict-free 32-entry table changed nothing).  P3 = 1 + r (1 + r (c2 + r / 6)),
+// conflicts of the lookups do not matter there (a conflict-free 32-entry table changed nothing, xt_math.h).  P3 = 1 + r (1 + r (c2 + r / 6)),
 // c2 = 1/2 + a^2 / 24 (the r^4 term folded in, a = ln2 / 2048): |rel err| < 1.5e-16 in exact arithmetic.
 // n = 1024 x / ln2 exceeds 32 bits at the clamp (XT_TCLAMP): the exponent e = n >> 10 is cut out of the 64-bit pattern of the magic-number
 // sum (one v_alignbit), j is the low 10 bits.  Two independent evaluations are interleaved instruction by instruction (a wave alone can only
@@ -66,7 +66,7 @@ XT_HD int xt_f2_swz(int w)
 #define XT_F2_EXP_ENTRIES 1024
 #define XT_F2_EXP_BYTES (XT_F2_EXP_ENTRIES * 8)
 #define XT_F2_EXP_SCALE 1477.3197218702985       // 1024 / ln2
-#define XT_F2_EXP_HI (-6.769015308236703e-04)    // -ln2 / 1024, high part (1/32 of xt_math.h's: exact) ...
+#define XT_F2_EXP_HI (-6.769015308236703e-04)    // -ln2 / 1024, high part (1/16 of xt_exp_tab's: exact) ...
 #define XT_F2_EXP_LO (-1.2691901263564344e-11)   // ... and the rest
 #define XT_F2_EXP_C2 0.5000000047728719          // 1/2 + a^2 / 24, a = ln2 / 2048
 XT_HD void xt_f2_exp_bits(double t, int& j, int& e)
@@ -104,13 +104,13 @@ XT_HD void xt_exp_tab_x2(double x0, double x1, double& p0, double& p1, int& j0, 
     xt_f2_exp_bits(t0, j0, e0);
     xt_f2_exp_bits(t1, j1, e1);
 }
-// TB[i] = 2^(i / 1024) = T32[i >> 5] * exp((i & 31) ln2 / 1024) at byte offset `off` of the workgroup's LDS; T32: the blob's table (already
-// staged).  The second factor: Taylor to s^7 (s <= 0.021: truncation 1e-18).  Call between two workgroup barriers.
+// TB[i] = 2^(i / 1024) = T64[i >> 4] * exp((i & 15) ln2 / 1024) at byte offset `off` of the workgroup's LDS; T64: the blob's table (already
+// staged).  The second factor: Taylor to s^7 (s <= 0.0102: truncation far below 1e-18).  Call between two workgroup barriers.
 template <class Ctx>
-XT_HD void xt_f2_build_exp_table(Ctx& cx, char* lds, int off, const double* T32)
+XT_HD void xt_f2_build_exp_table(Ctx& cx, char* lds, int off, const double* T64)
 {
     for (int i = cx.tid(); i < XT_F2_EXP_ENTRIES; i += cx.nthreads()) {
-        const double sv = (double)(i & 31) * (XT_LN2 / 1024.0);
+        const double sv = (double)(i & 15) * (XT_LN2 / 1024.0);
         double q = 1.0 / 5040.0;
         q = xt_fma(q, sv, 1.0 / 720.0);
         q = xt_fma(q, sv, 1.0 / 120.0);
@@ -119,7 +119,7 @@ XT_HD void xt_f2_build_exp_table(Ctx& cx, char* lds, int off, const double* T32)
         q = xt_fma(q, sv, 0.5);
         q = xt_fma(q, sv, 1.0);
         q = xt_fma(q, sv, 1.0);
-        *(double*)(lds + off + i * 8) = T32[i >> 5] * q;
+        *(double*)(lds + off + i * 8) = T64[i >> 4] * q;
     }
 }
 
@@ -133,7 +133,7 @@ struct XtF2State {
 // from the zm address by a compile-time offset - the exponents ze too: they sit in 8-byte slots (upper half unused), which
 // saves the address arithmetic a packed int array would need in every step.
 #define XT_F2_EXPB_OFF 1024                                    /* the 1024-entry exp table of xt_exp_tab_x2, built per workgroup */
-#define XT_F2_TAB_BYTES (1024 + XT_F2_EXP_BYTES)               /* model blob (tables 288 B + the blob's 32-entry exp table 512 B, NaN flags) + that table */
+#define XT_F2_TAB_BYTES (1024 + XT_F2_EXP_BYTES)               /* model blob (tables 288 B + the blob's 64-entry exp table 512 B, NaN flags) + that table */
 #define XT_F2_T64_OFF ((XT_BLOB_HDR + XT_NTAB * 4) * 8)   /* the blob's T64 table (xt_tables.h) */
 #define XT_F2_NAN_OFF 832                                      /* int[XT_F2_WAVES][8]: track has a NaN position / sigma */
 #define XT_F2_ARR (XT_F2_WAVES * 128 * 8)                      /* bytes of one double field for all waves */

@@ -101,60 +101,49 @@ XT_HD int xt_lo32(double t)
     return (int)u.i;
 }
 
-// exp(x), x <= 0, table-driven: x = (32 e + j) ln2/32 + r, |r| <= ln2/64, exp(x) = 2^e * T[j] * p with p = P5(r).
-// T[j] = 2^(j/32), j < 32, is part of the model blob (xt_tables.h; the first 32 of its 64 table slots).  32 entries of 8 bytes cover every LDS
-// bank exactly once (64 banks x 4 B), so the table lookups of a wavefront never conflict - equal indices broadcast.  With the 64-entry
-// table of rounds 1 - 3 entries j and j + 32 shared a bank pair: 29 % of the headline kernel's LDS cycles were conflicts and a conflict-free
-// timing experiment ran 4 % faster (round 4).  P5: Taylor coefficients with the r^6 term folded into c2 / c4 (Chebyshev economisation on
-// |r| <= ln2/64): |rel err| < 1.5e-16 in exact arithmetic, 2.5e-16 evaluated in fp64 - the figures of the 64-entry Taylor version.
-// A NaN argument stays NaN.
-// Clamp of the exponent argument: n = 32 x / ln2 must fit int32 AND the sum of a sequence's exponent (>= XT_EMIN = -2^30) and n
-// must not wrap: |n| < 2^30 <=> x > -2.3e7.  A Gaussian exponent below -1.1e7 is a jump of more than 4 600 standard deviations
+// exp(x), x <= 0, table-driven: x = (64 e + j) ln2/64 + r, |r| <= ln2/128, exp(x) = 2^e * T64[j] * p with p = P5(r).
+// T64[j] = 2^(j/64) is part of the model blob (xt_tables.h).  |rel err| < 3e-16.  A NaN argument stays NaN.
+// (Round 4 tried a 32-entry table - one entry per LDS bank pair, no conflicts - with the r^6 term folded into the coefficients: same speed
+// in every kernel, but the two extra non-inline constants cost the wave-uniform threshold-fusion apply kernel 4 VGPRs, i.e. its second
+// workgroup per CU: reverted.)
+// Clamp of the exponent argument: n = 64 x / ln2 must fit int32 AND the sum of a sequence's exponent (>= XT_EMIN = -2^30) and n
+// must not wrap: |n| < 2^30 <=> x > -1.16e7.  A Gaussian exponent below -1.1e7 is a jump of more than 4 600 standard deviations
 // in one frame; such a sequence's weight is 2^(-1.5e7) instead of its true (even smaller) value.
 #define XT_TCLAMP (-1.1e7)
-#define XT_EXP_SCALE 46.16624130844683       // 32 / ln2
-#define XT_EXP_HI (-0.02166084898635745)     // -ln2 / 32, high part (trailing zero bits: n * HI is exact) ...
-#define XT_EXP_LO (-4.06140840434059e-10)    // ... and the rest
-#define XT_EXP_MASK 31
-#define XT_EXP_SHIFT 5
-#define XT_EXP_C5 8.33333333333333333333e-03
-#define XT_EXP_C4 0.041666911037706464       // 1/24 + (3/2) a^2 / 720,  a = ln2 / 64
-#define XT_EXP_C3 1.66666666666666666667e-01
-#define XT_EXP_C2 0.4999999999892509         // 1/2 - (9/16) a^4 / 720
 XT_HD void xt_exp_tab(double x, double& p, int& j, int& e)
 {
     x = x < XT_TCLAMP ? XT_TCLAMP : x;
-    const double tk = xt_fma(x, XT_EXP_SCALE, XT_MAGIC);
+    const double tk = xt_fma(x, 92.33248261689366, XT_MAGIC);
     const double kf = tk - XT_MAGIC;
-    double r = xt_fma(kf, XT_EXP_HI, x);
-    r = xt_fma(kf, XT_EXP_LO, r);
-    double q = XT_EXP_C5;
-    q = xt_fma(q, r, XT_EXP_C4);
-    q = xt_fma(q, r, XT_EXP_C3);
-    q = xt_fma(q, r, XT_EXP_C2);
+    double r = xt_fma(kf, -0.010830424493178725, x);
+    r = xt_fma(kf, -2.030704202170295e-10, r);
+    double q = 8.33333333333333333333e-03;
+    q = xt_fma(q, r, 4.16666666666666666667e-02);
+    q = xt_fma(q, r, 1.66666666666666666667e-01);
+    q = xt_fma(q, r, 0.5);
     q = xt_fma(q, r, 1.0);
     p = xt_fma(q, r, 1.0);
     const int n = xt_lo32(tk);
-    j = n & XT_EXP_MASK;
-    e = n >> XT_EXP_SHIFT;
+    j = n & 63;
+    e = n >> 6;
 }
 
-// The same with a degree-4 polynomial (r^5 folded into c1 / c3: |rel err| < 8e-14): posterior weights only.
+// The same with a degree-4 polynomial (|rel err| < 5e-14): posterior weights only.
 XT_HD void xt_exp_tab_fast(double x, double& p, int& j, int& e)
 {
     x = x < XT_TCLAMP ? XT_TCLAMP : x;
-    const double tk = xt_fma(x, XT_EXP_SCALE, XT_MAGIC);
+    const double tk = xt_fma(x, 92.33248261689366, XT_MAGIC);
     const double kf = tk - XT_MAGIC;
-    double r = xt_fma(kf, XT_EXP_HI, x);
-    r = xt_fma(kf, XT_EXP_LO, r);
+    double r = xt_fma(kf, -0.010830424493178725, x);
+    r = xt_fma(kf, -2.030704202170295e-10, r);
     double q = 4.16666666666666666667e-02;
-    q = xt_fma(q, r, 0.16666788852186565);   // 1/6 + (5/4) a^2 / 120
+    q = xt_fma(q, r, 1.66666666666666666667e-01);
     q = xt_fma(q, r, 0.5);
-    q = xt_fma(q, r, 0.9999999999641697);    // 1 - (5/16) a^4 / 120
+    q = xt_fma(q, r, 1.0);
     p = xt_fma(q, r, 1.0);
     const int n = xt_lo32(tk);
-    j = n & XT_EXP_MASK;
-    e = n >> XT_EXP_SHIFT;
+    j = n & 63;
+    e = n >> 6;
 }
 
 // den^(-D/2) for a scalar variance (K == 1) given r = 1/den.

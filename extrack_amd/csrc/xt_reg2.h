@@ -47,7 +47,7 @@ XT_HD int xt_r2_slot(int lane)
     return ts;
 }
 
-// LDS map (bytes): [model blob 1 KiB (as xt_fast2.h: tables, 32-entry exp table, NaN flags)] [1024-entry exp table 8 KiB] [tangent blocks NP x TB] [staged positions] [accumulators]
+// LDS map (bytes): [model blob 1 KiB (as xt_fast2.h: tables, T64, NaN flags)] [1024-entry exp table 8 KiB] [tangent blocks NP x TB] [staged positions] [accumulators]
 #define XT_R2_TAN0 XT_F2_TAB_BYTES
 #define XT_R2_TB 36  // xt_grad_tb_doubles(2, 2)
 #define XT_R2_MAXU 4  // uniform directions served by one launch (on top of its NP full ones)
@@ -341,7 +341,7 @@ XT_HD void xt_r2_body(const XtKernelArgs& a, const XtGradArgs& ga, Ctx& cx)
     for (int i = cx.tid(); i < NU * XT_R2_TB; i += cx.nthreads()) xt_at<double>(lds, XT_R2_TAN0 + (NP * XT_R2_TB + i) * 8) = ga.udblob[i];
     cx.sync();
     xt_f2_check_lds_base(lds);
-    xt_f2_build_exp_table(cx, lds, XT_F2_EXPB_OFF, (const double*)(lds + XT_F2_T64_OFF));  // the 1024-entry table of xt_exp_tab_x2 from the blob's 32 entries
+    xt_f2_build_exp_table(cx, lds, XT_F2_EXPB_OFF, (const double*)(lds + XT_F2_T64_OFF));  // the 1024-entry table of xt_exp_tab_x2 from the blob's 64 entries
     cx.sync();
     const double* hdr = smem;
 

@@ -89,7 +89,7 @@ static inline void xt_build_blob(const XtModelHost& m, const XtConfig& c, std::v
 {
     const int S = c.S, NS = c.NS, G = c.G;
     blob.assign((size_t)xt_tab_doubles(S, G), 0.0);
-    for (int j = 0; j < 64; ++j) blob[(size_t)XT_BLOB_HDR + (size_t)XT_NTAB * S * G + j] = j < 32 ? exp2((double)j / 32.0) : 0.0;  // exp table (xt_exp_tab): 32 entries, one per LDS bank pair
+    for (int j = 0; j < 64; ++j) blob[(size_t)XT_BLOB_HDR + (size_t)XT_NTAB * S * G + j] = exp2((double)j / 64.0);
     for (int k = 0; k < 3; ++k) {
         const double s = m.locerr[k < m.locerr_dims ? k : 0];
         blob[k] = s * s;
@@ -183,7 +183,7 @@ static inline std::string xt_th_build_blob(const XtModelHost& m, std::vector<dou
     for (int i = 0; i < NS; ++i) G *= S;
     G_out = G;
     blob.assign((size_t)xt_tab_doubles(S, G), 0.0);
-    for (int j = 0; j < 64; ++j) blob[(size_t)XT_BLOB_HDR + (size_t)XT_NTAB * S * G + j] = j < 32 ? exp2((double)j / 32.0) : 0.0;  // exp table (xt_exp_tab): 32 entries, one per LDS bank pair
+    for (int j = 0; j < 64; ++j) blob[(size_t)XT_BLOB_HDR + (size_t)XT_NTAB * S * G + j] = exp2((double)j / 64.0);
     for (int k = 0; k < 3; ++k) {
         const double s = m.locerr[k < m.locerr_dims ? k : 0];
         blob[k] = s * s;

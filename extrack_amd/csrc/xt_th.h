@@ -1297,7 +1297,10 @@ XT_HD void xt_th_plan_body(const XtThArgs& a, Ctx& cx)
 // ------------------------------------------------------------------------------------------------------------------
 // DT = true: per-track time steps (XtThBucket::dt) - a separate instantiation, so that the fixed-dt kernels keep their register
 // budget (the two extra VGPRs of the time step cost the wave-uniform variant one wave per SIMD, i.e. one of its two workgroups per CU).
-template <int D, int K, bool UNI, bool SINGLE, bool DT, class Ctx>
+// SEQ = true: also writes the per-sequence matrix of the last position (XtThBucket::seq_out, extrack_sequence_matrix_th) - a separate
+// instantiation of the general variant only: the log() of that branch, compiled into every variant, cost the wave-uniform kernel 10 VGPRs
+// and one wave per SIMD (2 states x 30: apply kernel 2.08 -> 3.25 ms, measured round 4) although the branch is never taken in a fit.
+template <int D, int K, bool UNI, bool SINGLE, bool DT, bool SEQ = false, class Ctx>
 XT_HD void xt_th_apply_body(const XtThArgs& a, Ctx& cx)
 {
     typedef XtThView<D, K, true> View;
@@ -1625,7 +1628,7 @@ XT_HD void xt_th_apply_body(const XtThArgs& a, Ctx& cx)
                     int j, n2;
                     xt_exp_tab(-quad, p, j, n2);
                     acc.add(zq * TF[o + r] * (gf * T64[j]) * p, eq + n2);
-                    if (bk.seq_out) {  // the reference's per-sequence matrix (tracking.py:632-650), before its leaving term: the caller expands that
+                    if (SEQ && bk.seq_out) {  // the reference's per-sequence matrix (tracking.py:632-650), before its leaving term: the caller expands that
                         const double wq = zq * TAB[(stay ? 1 : 0) * S * G + o + r] * (gf * T64[j]) * p;
                         bk.seq_out[(first + x) * (int64_t)bk.seq_stride + g * G + r] =
                             nanflag[x] ? NAN : (wq > 0.0 ? log(wq) + (double)(eq + n2) * XT_LN2 + bk.ll_const : (wq == 0.0 ? -INFINITY : NAN));
