@@ -350,7 +350,7 @@ def other_configs(device, no_cpu_baseline=False, no_fits=False):
         m16 = ts.make_model(np.array([[[LOCERR]]]), dsb, np.array([.25] * 4), Tsub, 0.1, tuple(CELL), 3, 4)
         w16, k16, v16 = timed(lambda: ts.loglik_th(m16, 0.2, 120, 2000), 2, warm=1)
         out["c5_loglik_threshold_ns3"] = {"what": "configs[4] model (4 states, nb_substeps 3, frame_len 4) through the threshold-fusion kernels: 16 384 expanded sequences "
-                                                  "at the second position, the plan kernel's per-step arrays in its global workspace",
+                                                  "at the second position, the plan kernel's per-step arrays in its global workspace, the apply kernel reads that step's member list from global memory",
                                           "ms_per_eval": w16 * 1e3, "kernel_ms": k16, "tracks_per_s": N5 / w16, "finite": bool(math.isfinite(v16)),
                                           "launch": ts.ctx.last_launch_info()}
     except Exception as e:  # noqa: BLE001

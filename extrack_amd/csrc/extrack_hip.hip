@@ -1385,6 +1385,9 @@ static int xt_th_run_group(extrack_ctx* ctx, const extrack_model* m, const std::
     // enough (always, for the usual 2-3 state models); TT = as many tracks as keep the tile within ~48 KiB of LDS
     a.capG = maxG;
     a.plan_cap = (size_t)sumE * 6 + 2 * (size_t)Lmax <= 24 * 1024 ? std::max(sumE, 1) : 0;
+    // a step whose member list alone would take more than 32 KiB of LDS (4 states x 3 substeps: 16 384 members at the second position): the
+    // general variants read the lists from global memory instead, which leaves the LDS to the state of more tracks per tile
+    if (a.plan_cap == 0 && (size_t)maxG * G * 6 > 32 * 1024 && !getenv("EXTRACK_TH_NO_DIRECT")) a.plan_cap = -1;
     auto lds_of = [&](int tt, bool single = false) {
         return (size_t)xt_th_apply_lds_doubles(S, G, maxG, tt, D, K, a.locerr_mode ? a.KS : 0, Lmax, a.plan_cap, tt == 64, single) * 8;
     };

@@ -133,7 +133,7 @@ struct XtThArgs {
     int32_t TT, logTT;     // apply kernel: tracks per workgroup tile (power of two)
     int32_t capG;          // apply kernel: parent-sequence capacity of the LDS buffers
     int32_t bpc;           // apply kernel: workgroups per chunk (a workgroup serves tiles of ONE chunk)
-    int32_t plan_cap;      // apply kernel: members of ALL merged steps kept in LDS (0: the plan is streamed step by step)
+    int32_t plan_cap;      // apply kernel: members of ALL merged steps kept in LDS (0: the plan is streamed step by step; < 0: read from global memory)
     // Position refinement (extrack/refined_localization.py:48-204 get_LC_Km_Ks): the prediction-mode plan kernel run on ONE chunk
     // (the whole bucket) records, after every position, each track's surviving sequences instead of reading out posteriors.
     int32_t refine;        // 1: record mode; every workgroup repeats the pilot pass (same plan) and serves its share of the other tracks
@@ -305,8 +305,10 @@ XT_HD int xt_th_apply_lds_doubles(int S, int G, int capG, int TT, int D, int K, 
     const int capEl = capG * G;
     // plan region: member words + group starts (+ per-step offsets) for all steps (plan_cap > 0) or for one step;
     // none in the wave-uniform mode (scalar loads from global memory)
-    const int pm = uni ? 0 : (plan_cap > 0 ? plan_cap : capEl);
-    const int pg = uni ? 0 : (plan_cap > 0 ? plan_cap + L : capEl + 1);
+    // plan_cap < 0 ("direct"): the general variants read the member lists straight from global memory - for models whose largest step
+    // (n_states^(nb_substeps + 1) parents x n_states^nb_substeps digits: 16 384 members for 4 states x 3 substeps) would fill the LDS on its own
+    const int pm = (uni || plan_cap < 0) ? 0 : (plan_cap > 0 ? plan_cap : capEl);
+    const int pg = (uni || plan_cap < 0) ? 0 : (plan_cap > 0 ? plan_cap + L : capEl + 1);
     const int bytes = 4 * pm + 2 * pg + 16 * L + capG + 4 * TT + 16;
     return ((xt_tab_doubles(S, G) + 1) & ~1) + (single ? 1 : 2) * (int)xt_th_buf_doubles(plane, D, K) + XT_TH_STAGE * (D + KS) * (TT + 1) + TT +
            (bytes + 7) / 8 + 2;
@@ -1344,8 +1346,9 @@ XT_HD void xt_th_apply_body(const XtThArgs& a, Ctx& cx)
     double* red = w;
     w += TT;
     const bool resident = !UNI && a.plan_cap > 0;
-    const int pmcap = UNI ? 0 : (resident ? a.plan_cap : capEl);
-    const int pgcap = UNI ? 0 : (resident ? a.plan_cap + Lmax : capEl + 1);
+    const bool direct = !UNI && a.plan_cap < 0;  // member lists read from global memory (no LDS copy)
+    const int pmcap = (UNI || direct) ? 0 : (resident ? a.plan_cap : capEl);
+    const int pgcap = (UNI || direct) ? 0 : (resident ? a.plan_cap + Lmax : capEl + 1);
     int* nanflag = (int*)w;
     int* pstep = nanflag + TT;               // [L][4]: member offset, gstart offset, nE, nG
     uint32_t* pmem = (uint32_t*)(pstep + 4 * Lmax);
@@ -1511,9 +1514,9 @@ XT_HD void xt_th_apply_body(const XtThArgs& a, Ctx& cx)
             for (int t = 1; t <= L - 2; ++t) {
                 if ((t & (XT_TH_STAGE - 1)) == 0) stage(t);
                 const int nE = pstep[t * 4 + 2], nG = pstep[t * 4 + 3];
-                const uint32_t* mem = pmem + pstep[t * 4];
-                const uint16_t* gst = pgst + pstep[t * 4 + 1];
-                if (!resident) {
+                const uint32_t* mem = direct ? mpk_g + (int64_t)t * capE : pmem + pstep[t * 4];
+                const uint16_t* gst = direct ? gst_g + (int64_t)t * (capE + 1) : pgst + pstep[t * 4 + 1];
+                if (!resident && !direct) {
                     for (int i = tid; i < nE; i += nt) pmem[i] = mpk_g[(int64_t)t * capE + i];
                     for (int i = tid; i <= nG; i += nt) pgst[i] = gst_g[(int64_t)t * (capE + 1) + i];
                     cx.sync();
@@ -1560,9 +1563,9 @@ XT_HD void xt_th_apply_body(const XtThArgs& a, Ctx& cx)
             if (t < L - 1) {
                 const int nE = UNI ? hdr_u[t * 2] : pstep[t * 4 + 2];
                 const int nG = UNI ? hdr_u[t * 2 + 1] : pstep[t * 4 + 3];
-                const typename CU32::type mem = CU32::make(UNI ? mpk_g + (int64_t)t * capE : pmem + pstep[t * 4]);
-                const typename CU16::type gst = CU16::make(UNI ? gst_g + (int64_t)t * (capE + 1) : pgst + pstep[t * 4 + 1]);
-                if (!UNI && !resident) {
+                const typename CU32::type mem = CU32::make((UNI || direct) ? mpk_g + (int64_t)t * capE : pmem + pstep[t * 4]);
+                const typename CU16::type gst = CU16::make((UNI || direct) ? gst_g + (int64_t)t * (capE + 1) : pgst + pstep[t * 4 + 1]);
+                if (!UNI && !resident && !direct) {
                     for (int i = tid; i < nE; i += nt) pmem[i] = mpk_g[(int64_t)t * capE + i];
                     for (int i = tid; i <= nG; i += nt) pgst[i] = gst_g[(int64_t)t * (capE + 1) + i];
                 }

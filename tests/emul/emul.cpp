@@ -492,7 +492,7 @@ extern "C" int xt_emul_th_run(const double* tracks, const double* sigma, long lo
     while ((1 << a.logTT) < TT) ++a.logTT;
     // nblocks doubles as "workgroups per chunk"; a negative value asks for the streamed-plan mode
     a.bpc = nblocks < 0 ? -nblocks : nblocks;
-    a.plan_cap = nblocks < 0 ? 0 : (sumE > 0 ? sumE : 1);
+    a.plan_cap = nblocks < 0 ? (getenv("XT_EMUL_TH_DIRECT") ? -1 : 0) : (sumE > 0 ? sumE : 1);  // streamed through LDS, or (direct) read from global memory
     const int grid = a.nchunks * a.bpc;
     std::vector<double> partials(grid, 0.0);
     a.partials = partials.data();

@@ -73,7 +73,8 @@ def test_th_plan_many_sequences_wrapped_classes(threshold, max_nb, threads, stag
     assert np.abs(ll - ref).max() < 1e-10
 
 
-@pytest.mark.parametrize("variant", ["general", "streamed", "uniform", "uniform_single", "general_single", "general_single_streamed", "lds_workspace"])
+@pytest.mark.parametrize("variant", ["general", "streamed", "direct", "uniform", "uniform_single", "general_single", "general_single_streamed", "general_single_direct",
+                                     "lds_workspace"])
 def test_th_apply_variants_chunked(variant, monkeypatch):
     """Two chunks (the second ragged), 3 states, per-peak errors: every apply-kernel variant and the LDS-resident plan workspace."""
     E = _emul()
@@ -89,16 +90,20 @@ def test_th_apply_variants_chunked(variant, monkeypatch):
     ps = p_stay_table(ds, S, ns, [0.8])
     ref = np.concatenate([OT.proba_cs_th(Cs[a:a + chunk], LE[a:a + chunk], ds, Fs, T, 0.07, 1, [0.8], ns, F, 3, 0.2, 30) for a in range(0, N, chunk)])
     kw = dict(chunk=chunk, capE=128, TT=8, threads=128, nblocks=2)
-    if variant == "streamed":
+    if variant in ("streamed", "direct"):
         kw["nblocks"] = -2
+        if variant == "direct":  # member lists read from global memory (what the launcher takes when one step's list would fill the LDS)
+            monkeypatch.setenv("XT_EMUL_TH_DIRECT", "1")
     elif variant == "uniform":
         kw.update(TT=64, threads=256)
     elif variant == "uniform_single":
         kw.update(TT=64, threads=256)
         monkeypatch.setenv("XT_EMUL_TH_SINGLE", "1")
-    elif variant in ("general_single", "general_single_streamed"):
-        kw.update(TT=8, threads=128, nblocks=-2 if variant.endswith("streamed") else 2)
+    elif variant in ("general_single", "general_single_streamed", "general_single_direct"):
+        kw.update(TT=8, threads=128, nblocks=2 if variant == "general_single" else -2)
         monkeypatch.setenv("XT_EMUL_TH_SINGLE", "1")
+        if variant.endswith("direct"):
+            monkeypatch.setenv("XT_EMUL_TH_DIRECT", "1")
     elif variant == "lds_workspace":
         monkeypatch.setenv("XT_EMUL_TH_WSP", "24")
         monkeypatch.setenv("XT_EMUL_TH_WSE", "60")
