@@ -47,7 +47,7 @@ with open(root + "/pmc_summary.txt", "w") as out:
         if g("FETCH_SIZE") is not None and g("WRITE_SIZE") is not None:
             out.write("%-66s %-24s %.1f MB   (2 x FETCH_SIZE + WRITE_SIZE, KB -> bytes; gfx950 correction)\n" % (k, "=> HBM traffic/launch", (2 * g("FETCH_SIZE") + g("WRITE_SIZE")) * 1024 / 1e6))
 # ---- the headline workload alone: xt_ll_r2_kernel<6,2,1> also serves the 1e7-track c4 run of `scaling_runs` and the full-size fits; the
-# launches that open each pass (1 warm-up + 3 timed, 1e6 tracks x 30) are the bench's timed region
+# 4 launches that open each pass (1e6 tracks x 30: the bench's clock-settle launches of the headline workload) are that workload alone
 with open(root + "/pmc_summary.txt", "a") as out:
     per = {}
     for f in sorted(glob.glob(root + "/p*/**/*counter_collection.csv", recursive=True)):
@@ -55,7 +55,7 @@ with open(root + "/pmc_summary.txt", "a") as out:
         for c in set(r["Counter_Name"] for r in rows):
             rr = sorted([r for r in rows if r["Counter_Name"] == c], key=lambda r: int(r["Dispatch_Id"]))[:4]
             per[c] = sum(float(r["Counter_Value"]) for r in rr) / len(rr)
-    out.write("\nHEADLINE WORKLOAD ONLY (first 4 launches of every pass: 1e6 tracks x 30, the bench's timed region)\n")
+    out.write("\nHEADLINE WORKLOAD ONLY (first 4 launches of every pass: 1e6 tracks x 30, the workload of the bench's timed region)\n")
     for c, v in sorted(per.items()):
         out.write("%-66s %-24s n=4 mean=%.6g\n" % ("xt_ll_r2_kernel<6, 2, 1> [1e6 x 30]", c, v))
     if "FETCH_SIZE" in per and "WRITE_SIZE" in per:
@@ -68,9 +68,9 @@ for f in glob.glob(root + "/trace/**/*kernel_trace.csv", recursive=True):
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in rows]
     big = [d for d in dur if d > 1e6]          # the 1e6-track launches (the gradient section launches small ones too)
-    timed = big[3:23]                          # bench.py: 3 warm-up + 20 timed launches come first
+    timed = big[27:47]                         # bench.py: 24 clock-settle launches + 3 warm-up steps, then the 20 timed launches
     with open(root + "/headline_timed_launches.txt", "w") as out:
-        out.write("xt_ll_r2_kernel<6,2,1>: %d launches of the 1e6-track bucket in the trace; the 20 timed ones (after 3 warm-up):\n" % len(big))
+        out.write("xt_ll_r2_kernel<6,2,1>: %d launches of the 1e6-track bucket in the trace; the 20 timed ones (after 24 clock-settle launches + 3 warm-up steps):\n" % len(big))
         out.write("  mean %.1f us  min %.1f us  max %.1f us\n" % (sum(timed) / len(timed) / 1e3, min(timed) / 1e3, max(timed) / 1e3))
         out.write("  all (us): " + " ".join("%.0f" % (d / 1e3) for d in big) + "\n")
 PY
