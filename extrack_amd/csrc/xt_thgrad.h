@@ -61,6 +61,92 @@ struct XtThgAdj {
     XT_HD double& ub(int k, int g, int x) const { return base[((int64_t)g * (1 + D + K) + 1 + D + k) * 64 + x]; }
 };
 
+// One merge group of one track gathered straight from the LOG of the step before: every member's parent is integrated with position `c`
+// in registers on the way (tracking.py:76-98), so the integrated sequences Y never go through memory - the kernel is bound by the traffic of its
+// global state, the G-fold repeated exponential is free (VALU busy 0.08).  ONE pass over the members with a running exponent: the sums are
+// rescaled by exact powers of two, so the result is the one xt_th_gather_regs computes from a stored Y.
+template <int D, int K, class V>
+XT_HD void xt_thg_load_integrated(const V& X, int idx, const double* c, const double* l2, const double* T64, double& z, int& e, double* m, double* u)
+{
+    z = X.zm(idx);
+    e = X.ze(idx);
+    for (int d = 0; d < D; ++d) m[d] = X.m(d, idx);
+    for (int k = 0; k < K; ++k) u[k] = X.u(k, idx);
+    double dm[D], dsq = 0.0;
+    for (int d = 0; d < D; ++d) {
+        dm[d] = c[d] - m[d];
+        dsq = xt_fma(dm[d], dm[d], dsq);
+    }
+    double quad, gf, tt[K];
+    if (K == 1) {
+        const double r = xt_rcp(l2[0] + u[0]);
+        tt[0] = u[0] * r;
+        quad = 0.5 * dsq * r;
+        gf = xt_pow_half<D>(r);
+    } else {
+        quad = 0.0;
+        gf = 1.0;
+        for (int d = 0; d < D; ++d) {
+            const double r = xt_rcp(l2[d] + u[d]);
+            tt[d] = u[d] * r;
+            quad = xt_fma(0.5 * dm[d] * dm[d], r, quad);
+            gf *= r;
+        }
+        gf = sqrt(gf);
+    }
+    double p;
+    int j, n;
+    xt_exp_tab(-quad, p, j, n);
+    const double z0 = z;
+    z = z0 * (gf * T64[j]) * p;
+    const int en = e + n;
+    e = (z0 != 0.0 && en > XT_EMIN) ? en : XT_EMIN;
+    for (int d = 0; d < D; ++d) m[d] = xt_fma(dm[d], tt[K == 1 ? 0 : d], m[d]);
+    for (int k = 0; k < K; ++k) u[k] = l2[k] * tt[k];
+}
+template <int D, int K, class V, class MemP, class TabP>
+XT_HD void xt_thg_gather_int(const V& X, int xoff, MemP members, int k0, int k1, TabP TT, TabP TD2, const double* c, const double* l2,
+                             const double* T64, double& W, int& E, double* M, double* U)
+{
+    if (k1 - k0 == 1) {
+        const uint32_t pk = members[k0];
+        const int o = (int)(pk & 0xffffu);
+        double z;
+        xt_thg_load_integrated<D, K>(X, (int)(pk >> 16) * 64 + xoff, c, l2, T64, z, E, M, U);
+        W = z * TT[o];
+        for (int k = 0; k < K; ++k) U[k] += TD2[o];
+    } else {
+        E = XT_EMIN;
+        W = 0.0;
+        for (int d = 0; d < D; ++d) M[d] = 0.0;
+        for (int k = 0; k < K; ++k) U[k] = 0.0;
+        for (int kk = k0; kk < k1; ++kk) {
+            const uint32_t pk = members[kk];
+            const int o = (int)(pk & 0xffffu);
+            double z, m[D], u[K];
+            int e;
+            xt_thg_load_integrated<D, K>(X, (int)(pk >> 16) * 64 + xoff, c, l2, T64, z, e, m, u);
+            if (e > E) {  // a larger exponent: what has been summed moves to the new scale (exact; from XT_EMIN the zero sums stay zero)
+                const int sh = E - e;
+                W = xt_ldexp(W, sh);
+                for (int d = 0; d < D; ++d) M[d] = xt_ldexp(M[d], sh);
+                for (int k = 0; k < K; ++k) U[k] = xt_ldexp(U[k], sh);
+                E = e;
+            }
+            const double av = xt_ldexp(z * TT[o], e - E);  // hugely negative shift saturates to 0
+            W += av;
+            for (int d = 0; d < D; ++d) M[d] = xt_fma(av, m[d], M[d]);
+            for (int k = 0; k < K; ++k) U[k] = xt_fma(av, TD2[o] + u[k], U[k]);
+        }
+        const double rW = (W == 0.0) ? 0.0 : xt_rcp(W);
+        for (int d = 0; d < D; ++d) M[d] *= rW;
+        for (int k = 0; k < K; ++k) U[k] *= rW;
+    }
+    const bool live = W != 0.0;
+    E = live ? E + xt_frexp_exp(W) : XT_EMIN;
+    W = xt_frexp_mant(W);
+}
+
 // RG: the table-adjoint rows live in the wavefront's scratch region (global memory) instead of LDS - a compile-time choice so that the
 // LDS variant keeps LDS-typed accesses (a run-time select makes them flat: measured +20 %)
 template <int D, int K, bool RG, class Ctx>
@@ -187,15 +273,30 @@ XT_HD void xt_thg_body(const XtThArgs& a, const XtThGradArgs& ga, Ctx& cx)
         }
         int nPar = S;
         for (int t = 1; t <= L - 2; ++t) {
-            if (t >= 2) integrate_all(t - 1, nPar);
-            const View src = t >= 2 ? Y : logv(0);
             const View dst = logv(t);
             const int nG = hdr_g[t * 2 + 1];
             const typename CU32::type mem = mpk_g + (int64_t)t * capE;
             const typename CU16::type gst = gst_g + (int64_t)t * (capE + 1);
             const bool stay = t >= 2 && t >= a.min_len;
             const typename CD::type TTl = TAB + (stay ? 1 : 0) * SG;
-            for (int g2 = 0; g2 < nG; ++g2) xt_th_gather<D, K>(src, 64, x, mem, (int)gst[g2], (int)gst[g2 + 1], TTl, TD2, dst, g2 * 64 + x);
+            if (t >= 2) {  // X_t from X_{t-1}: position t - 1 integrated into every member's parent on the way (Y_{t-1} is never stored)
+                const View src = logv(t - 1);
+                double c[D], l2[K];
+                load_pos(t - 1, c);
+                load_l2(t - 1, l2);
+                for (int g2 = 0; g2 < nG; ++g2) {
+                    double W, M[D], U[K];
+                    int E;
+                    xt_thg_gather_int<D, K>(src, x, mem, (int)gst[g2], (int)gst[g2 + 1], TTl, TD2, c, l2, T64, W, E, M, U);
+                    const int di = g2 * 64 + x;
+                    dst.zm(di) = W;
+                    dst.ze(di) = E;
+                    for (int d = 0; d < D; ++d) dst.m(d, di) = M[d];
+                    for (int k = 0; k < K; ++k) dst.u(k, di) = U[k];
+                }
+            } else {  // X_1 from X_0, which is used as it is
+                for (int g2 = 0; g2 < nG; ++g2) xt_th_gather<D, K>(logv(0), 64, x, mem, (int)gst[g2], (int)gst[g2 + 1], TTl, TD2, dst, g2 * 64 + x);
+            }
             nPar = nG;
         }
         // ---- last position (+ leaving / bleaching term, tracking.py:611-633)

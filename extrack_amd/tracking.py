@@ -24,6 +24,8 @@ keyword ``fusion``:
 ``workers`` is accepted and ignored: the tracks are sharded over GPUs instead (extrack_amd.distributed).
 """
 import os
+import sys
+import time
 
 import numpy as np
 from scipy import linalg
@@ -561,7 +563,11 @@ def _fit_threshold_frozen_plan(params, fargs, method, ts, max_rounds=6):
             kw = {}
             if hinv is not None and str(method).lower() == "bfgs":
                 kw["options"] = {"hess_inv0": hinv}
+            t_round = time.perf_counter()
             fit = lmfit_compat.minimize_with_gradient(cum_Proba_Cs, cur, args=fargs, method=method, nan_policy="propagate", fcn_grad=cum_Proba_Cs_grad, **kw)
+            if os.environ.get("EXTRACK_FIT_TRACE"):
+                sys.stderr.write("[fit] plan round %d: %d + %d calls, %.3f s, frozen objective %.6f\n" % (
+                    rounds, int(fit.nfev), int(getattr(fit, "ngev", 0)), time.perf_counter() - t_round, float(fit.residual[0])))
             h = getattr(getattr(fit, "scipy_result", None), "hess_inv", None)
             hinv = None
             if isinstance(h, np.ndarray) and np.all(np.isfinite(h)):
